@@ -1,0 +1,178 @@
+/* plaidhip.h -- C ABI of the MI355X-native gene-set scoring hot path.
+ *
+ * Drop-in boundary for the R package bigomics/plaid (reference @ 2025-06-14).  The
+ * reference has NO native interface (NAMESPACE:1-16 has no useDynLib, there is no src/);
+ * the seam is therefore inside the R functions named below, whose BODIES are replaced by
+ * `.Call()` into this library while their R signatures stay (see INTEGRATION.md and
+ * r-pkg/).  Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no R / torch / HIP types in any signature; `void*` device pointers.
+ *   - matrices use R layout: column-major `double`; sparse = dgCMatrix slots
+ *     (`p` int32[ncol+1], `i` int32[nnz] 0-based sorted, `x` double[nnz]).
+ *   - every function returns a status code (0 = ok); the text of the last error of the
+ *     calling thread is available from plaidhip_last_error_string().  Nothing throws.
+ *   - element offsets are 64-bit: m*n may exceed 2^31-1 (the reason R/plaid.R:103-104
+ *     chunks).
+ *   - `host` entry points take caller-owned host buffers, stage them through HBM and
+ *     synchronise before returning (R's .Call contract).  `dev` entry points take
+ *     device pointers, enqueue on the context's stream and do NOT synchronise.
+ */
+#ifndef PLAIDHIP_H
+#define PLAIDHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLAIDHIP_VERSION 100 /* 0.1.0 */
+
+enum plaidhip_status {
+  PLAIDHIP_OK = 0,
+  PLAIDHIP_EINVAL = 1,       /* bad dimensions / arguments (R: stop())            */
+  PLAIDHIP_ENOMEM = 2,       /* device or host allocation failed                  */
+  PLAIDHIP_EHIP = 3,         /* a HIP runtime call or kernel failed               */
+  PLAIDHIP_EUNSUPPORTED = 4, /* shape outside what the kernels cover              */
+  PLAIDHIP_ENODEVICE = 5     /* no gfx950 device visible                          */
+};
+
+enum plaidhip_stat { PLAIDHIP_STAT_MEAN = 0, PLAIDHIP_STAT_SUM = 1 }; /* R/plaid.R:60 `stats` */
+enum plaidhip_ties {                                                   /* R/plaid.R:593 `ties.method` */
+  PLAIDHIP_TIES_AVERAGE = 0,
+  PLAIDHIP_TIES_MIN = 1,
+  PLAIDHIP_TIES_MAX = 2
+};
+enum plaidhip_ignore_zero { /* R/plaid.R:554 `ignore.zero`: NULL / FALSE / TRUE */
+  PLAIDHIP_IGNORE_ZERO_AUTO = -1,
+  PLAIDHIP_IGNORE_ZERO_FALSE = 0,
+  PLAIDHIP_IGNORE_ZERO_TRUE = 1
+};
+
+/* `flags` arguments are device arrays of 4 uint32 words set to 0/1 by the SpMM epilogue /
+ * plaidhip_dev_minflags (the caller zeroes them first): [0] a value < 0 was seen, [1] an exact
+ * zero, [2] a NaN, [3] reserved.  0/1 words so that a sample-sharded host can all-reduce(MAX)
+ * them in place.  min(x, na.rm=TRUE) == 0  <=>  flags[1] && !flags[0]   (R/plaid.R:556-557).
+ * The PLAIDHIP_FLAG_* bits are the in-kernel encoding (bit b <-> word b).                    */
+#define PLAIDHIP_FLAG_HAS_NEG 1u
+#define PLAIDHIP_FLAG_HAS_ZERO 2u
+#define PLAIDHIP_FLAG_HAS_NAN 4u
+
+typedef struct plaidhip_ctx plaidhip_ctx;         /* device, stream, workspace           */
+typedef struct plaidhip_geneset plaidhip_geneset; /* device-resident prepared membership */
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+int plaidhip_version(void);
+const char* plaidhip_last_error_string(void);
+int plaidhip_device_count(int* count);
+/* `stream`: an existing hipStream_t to enqueue on (e.g. the host framework's current
+ * stream) or NULL to create a private one. */
+int plaidhip_init(int device, void* stream, plaidhip_ctx** out);
+int plaidhip_finalize(plaidhip_ctx* ctx);
+int plaidhip_synchronize(plaidhip_ctx* ctx);
+/* device memory helpers for hosts without a tensor library (R) */
+int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr);
+int plaidhip_free(plaidhip_ctx* ctx, void* dptr);
+int plaidhip_memcpy_h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int plaidhip_memcpy_d2h(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- gene-set membership G (replaces R/plaid.R:72-77 on `gmt2mat()` output,
+ *      R/gmt-utils.R:19-66).  The caller passes the CSC pattern of the ALIGNED,
+ *      binarised membership: column j lists the rows OF X (0-based, < g) that belong to
+ *      set j, i.e. `matG[gg,] != 0` re-indexed into X's row space (R/plaid.R:65-73) --
+ *      X itself is never row-gathered.  Explicit zeros must already be dropped.
+ *      Set sizes (colSums(G), R/plaid.R:75) are the column lengths. ------------------- */
+int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp,
+                            const int32_t* Gi, plaidhip_geneset** out);
+int plaidhip_geneset_destroy(plaidhip_geneset* gs);
+/* info[0]=g info[1]=m info[2]=z (nnz) info[3]=padded index slots info[4]=tiles
+ * info[5]=1 if the LDS-resident column kernel is usable for f64 at this g             */
+int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]);
+
+/* ---- device-level hot path (pointers are device pointers) --------------------------- */
+
+/* S = alpha * (G^T X) (.) w + beta * (k (.) w):  the crossprod of R/plaid.R:80,107 with
+ * the column scaling of R/plaid.R:74-77 folded into the epilogue.  w_j = 1/(1e-8 + k_j)
+ * for STAT_MEAN, 1 for STAT_SUM; k_j = size of set j.  alpha=1, beta=0 is plaid() itself;
+ * (alpha, beta) = (1/nrow(X), -0.5) applied to raw ranks is replaid.sing (R/plaid.R:216),
+ * (1/max(rX), -0.5) is replaid.ssgsea (R/plaid.R:251) -- by linearity of the crossprod.
+ * X: g x n column-major, leading dimension ldx; S: m x n column-major, leading dim lds.
+ * `alpha_div` (device double*, may be NULL): alpha is divided by *alpha_div on the device, so
+ * the global max(rX) never visits the host.  `flags` (device uint32[4], may be NULL): see above. */
+int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
+                                int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
+                                double beta, void* S, int64_t lds, void* flags);
+/* same with X as CSC (dgCMatrix) -- sparse branch of Matrix::crossprod at R/plaid.R:107. */
+int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
+                              const void* Xi, const void* Xx, int32_t n, int stat, double alpha,
+                              const void* alpha_div, double beta, void* S, int64_t lds, void* flags);
+
+/* colranks(), dense branch: t(matrixStats::colRanks(as.matrix(X), ties.method))
+ * (R/plaid.R:611-619); `is_signed` = sign(X)*rank(|X|) (R/plaid.R:612-615).  Optional fused
+ * power transform rank^power (R/plaid.R:249, power = 1+alpha; pass 1.0 for none).
+ * R: g x n doubles (same layout as X).  colmax (device double[n], may be NULL) receives the
+ * per-column maximum of the written values (feeds max(rX), R/plaid.R:251).              */
+int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ldx, int32_t g,
+                                    int32_t n, int ties, int is_signed, double power, void* R,
+                                    int64_t ldr, void* colmax);
+/* sparse_colranks() (R/plaid.R:631-650): ranks of the stored non-zeros of each CSC column
+ * among themselves; only @x is produced, pattern unchanged (R/plaid.R:645-646).          */
+int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
+                                  int ties, int is_signed, double power, void* Rx, void* colmax);
+
+/* normalize_medians() (R/plaid.R:554-575) in three phases so that a sample-sharded host
+ * can all-reduce between them:
+ *   1. flags  : plaidhip_dev_minflags   (or the SpMM epilogue's `flags`)  -> ignore.zero
+ *   2. medians: plaidhip_dev_col_medians  (zeros masked when ignore_zero, all-masked
+ *               column -> 0, R/plaid.R:561-566).  ignore_zero = 0 / 1, or -1 to resolve
+ *               min(x)==0 on the device from `flags`.  plaidhip_dev_sum -> {sum, #non-NaN}.
+ *   3. shift  : x - med[col] + add  (R/plaid.R:572); with `red` (device double[2] = {sum,
+ *               count}) non-NULL, add = red[0]/red[1] is taken on the device instead.
+ * Nothing in the chain needs a host round trip.                                           */
+int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags);
+int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n,
+                             int ignore_zero, const void* flags, void* med);
+int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[2]: sum, #non-NaN */);
+int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,
+                               const void* med, double add, const void* red);
+/* max over a device double vector (global max(rX), R/plaid.R:251) */
+int plaidhip_dev_max(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[1] */);
+
+/* ---- host-level entry points: what the R `.Call` shim binds (r-pkg/src/plaidhip_R.c) -- */
+
+/* plaid(X, matG, stats, chunk=NULL, normalize) body, R/plaid.R:73-85, dense X.
+ * S_out: m x n doubles, caller-allocated.                                               */
+int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                         const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize,
+                         double* S_out);
+/* same for a dgCMatrix X */
+int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                       int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                       int stat, int normalize, double* S_out);
+/* normalize_medians(x, ignore.zero), R/plaid.R:554-575, in place; med_out (n) may be NULL */
+int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,
+                               double* med_out);
+/* colranks(X, signed, ties.method), dense branch R/plaid.R:611-619 */
+int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, int ties,
+                            int is_signed, double* R_out);
+/* sparse_colranks(X, signed, ties.method), R/plaid.R:631-650: Rx_out has Xp[n] entries */
+int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
+                          int ties, int is_signed, double* Rx_out);
+/* replaid.sing body, R/plaid.R:215-217 (dense X; G aligned to X's rows as above)         */
+int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                        const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out);
+/* replaid.ssgsea body, R/plaid.R:245-253, dense X                                        */
+int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                          const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
+                          double* S_out);
+/* replaid.ssgsea body for a dgCMatrix X (rank step = sparse_colranks, R/plaid.R:600-601)  */
+int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                        int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                        double alpha, double* S_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAIDHIP_H */

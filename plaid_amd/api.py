@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference's R API for the scoring hot path.
+
+Same function names (dots -> underscores), argument meaning, defaults, dimnames and error
+behaviour as R/plaid.R; the BODIES call the HIP library through the C ABI
+(include/plaidhip.h).  There is no CPU compute path in here: gene-name alignment and
+dimnames handling are host glue, everything numeric runs on the MI355X.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+from ._lib import EUNSUPPORTED, PlaidHipError
+from .engine import Context, default_context
+from .matrix import NamedMatrix, as_named
+
+INT_MAX = 2147483647  # .Machine$integer.max
+_TIES = ("average", "min", "max")
+
+
+def _message(txt: str):
+    print(txt, file=sys.stderr)   # R message()
+
+
+def _first_pos(names):
+    pos = {}
+    for k, nm in enumerate(names):
+        pos.setdefault(nm, k)
+    return pos
+
+
+def aligned_pattern(X: NamedMatrix, matG: NamedMatrix):
+    """Gene alignment + binarisation of R/plaid.R:65-73 without copying X:
+    gg = intersect(rownames(X), rownames(matG)); G = 1*(matG[gg,] != 0), returned as a CSC
+    pattern (Gp, Gi) whose row indices address X's rows.  None when nothing overlaps."""
+    posx = _first_pos(X.rownames)
+    G = sp.csc_matrix(matG.values)
+    g2x = np.full(G.shape[0], -1, dtype=np.int64)
+    seen = set()
+    for k, nm in enumerate(matG.rownames):
+        if nm in seen:
+            continue                      # matG[gg,] picks the first row of that name
+        seen.add(nm)
+        r = posx.get(nm)
+        if r is not None:
+            g2x[k] = r
+    if not np.any(g2x >= 0):
+        return None
+    new_idx = g2x[G.indices]
+    keep = (new_idx >= 0) & (G.data != 0)
+    m = G.shape[1]
+    col = np.repeat(np.arange(m, dtype=np.int64), np.diff(G.indptr))
+    counts = np.bincount(col[keep], minlength=m)
+    Gp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts, out=Gp[1:])
+    if Gp[-1] > INT_MAX:
+        raise PlaidHipError(EUNSUPPORTED, "membership matrix has more than 2^31-1 entries")
+    return Gp.astype(np.int32), new_idx[keep].astype(np.int32)
+
+
+def _auto_chunk(ncol_x: int) -> int:
+    return int(np.round(0.8 * INT_MAX / max(ncol_x, 1)))     # R/plaid.R:103-104
+
+
+def plaid(X, matG, stats=("mean", "sum"), chunk=None, normalize=True, ctx: Context | None = None):
+    """plaid(), R/plaid.R:60-87.  Returns a NamedMatrix (sets x samples) or None with a
+    message when no features overlap (:66-69)."""
+    stats = stats if isinstance(stats, str) else stats[0]     # :62
+    if stats not in ("mean", "sum"):
+        raise ValueError("stats must be 'mean' or 'sum'")
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    Gp, Gi = pat
+    ctx = ctx or default_context()
+    g, n = X.shape
+    m = matG.shape[1]
+    auto = _auto_chunk(m)                                     # plaid passes chunk=NULL (:80)
+    if n < auto:
+        S = _crossprod_block(ctx, X, 0, n, Gp, Gi, stats, normalize)
+    else:
+        _message(f"[chunked_crossprod] chunked compute: chunk = {auto}")
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        for j0 in range(0, n, auto):                          # :115-119
+            j1 = min(n, j0 + auto)
+            S[:, j0:j1] = _crossprod_block(ctx, X, j0, j1, Gp, Gi, stats, False)
+        if normalize:
+            S, _ = ctx.normalize_medians(S)                   # :83
+    return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+def _crossprod_block(ctx, X: NamedMatrix, j0, j1, Gp, Gi, stats, normalize):
+    if X.is_sparse:
+        V = X.values[:, j0:j1] if (j0, j1) != (0, X.shape[1]) else X.values
+        return ctx.plaid_csc(V.indptr, V.indices, V.data, X.shape[0], Gp, Gi, stats, normalize)
+    return ctx.plaid_dense(X.values[:, j0:j1], Gp, Gi, stats, normalize)
+
+
+def chunked_crossprod(x, y, chunk=None, ctx: Context | None = None):
+    """chunked_crossprod(), R/plaid.R:100-123: t(x) %*% y, `x` the genes x sets membership
+    (binary, optionally column-scaled as plaid() builds it, :73-77), `y` genes x samples with
+    the same rows.  Arbitrary per-entry weights in `x` are outside this path."""
+    x, y = as_named(x), as_named(y)
+    if x.shape[0] != y.shape[0]:
+        raise ValueError("non-conformable arguments")
+    G = sp.csc_matrix(x.values)
+    m = G.shape[1]
+    scale = np.ones(m)
+    nz = G.data != 0
+    col = np.repeat(np.arange(m), np.diff(G.indptr))
+    if nz.any():
+        vmin = np.full(m, np.inf)
+        vmax = np.full(m, -np.inf)
+        np.minimum.at(vmin, col[nz], G.data[nz])
+        np.maximum.at(vmax, col[nz], G.data[nz])
+        has = np.isfinite(vmin)
+        if np.any(vmin[has] != vmax[has]):
+            raise PlaidHipError(EUNSUPPORTED, "chunked_crossprod: x must be a 0/1 membership matrix, "
+                                              "optionally scaled per column")
+        scale[has] = vmin[has]
+    counts = np.bincount(col[nz], minlength=m)
+    Gp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts, out=Gp[1:])
+    Gp, Gi = Gp.astype(np.int32), G.indices[nz].astype(np.int32)
+    ctx = ctx or default_context()
+    n = y.shape[1]
+    if chunk is None or chunk < 0:
+        chunk = _auto_chunk(m)
+    if n < chunk:
+        S = _crossprod_block(ctx, y, 0, n, Gp, Gi, "sum", False)
+    else:
+        _message(f"[chunked_crossprod] chunked compute: chunk = {chunk}")
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        for j0 in range(0, n, chunk):
+            j1 = min(n, j0 + chunk)
+            S[:, j0:j1] = _crossprod_block(ctx, y, j0, j1, Gp, Gi, "sum", False)
+    S *= scale[:, None]
+    return NamedMatrix(S, x.colnames, y.colnames)
+
+
+def normalize_medians(x, ignore_zero=None, ctx: Context | None = None):
+    """normalize_medians(), R/plaid.R:554-575."""
+    x = as_named(x)
+    ctx = ctx or default_context()
+    S, _ = ctx.normalize_medians(x.dense(), ignore_zero)
+    return NamedMatrix(S, x.rownames, x.colnames)
+
+
+def _check_ties(ties_method):
+    if ties_method not in _TIES:
+        raise PlaidHipError(EUNSUPPORTED, f"ties.method={ties_method!r}: only {_TIES} are built")
+
+
+def sparse_colranks(X, signed=False, ties_method="average", ctx: Context | None = None):
+    """sparse_colranks(), R/plaid.R:631-650: ranks of the stored non-zeros per column; the
+    sparsity pattern is kept, @x replaced."""
+    _check_ties(ties_method)
+    X = as_named(X)
+    V = sp.csc_matrix(X.values)
+    ctx = ctx or default_context()
+    rx = ctx.colranks_csc(V.indptr, V.data, ties_method, signed)
+    R = sp.csc_matrix((rx, V.indices.copy(), V.indptr.copy()), shape=V.shape)
+    return NamedMatrix(R, X.rownames, X.colnames)
+
+
+def colranks(X, sparse=None, signed=False, keep_zero=False, ties_method="average",
+             ctx: Context | None = None):
+    """colranks(), R/plaid.R:589-623."""
+    _check_ties(ties_method)
+    X = as_named(X)
+    if sparse is None:
+        sparse = X.is_sparse                                   # :595-596
+    if sparse and keep_zero:
+        return sparse_colranks(X, signed=signed, ties_method=ties_method, ctx=ctx)   # :600-601
+    ctx = ctx or default_context()
+    # sparse without keep.zero: the reference's result is dense with the zeros ranked
+    # (sparseMatrixStats::colRanks, :603-609) -- same numbers as the dense branch (:612-618)
+    R = ctx.colranks_dense(X.dense(), ties_method, signed)
+    return NamedMatrix(R, X.rownames, X.colnames)
+
+
+def replaid_sing(X, matG, ctx: Context | None = None):
+    """replaid.sing(), R/plaid.R:213-219: min-ranks / nrow(X) - 0.5, then plaid(normalize=FALSE)."""
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    S = ctx.sing_dense(X.dense(), pat[0], pat[1])
+    return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+def replaid_ssgsea(X, matG, alpha=0, ctx: Context | None = None):
+    """replaid.ssgsea(), R/plaid.R:244-255: average ranks (non-zeros only for sparse X, :245 ->
+    :600-601), ^(1+alpha), / global max - 0.5, then plaid(stats="mean", normalize=TRUE)."""
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    if X.is_sparse:
+        V = X.values
+        S = ctx.ssgsea_csc(V.indptr, V.indices, V.data, X.shape[0], pat[0], pat[1], float(alpha))
+    else:
+        S = ctx.ssgsea_dense(X.values, pat[0], pat[1], float(alpha))
+    return NamedMatrix(S, matG.colnames, X.colnames)

@@ -1,0 +1,506 @@
+// C-ABI entry points (include/plaidhip.h): context lifecycle, device-level wrappers and the
+// host-buffer pipelines the R `.Call` shim binds.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace plaidhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return (e == hipErrorOutOfMemory) ? PLAIDHIP_ENOMEM : PLAIDHIP_EHIP;
+}
+
+int ensure_workspace(plaidhip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return PLAIDHIP_OK;
+  if (ctx->ws) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_HIP(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  PH_HIP(hipMalloc(&ctx->ws, bytes));
+  ctx->ws_bytes = bytes;
+  return PLAIDHIP_OK;
+}
+
+}  // namespace plaidhip
+
+using namespace plaidhip;
+
+#define PH_CTX(ctx)                                   \
+  PH_REQUIRE((ctx) != nullptr, "null plaidhip_ctx");  \
+  PH_HIP(hipSetDevice((ctx)->device))
+
+#define PH_TRY(expr)                      \
+  do {                                    \
+    int rc_ = (expr);                     \
+    if (rc_ != PLAIDHIP_OK) return rc_;   \
+  } while (0)
+
+namespace {
+
+// RAII for the device buffers of one host-level call
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    return PLAIDHIP_OK;
+  }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+struct GenesetHolder {
+  plaidhip_geneset* gs = nullptr;
+  ~GenesetHolder() { plaidhip_geneset_destroy(gs); }
+};
+
+int h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+// normalize_medians on a device-resident S (R/plaid.R:554-575), fully enqueued: ignore.zero is
+// resolved on the device from the flag words, mean(medx) from the {sum, count} pair.
+int normalize_on_device(plaidhip_ctx* ctx, double* dS, int32_t m, int32_t n, int ignore_zero,
+                        uint32_t* d_flags, bool have_flags, double* d_med, double* d_red) {
+  if (ignore_zero == PLAIDHIP_IGNORE_ZERO_AUTO && !have_flags) {
+    PH_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(uint32_t), ctx->stream));
+    PH_TRY(launch_minflags(ctx, dS, (int64_t)m * n, d_flags));
+  }
+  PH_TRY(launch_col_medians(ctx, dS, m, m, n, ignore_zero, d_flags, d_med));
+  PH_TRY(launch_sum(ctx, d_med, n, d_red));
+  PH_TRY(launch_shift_columns(ctx, dS, m, m, n, d_med, 0.0, d_red));
+  return PLAIDHIP_OK;
+}
+
+int check_host_common(const void* G_p, int32_t g, int32_t n, int32_t m) {
+  PH_REQUIRE(g > 0 && n >= 0 && m >= 0, "bad dims g=%d n=%d m=%d", g, n, m);
+  PH_REQUIRE(G_p != nullptr, "null Gp");
+  return PLAIDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plaidhip_version(void) { return PLAIDHIP_VERSION; }
+
+const char* plaidhip_last_error_string(void) { return g_err; }
+
+int plaidhip_device_count(int* count) {
+  PH_REQUIRE(count != nullptr, "device_count: null out pointer");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__);
+  }
+  *count = n;
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_init(int device, void* stream, plaidhip_ctx** out) {
+  PH_REQUIRE(out != nullptr, "init: null out pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    set_error("no HIP device visible (this library has no CPU path)");
+    return PLAIDHIP_ENODEVICE;
+  }
+  PH_REQUIRE(device >= 0 && device < n, "init: device %d out of range [0,%d)", device, n);
+  PH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PH_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return PLAIDHIP_ENODEVICE;
+  }
+  auto* ctx = new (std::nothrow) plaidhip_ctx();
+  if (!ctx) { set_error("out of host memory"); return PLAIDHIP_ENOMEM; }
+  ctx->device = device;
+  ctx->num_cu = prop.multiProcessorCount;
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_finalize(plaidhip_ctx* ctx) {
+  if (!ctx) return PLAIDHIP_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_synchronize(plaidhip_ctx* ctx) {
+  PH_CTX(ctx);
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr) {
+  PH_CTX(ctx);
+  PH_REQUIRE(dptr != nullptr, "malloc: null out pointer");
+  PH_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_free(plaidhip_ctx* ctx, void* dptr) {
+  PH_CTX(ctx);
+  if (dptr) PH_HIP(hipFree(dptr));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_memcpy_h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  PH_CTX(ctx);
+  if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_memcpy_d2h(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  PH_CTX(ctx);
+  if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+// ---- device-level ---------------------------------------------------------------------
+
+int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
+                                int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
+                                double beta, void* S, int64_t lds, void* flags) {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm: null geneset");
+  PH_REQUIRE(n >= 0, "spmm: n=%d", n);
+  PH_REQUIRE(n == 0 || (X != nullptr && S != nullptr), "spmm: null X/S");
+  PH_REQUIRE(ldx >= gs->g && lds >= gs->m, "spmm: leading dims ldx=%lld (g=%d) lds=%lld (m=%d)",
+             (long long)ldx, gs->g, (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm: bad stat %d", stat);
+  return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(X), ldx, n, stat, alpha,
+                               static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
+                               static_cast<uint32_t*>(flags));
+}
+
+int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
+                              const void* Xi, const void* Xx, int32_t n, int stat, double alpha,
+                              const void* alpha_div, double beta, void* S, int64_t lds, void* flags) {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm_csc: null geneset");
+  PH_REQUIRE(n >= 0, "spmm_csc: n=%d", n);
+  PH_REQUIRE(n == 0 || (Xp != nullptr && S != nullptr), "spmm_csc: null Xp/S");
+  PH_REQUIRE(lds >= gs->m, "spmm_csc: lds=%lld < m=%d", (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_csc: bad stat %d", stat);
+  return launch_spmm_csc_f64(ctx, gs, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
+                             static_cast<const double*>(Xx), n, stat, alpha,
+                             static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
+                             static_cast<uint32_t*>(flags));
+}
+
+static int check_ties(int ties) {
+  PH_REQUIRE(ties == PLAIDHIP_TIES_AVERAGE || ties == PLAIDHIP_TIES_MIN || ties == PLAIDHIP_TIES_MAX,
+             "colranks: unsupported ties.method code %d (average/min/max)", ties);
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ldx, int32_t g,
+                                    int32_t n, int ties, int is_signed, double power, void* R,
+                                    int64_t ldr, void* colmax) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(g >= 0 && n >= 0, "colranks: bad dims g=%d n=%d", g, n);
+  PH_REQUIRE(g == 0 || n == 0 || (X && R), "colranks: null X/R");
+  PH_REQUIRE(ldx >= g && ldr >= g, "colranks: leading dims below g");
+  return launch_colranks_dense_f64(ctx, static_cast<const double*>(X), ldx, g, n, ties, is_signed,
+                                   power, static_cast<double*>(R), ldr, static_cast<double*>(colmax));
+}
+
+int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
+                                  int ties, int is_signed, double power, void* Rx, void* colmax) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(n >= 0, "colranks_csc: n=%d", n);
+  PH_REQUIRE(n == 0 || Xp != nullptr, "colranks_csc: null Xp");
+  return launch_colranks_csc_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const double*>(Xx),
+                                 n, ties, is_signed, power, static_cast<double*>(Rx),
+                                 static_cast<double*>(colmax));
+}
+
+int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags) {
+  PH_CTX(ctx);
+  PH_REQUIRE(flags != nullptr && count >= 0, "minflags: bad arguments");
+  return launch_minflags(ctx, static_cast<const double*>(S), count, static_cast<uint32_t*>(flags));
+}
+
+int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n,
+                             int ignore_zero, const void* flags, void* med) {
+  PH_CTX(ctx);
+  PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "col_medians: bad dims m=%d n=%d lds=%lld", m, n, (long long)lds);
+  PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "col_medians: bad ignore_zero %d", ignore_zero);
+  PH_REQUIRE(ignore_zero >= 0 || flags != nullptr, "col_medians: ignore_zero=auto needs the flags words");
+  PH_REQUIRE(n == 0 || med != nullptr, "col_medians: null med");
+  return launch_col_medians(ctx, static_cast<const double*>(S), lds, m, n, ignore_zero,
+                            static_cast<const uint32_t*>(flags), static_cast<double*>(med));
+}
+
+int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) {
+  PH_CTX(ctx);
+  PH_REQUIRE(out != nullptr && count >= 0, "sum: bad arguments");
+  return launch_sum(ctx, static_cast<const double*>(v), count, static_cast<double*>(out));
+}
+
+int plaidhip_dev_max(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) {
+  PH_CTX(ctx);
+  PH_REQUIRE(out != nullptr && count >= 0, "max: bad arguments");
+  return launch_max(ctx, static_cast<const double*>(v), count, static_cast<double*>(out));
+}
+
+int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,
+                               const void* med, double add, const void* red) {
+  PH_CTX(ctx);
+  PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "shift_columns: bad dims");
+  return launch_shift_columns(ctx, static_cast<double*>(S), lds, m, n, static_cast<const double*>(med), add,
+                              static_cast<const double*>(red));
+}
+
+// ---- host-level pipelines ---------------------------------------------------------------
+
+
+int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                         const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize,
+                         double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(n == 0 || (X && S_out), "plaid_dense: null X/S_out");
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  DevBuf dX, dS, dsmall;
+  PH_TRY(dX.alloc((size_t)g * n * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), g, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
+  if (normalize)
+    PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                       int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                       int stat, int normalize, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(Xp != nullptr && (n == 0 || S_out), "plaid_csc: null Xp/S_out");
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  const int64_t zx = Xp[n];
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  DevBuf dXp, dXi, dXx, dS, dsmall;
+  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
+  PH_TRY(dXi.alloc((size_t)zx * 4));
+  PH_TRY(dXx.alloc((size_t)zx * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
+  PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
+  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), n, stat,
+                             1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
+  if (normalize)
+    PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,
+                               double* med_out) {
+  PH_CTX(ctx);
+  PH_REQUIRE(m >= 0 && n >= 0, "normalize_medians: bad dims");
+  PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "normalize_medians: bad ignore_zero %d", ignore_zero);
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(S != nullptr, "normalize_medians: null S");
+  DevBuf dS, dsmall;
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  PH_TRY(h2d(ctx, dS.p, S, (size_t)m * n * 8));
+  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, ignore_zero, d_flags, false, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (med_out) PH_HIP(hipMemcpyAsync(med_out, d_med, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, int ties,
+                            int is_signed, double* R_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(g >= 0 && n >= 0, "colranks_dense: bad dims");
+  if ((int64_t)g * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X && R_out, "colranks_dense: null X/R_out");
+  DevBuf dX, dR;
+  PH_TRY(dX.alloc((size_t)g * n * 8));
+  PH_TRY(dR.alloc((size_t)g * n * 8));
+  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), g, g, n, ties, is_signed, 1.0, dR.as<double>(), g, nullptr));
+  PH_HIP(hipMemcpyAsync(R_out, dR.p, (size_t)g * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
+                          int ties, int is_signed, double* Rx_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(n >= 0 && Xp != nullptr, "colranks_csc: bad arguments");
+  const int64_t zx = Xp[n];
+  if (zx == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(Xx && Rx_out, "colranks_csc: null Xx/Rx_out");
+  DevBuf dXp, dXx, dR;
+  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
+  PH_TRY(dXx.alloc((size_t)zx * 8));
+  PH_TRY(dR.alloc((size_t)zx * 8));
+  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
+  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
+  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, ties, is_signed, 1.0,
+                                 dR.as<double>(), nullptr));
+  PH_HIP(hipMemcpyAsync(Rx_out, dR.p, (size_t)zx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                        const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X && S_out, "sing_dense: null X/S_out");
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  DevBuf dX, dR, dS;
+  PH_TRY(dX.alloc((size_t)g * n * 8));
+  PH_TRY(dR.alloc((size_t)g * n * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), g, g, n, PLAIDHIP_TIES_MIN, 0, 1.0, dR.as<double>(), g, nullptr));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), g, n, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,
+                               dS.as<double>(), m, nullptr));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
+                          const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
+                          double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X && S_out, "ssgsea_dense: null X/S_out");
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  DevBuf dX, dR, dS, dsmall;
+  PH_TRY(dX.alloc((size_t)g * n * 8));
+  PH_TRY(dR.alloc((size_t)g * n * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  double* d_colmax = d_med + n;
+  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  // rX = colranks(X, ties="average")^(1+alpha) ; rX/max(rX) - 0.5 ; plaid(mean, normalize=TRUE)  (R/plaid.R:245-253)
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), g, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha,
+                                   dR.as<double>(), g, d_colmax));
+  double* d_gmax = d_red + 2;   // max(rX), stays on the device
+  PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), g, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5,
+                               dS.as<double>(), m, d_flags));
+  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                        int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                        double alpha, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(Xp != nullptr, "ssgsea_csc: null Xp");
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(S_out != nullptr, "ssgsea_csc: null S_out");
+  const int64_t zx = Xp[n];
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  DevBuf dXp, dXi, dXx, dRx, dS, dsmall;
+  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
+  PH_TRY(dXi.alloc((size_t)zx * 4));
+  PH_TRY(dXx.alloc((size_t)zx * 8));
+  PH_TRY(dRx.alloc((size_t)zx * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  double* d_colmax = d_med + n;
+  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
+  PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
+  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
+  // sparse branch: ranks of the non-zeros only, zeros stay 0 (R/plaid.R:600-601, 631-650); the
+  // "- 0.5" of R/plaid.R:251 applies to the zeros too, which the (alpha, beta) epilogue covers.
+  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, PLAIDHIP_TIES_AVERAGE, 0,
+                                 1.0 + alpha, dRx.as<double>(), d_colmax));
+  double* d_gmax = d_red + 2;   // max(rX), stays on the device
+  PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dRx.as<double>(), n,
+                             PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5, dS.as<double>(), m, d_flags));
+  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// normalize_medians() (R/plaid.R:554-575) as three device phases, plus the small
+// reductions a sample-sharded host needs between them.  gfx950 / wave64 only.
+//
+//   minflags    : min(x, na.rm=TRUE) == 0  <=>  HAS_ZERO && !HAS_NEG        (R/plaid.R:556-557)
+//   col_medians : per-sample median over gene sets; exact zeros masked when ignore_zero
+//                 (R/plaid.R:562-565), all-masked column -> 0 (R/plaid.R:566).  Even count:
+//                 mean of the two middle order statistics (matrixStats::colMedians).
+//   shift       : (x - med[col]) + add, add = mean(medx)                      (R/plaid.R:572)
+#include "common.h"
+#include "device_sort.h"
+
+namespace plaidhip {
+
+__global__ void __launch_bounds__(256)
+minflags_kernel(const double* __restrict__ S, int64_t count, uint32_t* flags) {
+  uint32_t f = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const double v = S[i];
+    f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;
+    f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;
+    f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;
+  }
+  for (int off = 32; off >= 1; off >>= 1) f |= __shfl_xor(f, off, 64);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      if ((f >> b) & 1u) {
+        if (__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+          __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+}
+
+// ignore.zero resolved on the device: explicit 0/1, or (-1) min(x)==0 from the flag words
+__device__ __forceinline__ int resolve_ignore_zero(int ignore_zero, const uint32_t* flags) {
+  if (ignore_zero >= 0) return ignore_zero;
+  return (flags[1] != 0u && flags[0] == 0u) ? 1 : 0;
+}
+
+__device__ __forceinline__ uint64_t masked_key(double v, int ignore_zero) {
+  if (ignore_zero && v == 0.0) return ~0ull;
+  return f64_to_key(v);  // NaN -> ~0 as well (na.rm = TRUE)
+}
+
+// m <= kMaxLdsGenes: the column is sorted in LDS.
+__global__ void __launch_bounds__(1024)
+col_medians_lds_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                       int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                       double* __restrict__ med, int32_t key_slots) {
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
+  uint32_t* s_u32 = reinterpret_cast<uint32_t*>(smem_raw + (size_t)key_slots * 8);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* sc = S + (int64_t)c * lds;
+    if (tid == 0) s_u32[0] = 0;
+    __syncthreads();
+    uint32_t masked = 0;
+    for (int i = tid; i < m; i += nthr) {
+      const uint64_t k = masked_key(sc[i], ignore_zero);
+      masked += (k == ~0ull);
+      keys[i] = k;
+    }
+    if (masked) atomicAdd(&s_u32[0], masked);
+    bitonic_sort_lds(keys, (uint32_t)m);
+    if (tid == 0) {
+      const uint32_t cnt = (uint32_t)m - s_u32[0];
+      double r;
+      if (cnt == 0) {
+        r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+      } else if (cnt & 1) {
+        r = key_to_f64(keys[cnt >> 1]);
+      } else {
+        r = 0.5 * (key_to_f64(keys[(cnt >> 1) - 1]) + key_to_f64(keys[cnt >> 1]));
+      }
+      med[c] = r;
+    }
+    __syncthreads();
+  }
+}
+
+// Any m: 8-bit MSD radix select over the column in global memory (L2-resident).
+// Selects order statistic `kth` (0-based) among unmasked keys.
+__device__ uint64_t radix_select_global(const double* sc, int32_t m, int ignore_zero, uint32_t kth,
+                                        uint32_t* hist /*256*/, uint32_t* s_sel /*2*/) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  uint64_t prefix = 0, mask = 0;
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int b = tid; b < 256; b += nthr) hist[b] = 0;
+    __syncthreads();
+    const int shift = pass * 8;
+    for (int i = tid; i < m; i += nthr) {
+      const uint64_t k = masked_key(sc[i], ignore_zero);
+      if (k != ~0ull && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cum = 0, b = 0;
+      for (; b < 256; ++b) {
+        if (cum + hist[b] > kth) break;
+        cum += hist[b];
+      }
+      s_sel[0] = b;
+      s_sel[1] = kth - cum;
+    }
+    __syncthreads();
+    prefix |= (uint64_t)s_sel[0] << shift;
+    mask |= 0xffull << shift;
+    kth = s_sel[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ void __launch_bounds__(1024)
+col_medians_select_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                          int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                          double* __restrict__ med) {
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_sel[2];
+  __shared__ uint32_t s_cnt;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* sc = S + (int64_t)c * lds;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t valid = 0;
+    for (int i = tid; i < m; i += nthr) valid += (masked_key(sc[i], ignore_zero) != ~0ull);
+    for (int off = 32; off >= 1; off >>= 1) valid += __shfl_xor(valid, off, 64);
+    if ((tid & 63) == 0 && valid) atomicAdd(&s_cnt, valid);
+    __syncthreads();
+    const uint32_t cnt = s_cnt;
+    double r;
+    if (cnt == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else if (cnt & 1) {
+      r = key_to_f64(radix_select_global(sc, m, ignore_zero, cnt >> 1, hist, s_sel));
+    } else {
+      const double lo = key_to_f64(radix_select_global(sc, m, ignore_zero, (cnt >> 1) - 1, hist, s_sel));
+      const double hi = key_to_f64(radix_select_global(sc, m, ignore_zero, cnt >> 1, hist, s_sel));
+      r = 0.5 * (lo + hi);
+    }
+    if (tid == 0) med[c] = r;
+    __syncthreads();
+  }
+}
+
+// deterministic single-workgroup reductions (n samples: tiny)
+__global__ void __launch_bounds__(1024)
+sum_kernel(const double* __restrict__ v, int64_t count, double* out) {
+  __shared__ double s_sum[1024];
+  __shared__ double s_cnt[1024];
+  const int tid = threadIdx.x;
+  double s = 0.0, c = 0.0;
+  for (int64_t i = tid; i < count; i += 1024) {
+    const double x = v[i];
+    if (x == x) { s += x; c += 1.0; }
+  }
+  s_sum[tid] = s;
+  s_cnt[tid] = c;
+  __syncthreads();
+  for (int h = 512; h >= 1; h >>= 1) {
+    if (tid < h) { s_sum[tid] += s_sum[tid + h]; s_cnt[tid] += s_cnt[tid + h]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = s_sum[0]; out[1] = s_cnt[0]; }
+}
+
+__global__ void __launch_bounds__(1024)
+max_kernel(const double* __restrict__ v, int64_t count, double* out) {
+  __shared__ double s_max[1024];
+  const int tid = threadIdx.x;
+  double s = -INFINITY;
+  for (int64_t i = tid; i < count; i += 1024) {
+    const double x = v[i];
+    s = (x > s) ? x : s;
+  }
+  s_max[tid] = s;
+  __syncthreads();
+  for (int h = 512; h >= 1; h >>= 1) {
+    if (tid < h) s_max[tid] = (s_max[tid + h] > s_max[tid]) ? s_max[tid + h] : s_max[tid];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = s_max[0];
+}
+
+__global__ void __launch_bounds__(256)
+shift_columns_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                     const double* __restrict__ med, double add, const double* __restrict__ red) {
+  if (red != nullptr) add = red[0] / red[1];   // mean(medx, na.rm=TRUE) from {sum, count}
+  // grid.y walks columns, grid.x * block walks rows
+  for (int c = blockIdx.y; c < n; c += gridDim.y) {
+    double* sc = S + (int64_t)c * lds;
+    const double md = med[c];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+      sc[i] = (sc[i] - md) + add;
+  }
+}
+
+int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags) {
+  if (count == 0) return PLAIDHIP_OK;
+  int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(minflags_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, S, count, flags);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
+                       int ignore_zero, const uint32_t* flags, double* med) {
+  if (n == 0) return PLAIDHIP_OK;
+  if (m <= kMaxLdsGenes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col_medians_lds_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      attr_set = true;
+    }
+    const int block = m > 8192 ? 1024 : (m > 2048 ? 512 : 256);
+    const int32_t key_slots = (m + 1) & ~1;
+    const size_t smem = (size_t)key_slots * 8 + 16;
+    hipLaunchKernelGGL(col_medians_lds_kernel, dim3(n), dim3(block), smem, ctx->stream, S, lds, m, n,
+                       ignore_zero, flags, med, key_slots);
+  } else {
+    hipLaunchKernelGGL(col_medians_select_kernel, dim3(n), dim3(1024), 0, ctx->stream, S, lds, m, n,
+                       ignore_zero, flags, med);
+  }
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_sum(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, count, out);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
+  hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, count, out);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,
+                         const double* med, double add, const double* red) {
+  if (n == 0 || m == 0) return PLAIDHIP_OK;
+  int bx = (m + 255) / 256;
+  if (bx > 64) bx = 64;
+  int by = n < 32768 ? n : 32768;
+  hipLaunchKernelGGL(shift_columns_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, S, lds, m, n, med, add, red);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+}  // namespace plaidhip

@@ -1,0 +1,179 @@
+// Per-sample column ranking: colranks() dense branch (R/plaid.R:611-619 ->
+// matrixStats::colRanks) and sparse_colranks() (R/plaid.R:631-650 -> base::rank over the
+// stored non-zeros of each CSC column).  gfx950 / wave64 only.
+//
+// Kernel shape: one workgroup per column.  The column's values are mapped to
+// order-preserving 64-bit keys (exact IEEE double order, -0 == +0, NaN last) and sorted IN
+// PLACE in LDS (20k doubles = 160 KB fill the CU's LDS exactly, so the sort carries no
+// payload).  Ranks are then recovered by binary search of each element's key in the sorted
+// keys: lb = #{x_j < x_i}, ub = #{x_j <= x_i};
+//   min = lb + 1,  max = ub,  average = (lb + 1 + ub) / 2      (bit-exact half-integers)
+// which is the definition of rank(ties.method=) for NaN-free input.  NaN inputs return NaN
+// (R: NA stays NA) and do not disturb the ranks of the others.
+#include "common.h"
+#include "device_sort.h"
+
+namespace plaidhip {
+
+__device__ __forceinline__ double rank_from_bounds(uint32_t lb, uint32_t ub, int ties) {
+  if (ties == PLAIDHIP_TIES_MIN) return (double)(lb + 1);
+  if (ties == PLAIDHIP_TIES_MAX) return (double)ub;
+  return 0.5 * (double)(lb + 1 + ub);
+}
+
+__device__ __forceinline__ double sign_of(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
+
+// keys: LDS (or, for the large-column fallback, a global scratch slice) with room for cnt keys;
+// scratch: 2 uint32 + nwaves doubles in LDS.
+template <bool GLOBAL_KEYS>
+__global__ void __launch_bounds__(1024)
+colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or CSC @x
+                    int64_t ldx, int32_t g_dense,   // dense: column stride / length
+                    const int32_t* __restrict__ Xp, // CSC: column pointers (nullptr for dense)
+                    int32_t n, int ties, int is_signed, double power, double* __restrict__ R,
+                    int64_t ldr, double* __restrict__ colmax, uint64_t* gkeys, int64_t gkeys_stride) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+
+  uint64_t* keys;
+  uint32_t* s_u32;
+  double* s_f64;
+  if constexpr (GLOBAL_KEYS) {
+    keys = gkeys + (int64_t)blockIdx.x * gkeys_stride;
+    s_u32 = reinterpret_cast<uint32_t*>(smem_raw);
+    s_f64 = reinterpret_cast<double*>(smem_raw + 16);
+  } else {
+    keys = reinterpret_cast<uint64_t*>(smem_raw);
+    // scratch sits behind the keys; offset supplied through gkeys_stride (in keys)
+    s_u32 = reinterpret_cast<uint32_t*>(smem_raw + gkeys_stride * 8);
+    s_f64 = reinterpret_cast<double*>(smem_raw + gkeys_stride * 8 + 16);
+  }
+
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* xc;
+    double* rc;
+    uint32_t cnt;
+    if (Xp != nullptr) {
+      const int p0 = Xp[c];
+      cnt = (uint32_t)(Xp[c + 1] - p0);
+      xc = Xv + p0;
+      rc = R + p0;
+    } else {
+      cnt = (uint32_t)g_dense;
+      xc = Xv + (int64_t)c * ldx;
+      rc = R + (int64_t)c * ldr;
+    }
+    if (tid == 0) s_u32[0] = 0;
+    __syncthreads();
+    uint32_t my_nan = 0;
+    for (uint32_t i = tid; i < cnt; i += nthr) {
+      double x = xc[i];
+      if (is_signed) x = fabs(x);
+      const uint64_t k = f64_to_key(x);
+      my_nan += (k == ~0ull);
+      keys[i] = k;
+    }
+    if (my_nan) atomicAdd(&s_u32[0], my_nan);
+    bitonic_sort_lds(keys, cnt);  // starts and ends with a barrier
+    const uint32_t nvalid = cnt - s_u32[0];
+
+    double vmax = -INFINITY;
+    for (uint32_t i = tid; i < cnt; i += nthr) {
+      const double x0 = xc[i];
+      const double x = is_signed ? fabs(x0) : x0;
+      const uint64_t k = f64_to_key(x);
+      double r;
+      if (k == ~0ull) {
+        r = __longlong_as_double(0x7ff8000000000000ll);
+      } else {
+        const uint32_t lb = lower_bound_lds(keys, nvalid, k);
+        const uint32_t ub = upper_bound_lds(keys, nvalid, k);
+        r = rank_from_bounds(lb, ub, ties);
+        if (power != 1.0) r = pow(r, power);
+        if (is_signed) r *= sign_of(x0);
+        vmax = (r > vmax) ? r : vmax;
+      }
+      rc[i] = r;
+    }
+    if (colmax != nullptr) {
+      vmax = wave_max_f64(vmax);
+      if (lane == 0) s_f64[wave] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        double v = s_f64[0];
+        for (int w = 1; w < nwaves; ++w) v = (s_f64[w] > v) ? s_f64[w] : v;
+        colmax[c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void max_col_nnz_kernel(const int32_t* Xp, int32_t n, int32_t* out) {
+  int32_t v = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t d = Xp[i + 1] - Xp[i];
+    v = d > v ? d : v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int32_t o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+}
+
+static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense,
+                        const int32_t* Xp, int32_t n, int32_t max_len, int ties, int is_signed,
+                        double power, double* R, int64_t ldr, double* colmax) {
+  if (n == 0 || max_len == 0) return PLAIDHIP_OK;
+  const int block = max_len > 8192 ? 1024 : (max_len > 2048 ? 512 : 256);
+  const size_t scratch = 16 + 16 * sizeof(double);
+  if (max_len <= kMaxLdsGenes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_f64_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      attr_set = true;
+    }
+    const int64_t key_slots = ((int64_t)max_len + 1) & ~1ll;  // keep scratch 16-B aligned
+    const size_t smem = (size_t)key_slots * 8 + scratch;
+    hipLaunchKernelGGL(colranks_f64_kernel<false>, dim3(n), dim3(block), smem, ctx->stream, Xv, ldx,
+                       g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, (uint64_t*)nullptr,
+                       key_slots);
+  } else {
+    // large columns: keys live in a global scratch slice per workgroup (L2-resident)
+    const int grid = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
+    const int64_t stride = ((int64_t)max_len + 1) & ~1ll;
+    int rc = ensure_workspace(ctx, (size_t)grid * stride * 8);
+    if (rc != PLAIDHIP_OK) return rc;
+    hipLaunchKernelGGL(colranks_f64_kernel<true>, dim3(grid), dim3(1024), scratch, ctx->stream, Xv,
+                       ldx, g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax,
+                       reinterpret_cast<uint64_t*>(ctx->ws), stride);
+  }
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
+                              int ties, int is_signed, double power, double* R, int64_t ldr,
+                              double* colmax) {
+  return launch_ranks(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax);
+}
+
+int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
+                            int ties, int is_signed, double power, double* Rx, double* colmax) {
+  if (n == 0) return PLAIDHIP_OK;
+  // the LDS size depends on the longest column: one small reduction + 4-byte D2H
+  int rc = ensure_workspace(ctx, 256);
+  if (rc != PLAIDHIP_OK) return rc;
+  int32_t* d_max = reinterpret_cast<int32_t*>(ctx->ws);
+  PH_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(max_col_nnz_kernel, dim3(256), dim3(256), 0, ctx->stream, Xp, n, d_max);
+  int32_t h_max = 0;
+  PH_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return launch_ranks(ctx, Xx, 0, 0, Xp, n, h_max, ties, is_signed, power, Rx, 0, colmax);
+}
+
+}  // namespace plaidhip

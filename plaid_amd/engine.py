@@ -1,0 +1,215 @@
+"""Thin object layer over the C ABI: a device context, a prepared gene-set handle, and the
+device-level / host-level calls.  Pointers are plain integers (`tensor.data_ptr()`,
+`ndarray.ctypes.data`); no tensor types cross the boundary."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import STAT, TIES, check
+
+
+def _np_ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _as_f64_fortran(a) -> np.ndarray:
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _as_i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Geneset:
+    """Device-resident prepared membership (plaidhip_geneset)."""
+
+    def __init__(self, ctx: "Context", g: int, Gp, Gi):
+        Gp = _as_i32(Gp)
+        Gi = _as_i32(Gi)
+        self.ctx = ctx
+        self.g = int(g)
+        self.m = int(len(Gp) - 1)
+        self.sizes = np.diff(Gp).astype(np.int64)
+        h = C.c_void_p()
+        check(ctx.lib.plaidhip_geneset_create(ctx.handle, self.g, self.m, _np_ptr(Gp), _np_ptr(Gi), C.byref(h)))
+        self.handle = h
+
+    def info(self) -> dict:
+        buf = (C.c_int64 * 8)()
+        check(self.ctx.lib.plaidhip_geneset_info(self.handle, buf))
+        return {"g": buf[0], "m": buf[1], "z": buf[2], "padded_slots": buf[3], "tiles": buf[4],
+                "lds_resident": bool(buf[5])}
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.plaidhip_geneset_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """plaidhip_ctx: one device + one stream.  `stream` is a raw hipStream_t value (e.g.
+    `torch.cuda.current_stream().cuda_stream`) or None for a private stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.plaidhip_init(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            self.lib.plaidhip_finalize(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.plaidhip_synchronize(self.handle))
+
+    def geneset(self, g: int, Gp, Gi) -> Geneset:
+        return Geneset(self, g, Gp, Gi)
+
+    # ---- device-level (raw device pointers) ------------------------------------------
+    def dev_spmm_dense(self, gs: Geneset, X: int, ldx: int, n: int, S: int, lds: int, stat="mean",
+                       alpha=1.0, beta=0.0, flags: int | None = None, alpha_div: int | None = None):
+        check(self.lib.plaidhip_dev_spmm_dense_f64(self.handle, gs.handle, X, ldx, n, STAT[stat], alpha,
+                                                   alpha_div, beta, S, lds, flags))
+
+    def dev_spmm_csc(self, gs: Geneset, Xp: int, Xi: int, Xx: int, n: int, S: int, lds: int,
+                     stat="mean", alpha=1.0, beta=0.0, flags: int | None = None,
+                     alpha_div: int | None = None):
+        check(self.lib.plaidhip_dev_spmm_csc_f64(self.handle, gs.handle, Xp, Xi, Xx, n, STAT[stat], alpha,
+                                                 alpha_div, beta, S, lds, flags))
+
+    def dev_colranks_dense(self, X: int, ldx: int, g: int, n: int, R: int, ldr: int, ties="average",
+                           signed=False, power=1.0, colmax: int | None = None):
+        check(self.lib.plaidhip_dev_colranks_dense_f64(self.handle, X, ldx, g, n, TIES[ties], int(signed),
+                                                       power, R, ldr, colmax))
+
+    def dev_colranks_csc(self, Xp: int, Xx: int, n: int, Rx: int, ties="average", signed=False,
+                         power=1.0, colmax: int | None = None):
+        check(self.lib.plaidhip_dev_colranks_csc_f64(self.handle, Xp, Xx, n, TIES[ties], int(signed), power,
+                                                     Rx, colmax))
+
+    def dev_minflags(self, S: int, count: int, flags: int):
+        check(self.lib.plaidhip_dev_minflags(self.handle, S, count, flags))
+
+    def dev_col_medians(self, S: int, lds: int, m: int, n: int, ignore_zero, med: int,
+                        flags: int | None = None):
+        """ignore_zero: True / False, or None to resolve min(x)==0 on the device from `flags`."""
+        iz = -1 if ignore_zero is None else int(bool(ignore_zero))
+        check(self.lib.plaidhip_dev_col_medians(self.handle, S, lds, m, n, iz, flags, med))
+
+    def dev_sum(self, v: int, count: int, out: int):
+        check(self.lib.plaidhip_dev_sum(self.handle, v, count, out))
+
+    def dev_max(self, v: int, count: int, out: int):
+        check(self.lib.plaidhip_dev_max(self.handle, v, count, out))
+
+    def dev_shift_columns(self, S: int, lds: int, m: int, n: int, med: int, add: float = 0.0,
+                          red: int | None = None):
+        """x - med[col] + add; with `red` (device {sum, count}) add = sum/count on the device."""
+        check(self.lib.plaidhip_dev_shift_columns(self.handle, S, lds, m, n, med, float(add), red))
+
+    # ---- host-level (numpy in, numpy out; the library stages through HBM) -------------
+    def plaid_dense(self, X, Gp, Gi, stat="mean", normalize=True) -> np.ndarray:
+        X = _as_f64_fortran(X)
+        g, n = X.shape
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_plaid_dense(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m,
+                                            STAT[stat], int(bool(normalize)), _np_ptr(S)))
+        return S
+
+    def plaid_csc(self, Xp, Xi, Xx, g: int, Gp, Gi, stat="mean", normalize=True) -> np.ndarray:
+        Xp, Xi = _as_i32(Xp), _as_i32(Xi)
+        Xx = np.ascontiguousarray(Xx, dtype=np.float64)
+        n = len(Xp) - 1
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_plaid_csc(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n,
+                                          _np_ptr(Gp), _np_ptr(Gi), m, STAT[stat], int(bool(normalize)),
+                                          _np_ptr(S)))
+        return S
+
+    def normalize_medians(self, S, ignore_zero=None):
+        S = np.array(S, dtype=np.float64, order="F", copy=True)
+        m, n = S.shape
+        med = np.empty(n, dtype=np.float64)
+        iz = -1 if ignore_zero is None else int(bool(ignore_zero))
+        check(self.lib.plaidhip_normalize_medians(self.handle, _np_ptr(S), m, n, iz, _np_ptr(med)))
+        return S, med
+
+    def colranks_dense(self, X, ties="average", signed=False) -> np.ndarray:
+        X = _as_f64_fortran(X)
+        g, n = X.shape
+        R = np.empty((g, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_colranks_dense(self.handle, _np_ptr(X), g, n, TIES[ties], int(bool(signed)),
+                                               _np_ptr(R)))
+        return R
+
+    def colranks_csc(self, Xp, Xx, ties="average", signed=False) -> np.ndarray:
+        Xp = _as_i32(Xp)
+        Xx = np.ascontiguousarray(Xx, dtype=np.float64)
+        R = np.empty(len(Xx), dtype=np.float64)
+        check(self.lib.plaidhip_colranks_csc(self.handle, _np_ptr(Xp), _np_ptr(Xx), len(Xp) - 1, TIES[ties],
+                                             int(bool(signed)), _np_ptr(R)))
+        return R
+
+    def sing_dense(self, X, Gp, Gi) -> np.ndarray:
+        X = _as_f64_fortran(X)
+        g, n = X.shape
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_sing_dense(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m, _np_ptr(S)))
+        return S
+
+    def ssgsea_dense(self, X, Gp, Gi, alpha=0.0) -> np.ndarray:
+        X = _as_f64_fortran(X)
+        g, n = X.shape
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_ssgsea_dense(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m,
+                                             float(alpha), _np_ptr(S)))
+        return S
+
+    def ssgsea_csc(self, Xp, Xi, Xx, g: int, Gp, Gi, alpha=0.0) -> np.ndarray:
+        Xp, Xi = _as_i32(Xp), _as_i32(Xi)
+        Xx = np.ascontiguousarray(Xx, dtype=np.float64)
+        n = len(Xp) - 1
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_ssgsea_csc(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n,
+                                           _np_ptr(Gp), _np_ptr(Gi), m, float(alpha), _np_ptr(S)))
+        return S
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    """Process-wide context on device LOCAL_RANK (or 0), private stream."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

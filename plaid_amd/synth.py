@@ -1,0 +1,82 @@
+"""Synthetic genes x samples x genesets inputs (SURVEY.md section 8d / BASELINE.md section 3).
+
+One generator feeds the HIP path, the tests and the CPU baseline with identical
+bytes.  Seeds are fixed (`X` 20250614, `G` 20250615); columns are generated in
+independent 256-column blocks so any column range (a shard of a rank, the bounded
+CPU-baseline sample) can be reproduced without generating the whole matrix.
+
+Shapes follow the reference's conventions: expression is genes x samples,
+column-major (`order="F"`, R layout); membership is a genes x sets 0/1 CSC matrix
+like `gmt2mat()` returns (R/gmt-utils.R:19-66): sets ordered by decreasing size.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_X = 20250614
+SEED_G = 20250615
+BLOCK = 256
+
+
+def geneset_csc(g: int, m: int, seed: int = SEED_G, kmin: int = 15, kmax: int = 500,
+                sort_by_size: bool = True):
+    """m gene sets over g genes; size k_j = round(exp(U(ln kmin, ln kmax))) (mean about
+    138 for 15..500, cf. inst/extdata/hallmarks.gmt sizes 32..200); members uniform
+    without replacement; CSC with sorted row indices.  Returns (Gp int32[m+1], Gi int32[z])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kmax = min(kmax, g)
+    kmin = min(kmin, kmax)
+    sizes = np.rint(np.exp(rng.uniform(np.log(kmin), np.log(kmax), size=m))).astype(np.int64)
+    sizes = np.clip(sizes, 1, g)
+    if sort_by_size:
+        sizes = -np.sort(-sizes, kind="stable")   # gmt2mat: decreasing size
+    Gp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(sizes, out=Gp[1:])
+    Gi = np.empty(int(Gp[-1]), dtype=np.int32)
+    for j in range(m):
+        k = int(sizes[j])
+        # Floyd-free: permutation prefix is fine at these sizes
+        Gi[Gp[j]:Gp[j + 1]] = np.sort(rng.choice(g, size=k, replace=False))
+    return Gp.astype(np.int32), Gi
+
+
+def _block_rng(seed: int, block: int):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, block])))
+
+
+def dense_columns(g: int, j0: int, j1: int, seed: int = SEED_X, tied: bool = False):
+    """Columns [j0, j1) of the dense expression matrix: N(8, 2^2) doubles (tie-free) or,
+    with `tied`, rounded to one decimal (heavy ties for the rank kernels).
+    Returns a Fortran-ordered (g, j1-j0) float64 array."""
+    out = np.empty((g, j1 - j0), dtype=np.float64, order="F")
+    b0, b1 = j0 // BLOCK, (j1 - 1) // BLOCK if j1 > j0 else j0 // BLOCK
+    for b in range(b0, b1 + 1):
+        rng = _block_rng(seed, b)
+        blk = rng.normal(8.0, 2.0, size=(BLOCK, g))      # row = one sample column
+        lo, hi = max(j0, b * BLOCK), min(j1, (b + 1) * BLOCK)
+        out[:, lo - j0:hi - j0] = blk[lo - b * BLOCK:hi - b * BLOCK].T
+    if tied:
+        np.round(out, 1, out=out)
+    return out
+
+
+def sparse_columns(g: int, j0: int, j1: int, seed: int = SEED_X + 1, density: float = 0.05,
+                   levels: int = 50):
+    """Columns [j0, j1) of the sparse (about 95 % zero) expression matrix as CSC arrays
+    (Xp int32, Xi int32 sorted, Xx float64).  Per cell Binomial(g, density) non-zero rows,
+    uniform; values log1p(count / size_factor) with counts from a geometric-like law so
+    that a column has about `levels` distinct values (the reference fixture: 52 distinct
+    values in 1,352 non-zeros)."""
+    ps, idx, val = [0], [], []
+    for j in range(j0, j1):
+        rng = _block_rng(seed, j)
+        nnz = int(rng.binomial(g, density))
+        rows = np.sort(rng.choice(g, size=nnz, replace=False)).astype(np.int32)
+        counts = np.minimum(rng.geometric(0.12, size=nnz), levels).astype(np.float64)
+        sf = 0.5 + rng.random()                            # per-cell size factor
+        idx.append(rows)
+        val.append(np.log1p(counts / sf))
+        ps.append(ps[-1] + nnz)
+    Xi = np.concatenate(idx) if idx else np.zeros(0, np.int32)
+    Xx = np.concatenate(val) if val else np.zeros(0, np.float64)
+    return np.asarray(ps, dtype=np.int64), Xi, Xx

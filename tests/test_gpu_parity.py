@@ -1,0 +1,241 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle -- `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): ranks bit-exact; float scores within 1e-5 relative.
+The score tolerance used here is |a-b| <= RTOL*|b| + ATOL with RTOL = 1e-5 and
+ATOL = 1e-9 (fp64 accumulation leaves ~1e-13, the ATOL only covers scores that cancel to
+~0 after the -0.5 centring of R/plaid.R:216,251).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-9
+
+
+def close(a, b):
+    np.testing.assert_allclose(a, b, rtol=RTOL, atol=ATOL)
+
+
+def _oracle():
+    from oracle import plaid_oracle
+    return plaid_oracle
+
+
+# ---------------------------------------------------------------- golden: synthetic cases
+@pytest.mark.parametrize("tm", ["average", "min", "max"])
+@pytest.mark.parametrize("signed", [False, True])
+def test_colranks_dense_golden(hip_ctx, synth, tm, signed):
+    R = hip_ctx.colranks_dense(synth["rank_X"], tm, signed)
+    exp = synth[f"rank_signed_{tm}" if signed else f"rank_{tm}"]
+    assert np.array_equal(R, exp)          # bit-exact (half-)integers
+
+
+@pytest.mark.parametrize("tm", ["average", "min", "max"])
+@pytest.mark.parametrize("signed", [False, True])
+def test_sparse_colranks_golden(hip_ctx, synth, tm, signed):
+    R = hip_ctx.colranks_csc(synth["rank_csc_p"], synth["rank_csc_x"], tm, signed)
+    exp = synth[f"rank_csc_signed_{tm}" if signed else f"rank_csc_{tm}"]
+    assert np.array_equal(R, exp)
+
+
+def test_crossprod_golden(hip_ctx, synth):
+    X, Gp, Gi = synth["cp_X"], synth["cp_Gp"], synth["cp_Gi"]
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", False), synth["cp_mean_raw"])
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "sum", False), synth["cp_sum_raw"])
+    S = hip_ctx.plaid_dense(X, Gp, Gi, "mean", False)
+    assert np.all(S[3, :] == 0.0)          # empty set: exactly 0 (R/plaid.R:75-76: 0 * 1e8)
+
+
+def test_plaid_normalised_golden(hip_ctx, synth):
+    X, Gp, Gi = synth["cp_X"], synth["cp_Gp"], synth["cp_Gi"]
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", True), synth["cp_mean_norm"])      # ignore.zero branch
+    close(hip_ctx.plaid_dense(X - 8.0, Gp, Gi, "mean", True), synth["cp_neg_norm"])  # negatives: plain medians
+    # drop the empty set -> no exact zeros -> plain medians
+    keep = [j for j in range(len(Gp) - 1) if j != 3]
+    sizes = np.diff(Gp)
+    Gp2 = np.concatenate([[0], np.cumsum(sizes[keep])]).astype(np.int32)
+    Gi2 = np.concatenate([Gi[Gp[j]:Gp[j + 1]] for j in keep]).astype(np.int32)
+    close(hip_ctx.plaid_dense(X, Gp2, Gi2, "mean", True), synth["cp_nozero_norm"])
+
+
+def test_plaid_csc_equals_dense(hip_ctx, synth):
+    X, Gp, Gi = synth["cp_X"].copy(), synth["cp_Gp"], synth["cp_Gi"]
+    X[np.random.default_rng(3).random(X.shape) < 0.8] = 0.0
+    Xs = sp.csc_matrix(X)
+    a = hip_ctx.plaid_dense(X, Gp, Gi, "mean", True)
+    b = hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, X.shape[0], Gp, Gi, "mean", True)
+    close(b, a)
+    rn = [f"g{k}" for k in range(X.shape[0])]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(X.shape[0], len(Gp) - 1))
+    close(b, _oracle().plaid(Xs, rn, G, rn))
+
+
+def test_normalize_medians_golden(hip_ctx, synth):
+    close(hip_ctx.normalize_medians(synth["nm_S"])[0], synth["nm_auto"])
+    close(hip_ctx.normalize_medians(synth["nm_S"], True)[0], synth["nm_true"])
+    close(hip_ctx.normalize_medians(synth["nm_S"], False)[0], synth["nm_false"])
+    close(hip_ctx.normalize_medians(synth["nm_pos_S"])[0], synth["nm_pos_auto"])
+
+
+# ---------------------------------------------------------------- golden: reference fixture
+def _pbmc_named(pbmc):
+    import plaid_amd
+    d, e = pbmc
+    X = sp.csc_matrix((d["x"], d["i"], d["p"]), shape=tuple(d["dim"]))
+    Xn = plaid_amd.NamedMatrix(X, d["rownames"], d["colnames"])
+    return Xn, e
+
+
+def test_fixture_plaid_via_r_api(pbmc, golden_dir):
+    """read.gmt -> gmt2mat -> plaid on the reference's own bundled data (the vignette path,
+    vignettes/plaid-vignette.Rmd:49-61), checked against the KAT-pinned oracle outputs."""
+    import os
+    import plaid_amd
+    Xn, e = _pbmc_named(pbmc)
+    matG = plaid_amd.gmt2mat(plaid_amd.read_gmt(os.path.join(golden_dir, "hallmarks.gmt")))
+    assert matG.shape == (4386, 50)                       # doc/plaid-vignette.html:798
+    assert matG.colnames == list(e["G_colnames"])
+    S = plaid_amd.plaid(Xn, matG)
+    assert S.shape == (50, 50)                            # doc/plaid-vignette.html:809
+    close(S.values, e["plaid_norm"])
+    close(plaid_amd.plaid(Xn, matG, normalize=False).values, e["plaid_raw"])
+    close(plaid_amd.plaid(Xn, matG, stats="sum", normalize=False).values, e["plaid_sum_raw"])
+    Xd = plaid_amd.NamedMatrix(Xn.dense(), Xn.rownames, Xn.colnames)
+    close(plaid_amd.plaid(Xd, matG).values, e["plaid_dense_norm"])
+
+
+def test_fixture_ranks_and_replaid(pbmc, golden_dir):
+    import os
+    import plaid_amd
+    Xn, e = _pbmc_named(pbmc)
+    matG = plaid_amd.gmt2mat(plaid_amd.read_gmt(os.path.join(golden_dir, "hallmarks.gmt")))
+    assert np.array_equal(plaid_amd.sparse_colranks(Xn).values.data, e["sparse_colranks_avg"])
+    assert np.array_equal(plaid_amd.sparse_colranks(Xn, ties_method="min").values.data, e["sparse_colranks_min"])
+    assert np.array_equal(plaid_amd.colranks(Xn).values, e["colranks_avg"].astype(np.float64))
+    assert np.array_equal(plaid_amd.colranks(Xn, ties_method="min").values, e["colranks_min"].astype(np.float64))
+    close(plaid_amd.replaid_sing(Xn, matG).values, e["sing"])
+    close(plaid_amd.replaid_ssgsea(Xn, matG, alpha=0).values, e["ssgsea_a0"])
+    close(plaid_amd.replaid_ssgsea(Xn, matG, alpha=0.25).values, e["ssgsea_a025"])
+    Xd = plaid_amd.NamedMatrix(Xn.dense(), Xn.rownames, Xn.colnames)
+    close(plaid_amd.replaid_ssgsea(Xd, matG, alpha=0).values, e["ssgsea_dense_a0"])
+    close(plaid_amd.replaid_ssgsea(Xd, matG, alpha=0.25).values, e["ssgsea_dense_a025"])
+
+
+def test_no_overlap_returns_none(hip_ctx, capsys):
+    import plaid_amd
+    X = plaid_amd.NamedMatrix(np.ones((3, 2)), ["a", "b", "c"], ["s1", "s2"])
+    G = plaid_amd.NamedMatrix(sp.csc_matrix(np.ones((2, 1))), ["x", "y"], ["set"])
+    assert plaid_amd.plaid(X, G) is None                  # R/plaid.R:66-69
+    assert "No overlapping features" in capsys.readouterr().err
+
+
+# ---------------------------------------------------------------- seeded vs oracle at larger sizes
+def test_spmm_seeded_vs_oracle_20k(hip_ctx):
+    """20k genes (the LDS-resident limit region), 256 samples, 700 sets, incl. size-500 sets."""
+    from plaid_amd import synth as sy
+    g, n, m = 20000, 256, 700
+    Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    exp = _oracle().plaid(X, rn, G, rn)
+    close(hip_ctx.plaid_dense(X, Gp, Gi), exp)
+
+
+def test_spmm_large_g_fallback(hip_ctx):
+    """g above the LDS-resident limit takes the global-gather kernel."""
+    from plaid_amd import synth as sy
+    g, n, m = 30000, 32, 150
+    Gp, Gi = sy.geneset_csc(g, m)
+    X = sy.dense_columns(g, 0, n)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(hip_ctx.plaid_dense(X, Gp, Gi), _oracle().plaid(X, rn, G, rn))
+
+
+@pytest.mark.parametrize("g", [1, 2, 63, 64, 65, 1000, 4097, 20000, 20448, 20449, 33000])
+def test_colranks_sizes_vs_oracle(hip_ctx, g):
+    """column lengths around wave/workgroup/LDS boundaries, tied (rounded) data"""
+    from oracle import c_oracle
+    X = np.round(np.random.default_rng(g).normal(0, 3, size=(g, 5)), 1)
+    for tm in ("average", "min"):
+        assert np.array_equal(hip_ctx.colranks_dense(X, tm), c_oracle.colranks_dense(X, tm))
+
+
+def test_colranks_nan_and_negzero(hip_ctx):
+    x = np.array([3.0, np.nan, -0.0, 0.0, -2.0, 3.0, np.nan, 1e-300, -1e-300])
+    R = hip_ctx.colranks_dense(x.reshape(-1, 1), "average")[:, 0]
+    assert np.isnan(R[1]) and np.isnan(R[6])
+    assert np.array_equal(R[[0, 2, 3, 4, 5, 7, 8]], np.array([6.5, 3.5, 3.5, 1.0, 6.5, 5.0, 2.0]))
+
+
+def test_sparse_colranks_ragged(hip_ctx):
+    """empty columns, single-entry columns and one long column"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 0, 5, 300, 0, 2500, 64, 65, 0]
+    Xp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    Xx = np.round(rng.gamma(2.0, 1.0, size=Xp[-1]), 1) + 0.1
+    for tm in ("average", "min", "max"):
+        assert np.array_equal(hip_ctx.colranks_csc(Xp, Xx, tm), c_oracle.sparse_colranks(Xp, Xx, tm))
+
+
+def test_medians_large_m_select_path(hip_ctx):
+    """m above the LDS sort limit takes the radix-select kernel"""
+    rng = np.random.default_rng(11)
+    S = rng.normal(size=(25000, 6))
+    S[rng.random(S.shape) < 0.1] = 0.0
+    S = np.abs(S)
+    S[:, 3] = 0.0
+    exp, _ = _oracle().normalize_medians(S)
+    close(hip_ctx.normalize_medians(S)[0], exp)
+    exp, _ = _oracle().normalize_medians(S, False)
+    close(hip_ctx.normalize_medians(S, False)[0], exp)
+
+
+def test_empty_inputs(hip_ctx):
+    Gp = np.zeros(1, dtype=np.int32)
+    Gi = np.zeros(0, dtype=np.int32)
+    assert hip_ctx.plaid_dense(np.ones((5, 3)), Gp, Gi).shape == (0, 3)          # no sets
+    Gp1 = np.array([0, 2], dtype=np.int32)
+    Gi1 = np.array([0, 4], dtype=np.int32)
+    assert hip_ctx.plaid_dense(np.ones((5, 0)), Gp1, Gi1).shape == (1, 0)         # no samples
+
+
+def test_bad_arguments_raise(hip_ctx):
+    import plaid_amd
+    with pytest.raises(plaid_amd.PlaidHipError):
+        hip_ctx.plaid_dense(np.ones((5, 3)), np.array([0, 1], dtype=np.int32), np.array([7], dtype=np.int32))
+    with pytest.raises(plaid_amd.PlaidHipError):
+        plaid_amd.colranks(np.ones((4, 2)), ties_method="first")
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE C2)
+def test_c2_full_size_properties(hip_ctx):
+    """20k genes x 2,048 samples x 5k sets (C2's shape per sample; the sample axis is
+    embarrassingly parallel): linearity of the crossprod, column-permutation equivariance,
+    and median-normalisation idempotence -- none needs a CPU oracle at this size."""
+    from plaid_amd import synth as sy
+    g, n, m = 20000, 2048, 5000
+    Gp, Gi = sy.geneset_csc(g, m)
+    X = sy.dense_columns(g, 0, n)
+    S = hip_ctx.plaid_dense(X, Gp, Gi, "mean", False)
+    # linearity: plaid(2X + 1) == 2 plaid(X) + k/(k+1e-8)
+    k = np.diff(Gp).astype(np.float64)
+    S2 = hip_ctx.plaid_dense(2.0 * X + 1.0, Gp, Gi, "mean", False)
+    close(S2, 2.0 * S + (k / (k + 1e-8))[:, None])
+    # sample permutation equivariance (bit-exact: same per-column arithmetic)
+    perm = np.random.default_rng(0).permutation(n)
+    Sp = hip_ctx.plaid_dense(np.asfortranarray(X[:, perm]), Gp, Gi, "mean", False)
+    assert np.array_equal(Sp, S[:, perm])
+    # spot-check 3 columns against the oracle
+    from oracle import c_oracle
+    close(S[:, [0, 777, 2047]], c_oracle.plaid_dense(X[:, [0, 777, 2047]], Gp, Gi, "mean", False))
+    # normalised medians: every column median equals the common value; second pass is a no-op
+    N1, _ = hip_ctx.normalize_medians(S)
+    med = np.median(N1, axis=0)
+    close(med, np.full(n, med.mean()))
+    N2, _ = hip_ctx.normalize_medians(N1)
+    close(N2, N1)
