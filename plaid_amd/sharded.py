@@ -1,0 +1,150 @@
+"""Sample-sharded scoring across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Every output column depends on one input column (R/plaid.R:107, :634-642), so samples
+shard embarrassingly: rank r owns a contiguous block of sample columns (contiguous bytes in
+R's column-major layout) and a replica of the prepared membership G.  The only couplings
+between shards are three SCALARS, each one small all-reduce:
+
+    max(rX)            R/plaid.R:251   -> all_reduce(MAX)   (replaid.ssgsea)
+    min(x) == 0        R/plaid.R:557   -> all_reduce(MAX) of the 0/1 flag words
+    mean(medx)         R/plaid.R:572   -> all_reduce(SUM) of {sum, count}
+
+and, when the caller wants one matrix, a final gather of the score shards to a root as
+direct peer->root transfers (grouped send/recv: each of the root's xGMI links carries one
+shard; a ring would be bound by a single link).
+
+The arithmetic is delegated to a *phase engine* working on torch tensors: `HipPhaseEngine`
+(the product: device pointers into the C ABI).  The collectives only need tensors, so the
+same code runs under gloo with a stand-in engine in the CPU tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous blocks of ceil(n/world) columns; trailing ranks may be short or empty."""
+    per = -(-n // world) if world > 0 else n
+    lo = min(n, rank * per)
+    hi = min(n, lo + per)
+    return lo, hi
+
+
+class HipPhaseEngine:
+    """Phases of the hot path on one GPU, on torch CUDA tensors (float64, row-major
+    (n_local, g) == column-major g x n_local)."""
+
+    def __init__(self, ctx, geneset, device):
+        import torch
+        self.torch = torch
+        self.ctx, self.gs, self.device = ctx, geneset, device
+
+    def new_flags(self):
+        return self.torch.zeros(4, dtype=self.torch.int32, device=self.device)
+
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None):
+        t = self.torch
+        n = X.shape[0]
+        S = t.empty((n, self.gs.m), dtype=t.float64, device=self.device)
+        self.ctx.dev_spmm_dense(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta,
+                                flags.data_ptr() if flags is not None else None,
+                                alpha_div.data_ptr() if alpha_div is not None else None)
+        return S
+
+    def colranks(self, X, ties="average", signed=False, power=1.0):
+        t = self.torch
+        n, g = X.shape
+        R = t.empty_like(X)
+        colmax = t.empty(max(n, 1), dtype=t.float64, device=self.device)
+        self.ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, ties, signed, power, colmax.data_ptr())
+        gmax = t.full((1,), -np.inf, dtype=t.float64, device=self.device)
+        if n > 0:
+            self.ctx.dev_max(colmax.data_ptr(), n, gmax.data_ptr())
+        return R, gmax
+
+    def medians(self, S, flags):
+        t = self.torch
+        n, m = S.shape
+        med = t.empty(max(n, 1), dtype=t.float64, device=self.device)
+        red = t.zeros(2, dtype=t.float64, device=self.device)
+        if n > 0:
+            self.ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            self.ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
+        return med, red
+
+    def shift(self, S, med, red):
+        n, m = S.shape
+        if n > 0:
+            self.ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
+
+
+def _world(group):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
+                  group=None):
+    """plaid() body (R/plaid.R:73-85) on this rank's sample shard; returns the local
+    (n_local, m) score block.  Collective: every rank of `group` must call it."""
+    import torch.distributed as dist
+    world, _ = _world(group)
+    flags = engine.new_flags()
+    S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags)
+    if normalize:
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)       # min(x) == 0 over all samples
+        med, red = engine.medians(S, flags)
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)         # mean(medx) over all samples
+        engine.shift(S, med, red)
+    return S
+
+
+def sharded_sing(engine, X_local, group=None):
+    """replaid.sing (R/plaid.R:213-219): no cross-shard coupling at all."""
+    R, _ = engine.colranks(X_local, "min")
+    return sharded_plaid(engine, R, "mean", False, 1.0 / X_local.shape[1], -0.5, None, group)
+
+
+def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):
+    """replaid.ssgsea (R/plaid.R:244-255): global max(rX) is one all_reduce(MAX)."""
+    import torch.distributed as dist
+    world, _ = _world(group)
+    R, gmax = engine.colranks(X_local, "average", False, 1.0 + alpha)
+    if world > 1:
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    return sharded_plaid(engine, R, "mean", True, 1.0, -0.5, gmax, group)
+
+
+def gather_scores(S_local, n_total: int, dst: int = 0, group=None):
+    """Reassemble the (n_total, m) score matrix on `dst` from the per-rank blocks laid out by
+    shard_bounds(): direct peer->root transfers, one grouped batch of send/recv.  Returns the
+    full tensor on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = _world(group)
+    if world == 1:
+        return S_local
+    m = S_local.shape[1]
+    if rank == dst:
+        full = torch.empty((n_total, m), dtype=S_local.dtype, device=S_local.device)
+        lo, hi = shard_bounds(n_total, world, rank)
+        full[lo:hi].copy_(S_local)
+        ops = []
+        for src in range(world):
+            if src == dst:
+                continue
+            lo, hi = shard_bounds(n_total, world, src)
+            if hi > lo:
+                ops.append(dist.P2POp(dist.irecv, full[lo:hi], src, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return full
+    if S_local.shape[0] > 0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, S_local.contiguous(), dst, group)]):
+            w.wait()
+    return None
