@@ -101,6 +101,9 @@ extern "C" {
 
 int plaidhip_version(void) { return PLAIDHIP_VERSION; }
 
+// not part of include/plaidhip.h: selects a diagnostic SpMM variant for tools/bench_spmm.py
+int plaidhip_debug_set_ablation(int mode, void* dbg) { debug_set_ablation(mode, dbg); return PLAIDHIP_OK; }
+
 const char* plaidhip_last_error_string(void) { return g_err; }
 
 int plaidhip_device_count(int* count) {

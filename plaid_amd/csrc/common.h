@@ -49,25 +49,31 @@ struct plaidhip_ctx {
   int num_cu = 256;
 };
 
-// Prepared membership.  Sets are processed in "tiles" of 64 (one per wavefront lane),
-// taken in order of decreasing size so a tile's lanes have similar list lengths.
-//   tile_idx : u16 gene ids, layout [tile chunk][lane 0..63][8]  (a chunk = 8 steps;
-//              one 16-byte load per lane per chunk, 1 KiB per wave, coalesced).  Padded
-//              slots hold g + (a pad slot id) and read a zero entry of the LDS column.
-//   tile_chunk_off[t] : first chunk of tile t (tiles+1 entries)
-//   lane_set[t*64+l]  : original set id handled by lane l of tile t, or -1
-//   set_size[j]       : k_j
+// Prepared membership (built by geneset.cpp, see the header comment there).
+//   tile_idx : u16 gene ids, layout [chunk][lane 0..63][8]  (a chunk = 8 gather steps; one
+//              16-byte load per lane per chunk, 1 KiB per wave, coalesced).  Idle slots hold
+//              g + r (r < kPadSlots) and read a zero entry behind the column in LDS.
+//   wave_chunk_off[w] .. [w+1] : the contiguous chunk stream of wavefront w of the workgroup
+//   wave_tile_off[w]  .. [w+1] : its tiles, as entries of wtile_end / wtile_id
+//   wtile_end[k]      : absolute chunk index one past tile k's last chunk
+//   meta_j/meta_w/meta_k[k*64 + lane] : per lane of wave-stream tile k: set id (or -1),
+//                       1/(1e-8 + size) and size -- everything the epilogue needs, one
+//                       coalesced load each, fetched a tile ahead
 struct plaidhip_geneset {
   plaidhip_ctx* ctx = nullptr;
   int32_t g = 0, m = 0;
   int64_t z = 0;
   int32_t tiles = 0;
+  int32_t waves = 0;           // wavefronts per workgroup the plan was built for
   int64_t chunks = 0;          // total 8-step chunks over all tiles
   // device
   uint16_t* d_tile_idx = nullptr;
-  int32_t* d_tile_chunk_off = nullptr;
-  int32_t* d_lane_set = nullptr;
-  int32_t* d_set_size = nullptr;
+  int32_t* d_wave_chunk_off = nullptr;
+  int32_t* d_wave_tile_off = nullptr;
+  int32_t* d_wtile_end = nullptr;
+  int32_t* d_meta_j = nullptr;
+  double* d_meta_w = nullptr;
+  double* d_meta_k = nullptr;
   int32_t* d_Gp = nullptr;     // plain CSC copy (fallback kernel, large-g path)
   int32_t* d_Gi = nullptr;
   bool lds_ok = false;         // g <= kMaxLdsGenes
@@ -76,6 +82,7 @@ struct plaidhip_geneset {
 namespace plaidhip {
 
 int ensure_workspace(plaidhip_ctx* ctx, size_t bytes);
+int spmm_block_for_genes(int32_t g);   // workgroup size of the column-resident SpMM kernel
 
 // kernels_spmm.hip
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
@@ -84,6 +91,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
+void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ only)
 // kernels_rank.hip
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
                               int ties, int is_signed, double power, double* R, int64_t ldr,

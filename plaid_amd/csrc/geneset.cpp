@@ -2,9 +2,24 @@
 // Input is what gmt2mat() (R/gmt-utils.R:19-66) produces after plaid()'s alignment and
 // binarisation (R/plaid.R:65-73): a 0/1 CSC pattern, genes x sets, rows indexed in X's
 // row space.  colSums(G) (R/plaid.R:75) are the column lengths.
+//
+// What is built (once per G, reused for every sample column, chunk and GPU):
+//   1. sets are sorted by decreasing size (stable) and cut into tiles of 64 -- one set per
+//      wavefront lane, so the lanes of a tile have similar list lengths;
+//   2. inside each half-tile (32 lanes = one LDS lane group of ds_read_b64) the order in which
+//      every lane visits its genes is chosen by EDGE-COLOURING the bipartite multigraph
+//      lanes x LDS bank-slots (slot = gene mod 32): at every step the 32 lanes read 32
+//      different bank-slots, so the gather is LDS-bank-conflict free by construction.  By
+//      Koenig's theorem max(longest list, busiest slot) steps suffice; idle (lane, step) pairs
+//      read one of 32 zero entries behind the column, again on an unused slot;
+//   3. tiles are dealt to the W wavefronts of the workgroup by longest-processing-time, and
+//      every wavefront's tiles are laid out back to back as one contiguous stream of 16-byte
+//      chunks (8 u16 gene ids per lane), so the kernel's index prefetch never restarts.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 
@@ -12,53 +27,210 @@ using namespace plaidhip;
 
 namespace {
 
-struct HostTiles {
-  std::vector<uint16_t> idx;        // [chunk][lane][8]
-  std::vector<int32_t> chunk_off;   // tiles + 1
-  std::vector<int32_t> lane_set;    // tiles * 64
+struct Edge {
+  uint8_t u, v;      // lane (0..31), slot (0..31)
+  uint16_t gene;
+  int32_t color;
 };
 
-// Tiles of 64 sets in order of decreasing size (stable), every lane's list padded to the
-// tile's longest list rounded up to 8 steps.  Padded slots read the zero entries that
-// follow the column in LDS (g .. g+kPadSlots-1).
-void build_tiles(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, HostTiles& t) {
-  std::vector<int32_t> order(m);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-    return (Gp[a + 1] - Gp[a]) > (Gp[b + 1] - Gp[b]);
-  });
-  const int32_t tiles = (m + 63) / 64;
-  t.chunk_off.assign(tiles + 1, 0);
-  t.lane_set.assign((size_t)tiles * 64, -1);
-  for (int32_t ti = 0; ti < tiles; ++ti) {
-    int32_t longest = 0;
-    for (int l = 0; l < 64; ++l) {
-      const int32_t s = ti * 64 + l;
-      if (s >= m) break;
-      const int32_t j = order[s];
-      t.lane_set[(size_t)ti * 64 + l] = j;
-      longest = std::max(longest, Gp[j + 1] - Gp[j]);
-    }
-    t.chunk_off[ti + 1] = t.chunk_off[ti] + (longest + 7) / 8;
-  }
-  const size_t chunks = (size_t)t.chunk_off[tiles];
-  t.idx.assign(chunks * 64 * 8, 0);
-  for (int32_t ti = 0; ti < tiles; ++ti) {
-    const int32_t c0 = t.chunk_off[ti], c1 = t.chunk_off[ti + 1];
-    for (int l = 0; l < 64; ++l) {
-      const int32_t j = t.lane_set[(size_t)ti * 64 + l];
-      const int32_t p0 = j >= 0 ? Gp[j] : 0;
-      const int32_t len = j >= 0 ? Gp[j + 1] - Gp[j] : 0;
-      const uint16_t pad = (uint16_t)(g + (l & (kPadSlots - 1)));
-      for (int32_t c = c0; c < c1; ++c) {
-        uint16_t* dst = &t.idx[((size_t)c * 64 + l) * 8];
-        for (int e = 0; e < 8; ++e) {
-          const int32_t step = (c - c0) * 8 + e;
-          dst[e] = step < len ? (uint16_t)Gi[p0 + step] : pad;
+// Proper edge colouring of a bipartite multigraph with D = max degree colours
+// (alternating-path / Koenig construction).  32 + 32 vertices.
+void color_bipartite(std::vector<Edge>& E, int D) {
+  if (E.empty()) return;
+  std::vector<int32_t> atU((size_t)32 * D, -1), atV((size_t)32 * D, -1);
+  std::vector<int32_t> path;
+  auto first_free = [&](const std::vector<int32_t>& at, int x) {
+    const int32_t* row = &at[(size_t)x * D];
+    for (int c = 0; c < D; ++c)
+      if (row[c] < 0) return c;
+    return -1;
+  };
+  for (int32_t e = 0; e < (int32_t)E.size(); ++e) {
+    const int u = E[e].u, v = E[e].v;
+    const int a = first_free(atU, u);
+    int c = -1;
+    if (atV[(size_t)v * D + a] < 0) {
+      c = a;
+    } else {
+      const int b = first_free(atV, v);
+      if (atU[(size_t)u * D + b] < 0) {
+        c = b;
+      } else {
+        // a is free at u only, b is free at v only: swap a<->b on the alternating path from v
+        path.clear();
+        int x = v, col = a;
+        bool at_v = true;
+        for (;;) {
+          const int32_t pe = at_v ? atV[(size_t)x * D + col] : atU[(size_t)x * D + col];
+          if (pe < 0) break;
+          path.push_back(pe);
+          x = at_v ? E[pe].u : E[pe].v;
+          at_v = !at_v;
+          col = (col == a) ? b : a;
         }
+        for (int32_t pe : path) {
+          atU[(size_t)E[pe].u * D + E[pe].color] = -1;
+          atV[(size_t)E[pe].v * D + E[pe].color] = -1;
+        }
+        for (int32_t pe : path) {
+          const int nc = (E[pe].color == a) ? b : a;
+          E[pe].color = nc;
+          atU[(size_t)E[pe].u * D + nc] = pe;
+          atV[(size_t)E[pe].v * D + nc] = pe;
+        }
+        c = a;  // now free at both ends
       }
     }
+    E[e].color = c;
+    atU[(size_t)u * D + c] = e;
+    atV[(size_t)v * D + c] = e;
   }
+}
+
+struct TilePlan {
+  int32_t steps = 0;                 // multiple of 8
+  std::vector<uint16_t> idx;         // [step][lane 0..63]
+};
+
+// Schedule one tile (64 lanes; lane l handles set lane_set[l] or nothing).
+void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* lane_set, TilePlan& tp) {
+  std::vector<Edge> half[2];
+  int D[2] = {0, 0};
+  for (int h = 0; h < 2; ++h) {
+    int degU[32] = {0}, degV[32] = {0};
+    for (int l = 0; l < 32; ++l) {
+      const int32_t j = lane_set[h * 32 + l];
+      if (j < 0) continue;
+      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
+        const int32_t gene = Gi[p];
+        Edge e{(uint8_t)l, (uint8_t)(gene & 31), (uint16_t)gene, -1};
+        half[h].push_back(e);
+        ++degU[l];
+        ++degV[gene & 31];
+      }
+    }
+    for (int k = 0; k < 32; ++k) D[h] = std::max(D[h], std::max(degU[k], degV[k]));
+    color_bipartite(half[h], D[h]);
+  }
+  tp.steps = std::max(8, (std::max(D[0], D[1]) + 7) & ~7);   // >= 1 chunk: empty sets still get their 0 written
+  tp.idx.assign((size_t)tp.steps * 64, 0);
+  std::vector<uint8_t> used((size_t)tp.steps * 64, 0);     // (step, half*32 + slot) taken by a real read
+  std::vector<uint8_t> filled((size_t)tp.steps * 64, 0);   // (step, lane) has a real read
+  for (int h = 0; h < 2; ++h)
+    for (const Edge& e : half[h]) {
+      const size_t s = (size_t)e.color;
+      tp.idx[s * 64 + h * 32 + e.u] = e.gene;
+      filled[s * 64 + h * 32 + e.u] = 1;
+      used[s * 64 + h * 32 + e.v] = 1;
+    }
+  // idle (lane, step) pairs read a zero entry behind the column (index g + r, r < 32) whose
+  // bank-slot ((g + r) mod 32) nobody else uses in this step: #free slots == #idle lanes.
+  for (int32_t s = 0; s < tp.steps; ++s)
+    for (int h = 0; h < 2; ++h) {
+      int slot = 0;
+      for (int l = 0; l < 32; ++l) {
+        if (filled[(size_t)s * 64 + h * 32 + l]) continue;
+        while (used[(size_t)s * 64 + h * 32 + slot]) ++slot;
+        const int r = ((slot - g) % 32 + 32) % 32;
+        tp.idx[(size_t)s * 64 + h * 32 + l] = (uint16_t)(g + r);
+        ++slot;
+      }
+    }
+}
+
+struct HostPlan {
+  int32_t waves = 0;
+  std::vector<uint16_t> idx;          // [chunk][lane][8]
+  std::vector<int32_t> wave_chunk_off;  // waves + 1
+  std::vector<int32_t> wave_tile_off;   // waves + 1  (into wtile_*)
+  std::vector<int32_t> wtile_end;       // absolute chunk index one past the tile's last chunk
+  std::vector<int32_t> wtile_id;        // tile ordinal -> lane_set[tile*64 ..]
+  std::vector<int32_t> lane_set;        // tiles * 64
+  std::vector<int32_t> meta_j;          // [wave-stream tile k][lane]
+  std::vector<double> meta_w, meta_k;
+  int64_t chunks = 0;
+};
+
+void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, int waves, HostPlan& hp) {
+  std::vector<int32_t> order(m);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return (Gp[a + 1] - Gp[a]) > (Gp[b + 1] - Gp[b]); });
+  const int32_t tiles = (m + 63) / 64;
+  hp.waves = waves;
+  hp.lane_set.assign((size_t)tiles * 64, -1);
+  for (int32_t s = 0; s < m; ++s) hp.lane_set[s] = order[s];
+
+  std::vector<TilePlan> plans(tiles);
+  {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 16u));
+    if (tiles < 8) nt = 1;
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nt; ++w)
+      pool.emplace_back([&, w]() {
+        for (int32_t t = (int32_t)w; t < tiles; t += (int32_t)nt)
+          plan_tile(g, Gp, Gi, &hp.lane_set[(size_t)t * 64], plans[t]);
+      });
+    for (auto& th : pool) th.join();
+  }
+
+  // longest-processing-time assignment of tiles to wavefronts
+  std::vector<int32_t> by_len(tiles);
+  std::iota(by_len.begin(), by_len.end(), 0);
+  std::stable_sort(by_len.begin(), by_len.end(),
+                   [&](int32_t a, int32_t b) { return plans[a].steps > plans[b].steps; });
+  std::vector<std::vector<int32_t>> mine(waves);
+  std::vector<int64_t> load(waves, 0);
+  for (int32_t t : by_len) {
+    const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    mine[w].push_back(t);
+    load[w] += plans[t].steps;
+  }
+  hp.wave_chunk_off.assign(waves + 1, 0);
+  hp.wave_tile_off.assign(waves + 1, 0);
+  int32_t chunk = 0;
+  for (int w = 0; w < waves; ++w) {
+    hp.wave_chunk_off[w] = chunk;
+    hp.wave_tile_off[w] = (int32_t)hp.wtile_id.size();
+    for (int32_t t : mine[w]) {
+      chunk += plans[t].steps / 8;
+      hp.wtile_end.push_back(chunk);
+      hp.wtile_id.push_back(t);
+    }
+  }
+  hp.wave_chunk_off[waves] = chunk;
+  hp.wave_tile_off[waves] = (int32_t)hp.wtile_id.size();
+  hp.chunks = chunk;
+  // 8 spare chunks behind the stream: the kernel's 4-deep index prefetch may run past the end
+  hp.idx.assign(((size_t)chunk + 12) * 64 * 8, (uint16_t)g);
+  for (int w = 0; w < waves; ++w) {
+    int32_t c = hp.wave_chunk_off[w];
+    for (int32_t t : mine[w]) {
+      const TilePlan& tp = plans[t];
+      for (int32_t s = 0; s < tp.steps; ++s) {
+        const int32_t ch = c + s / 8, e = s & 7;
+        for (int l = 0; l < 64; ++l) hp.idx[(((size_t)ch * 64) + l) * 8 + e] = tp.idx[(size_t)s * 64 + l];
+      }
+      c += tp.steps / 8;
+    }
+  }
+  // sentinel so that reading entry k one past a wave's last tile is harmless
+  hp.wtile_end.push_back(-1);
+  hp.wtile_id.push_back(0);
+  const size_t nk = hp.wtile_id.size();
+  hp.meta_j.assign(nk * 64, -1);
+  hp.meta_w.assign(nk * 64, 0.0);
+  hp.meta_k.assign(nk * 64, 0.0);
+  for (size_t k = 0; k + 1 < nk; ++k)
+    for (int l = 0; l < 64; ++l) {
+      const int32_t j = hp.lane_set[(size_t)hp.wtile_id[k] * 64 + l];
+      if (j < 0) continue;
+      const double size = (double)(Gp[j + 1] - Gp[j]);
+      hp.meta_j[k * 64 + l] = j;
+      hp.meta_w[k * 64 + l] = 1.0 / (1e-8 + size);   // R/plaid.R:75-76
+      hp.meta_k[k * 64 + l] = size;
+    }
 }
 
 template <typename T>
@@ -75,6 +247,14 @@ int upload(plaidhip_ctx* ctx, const std::vector<T>& h, T** d) {
 }
 
 }  // namespace
+
+namespace plaidhip {
+int spmm_block_for_genes(int32_t g) {
+  static const char* e = getenv("PLAIDHIP_SPMM_BLOCK");   // tuning knob (tools/)
+  if (e && g > 2048) return atoi(e) == 512 ? 512 : 1024;
+  return g > 8192 ? 1024 : (g > 2048 ? 512 : 256);
+}
+}  // namespace plaidhip
 
 extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp,
                                        const int32_t* Gi, plaidhip_geneset** out) {
@@ -100,19 +280,21 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
   gs->tiles = (m + 63) / 64;
 
   int rc = PLAIDHIP_OK;
-  std::vector<int32_t> sizes(m);
-  for (int32_t j = 0; j < m; ++j) sizes[j] = Gp[j + 1] - Gp[j];
   std::vector<int32_t> hGp(Gp, Gp + m + 1), hGi(Gi, Gi + z);
-  if ((rc = upload(ctx, sizes, &gs->d_set_size)) != PLAIDHIP_OK) goto fail;
   if ((rc = upload(ctx, hGp, &gs->d_Gp)) != PLAIDHIP_OK) goto fail;
   if ((rc = upload(ctx, hGi, &gs->d_Gi)) != PLAIDHIP_OK) goto fail;
-  if (gs->lds_ok) {
-    HostTiles t;
-    build_tiles(g, m, Gp, Gi, t);
-    gs->chunks = t.chunk_off.back();
-    if ((rc = upload(ctx, t.idx, &gs->d_tile_idx)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, t.chunk_off, &gs->d_tile_chunk_off)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, t.lane_set, &gs->d_lane_set)) != PLAIDHIP_OK) goto fail;
+  if (gs->lds_ok && m > 0) {
+    HostPlan hp;
+    gs->waves = spmm_block_for_genes(g) / 64;
+    build_plan(g, m, Gp, Gi, gs->waves, hp);
+    gs->chunks = hp.chunks;
+    if ((rc = upload(ctx, hp.idx, &gs->d_tile_idx)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.wave_chunk_off, &gs->d_wave_chunk_off)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.wave_tile_off, &gs->d_wave_tile_off)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.wtile_end, &gs->d_wtile_end)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.meta_j, &gs->d_meta_j)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.meta_w, &gs->d_meta_w)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, hp.meta_k, &gs->d_meta_k)) != PLAIDHIP_OK) goto fail;
     // host vectors die at scope exit: make sure the copies have landed
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
@@ -127,9 +309,12 @@ fail:
 extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   if (!gs) return PLAIDHIP_OK;
   hipFree(gs->d_tile_idx);
-  hipFree(gs->d_tile_chunk_off);
-  hipFree(gs->d_lane_set);
-  hipFree(gs->d_set_size);
+  hipFree(gs->d_wave_chunk_off);
+  hipFree(gs->d_wave_tile_off);
+  hipFree(gs->d_wtile_end);
+  hipFree(gs->d_meta_j);
+  hipFree(gs->d_meta_w);
+  hipFree(gs->d_meta_k);
   hipFree(gs->d_Gp);
   hipFree(gs->d_Gi);
   delete gs;
@@ -145,5 +330,6 @@ extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]
   info[3] = gs->chunks * 64 * 8;
   info[4] = gs->tiles;
   info[5] = gs->lds_ok ? 1 : 0;
+  info[6] = gs->waves;
   return PLAIDHIP_OK;
 }

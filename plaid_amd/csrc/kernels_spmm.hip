@@ -2,19 +2,23 @@
 // (replaces Matrix::crossprod at R/plaid.R:107 with the 1/|set| column scaling of
 //  R/plaid.R:74-77 folded into the epilogue).  gfx950 / wave64 only.
 //
-// Kernel shape ("column-resident gather"):
-//   * one workgroup owns one sample column at a time.  R's layout is column-major, so a
-//     sample column is one contiguous, perfectly coalesced HBM read (g * 8 B).
-//   * the column lives in LDS as 8-byte entries (g <= 20448 fits the CU's 160 KiB);
-//     32 trailing zero entries absorb padded index slots, so the inner loop is branch-free.
-//   * lanes = gene sets.  A wavefront walks one "tile" of 64 sets (pre-sorted by size, so
-//     lanes finish together); each lane streams its set's u16 gene ids (8 per 16-byte
-//     load, 1 KiB per wave, L2-resident -- the lists are shared by every column) and
-//     gathers the gene's value from LDS (ds_read_b64), accumulating in fp64.
-//   * epilogue per set: alpha * (sum * w) + beta * (k * w), plus min()==0 bookkeeping for
-//     normalize_medians (R/plaid.R:556-557).
-// Algorithmic HBM bytes per column: 8 g (X) + 8 m (S); the index lists (2 B per
-// membership) are read from L2, once per column.
+// Kernel shape ("column-resident gather", persistent):
+//   * a workgroup owns one sample column at a time and walks columns c, c+grid, ...  R's
+//     layout is column-major, so a column is one contiguous, perfectly coalesced HBM read
+//     (8 g bytes).  The NEXT column is prefetched into registers (16-byte loads) while the
+//     current one is being consumed, then written to LDS behind a barrier.
+//   * the column lives in LDS as 8-byte entries (g <= 20448 fits the CU's 160 KiB); 32
+//     trailing zero entries absorb idle index slots, so the inner loop is branch-free.
+//   * lanes = gene sets.  Each wavefront streams ITS OWN pre-built list of tiles (64 sets per
+//     tile; geneset.cpp): 8 u16 gene ids per lane per 16-byte load (1 KiB per wave, coalesced,
+//     L2-resident: the lists are shared by every column), two loads kept in flight.  Every
+//     id becomes one ds_read_b64 gather; the visiting order was edge-coloured on the host so
+//     the 32 lanes of each LDS lane group always hit 32 different bank pairs (conflict-free).
+//   * fp64 accumulation (4 partial sums per lane), epilogue per set:
+//       alpha * (sum * w) + beta * (k * w),  w = 1/(1e-8 + k) or 1,
+//     plus the min(x)==0 bookkeeping normalize_medians needs (R/plaid.R:556-557).
+// Algorithmic HBM bytes per column: 8 g (X) + 8 m (S); the index lists (2 B per membership
+// slot) come from L2 once per column.
 #include "common.h"
 
 namespace plaidhip {
@@ -25,17 +29,21 @@ struct SpmmArgs {
   const int32_t* Xp;
   const int32_t* Xi;
   const double* Xx;
-  int32_t g, n, m, tiles;
+  int32_t g, n, m;
   const uint4* tile_idx;
-  const int32_t* tile_chunk_off;
-  const int32_t* lane_set;
-  const int32_t* set_size;
+  const int32_t* wave_chunk_off;
+  const int32_t* wave_tile_off;
+  const int32_t* wtile_end;
+  const int32_t* meta_j;     // [wave-stream tile k][lane] set id or -1
+  const double* meta_w;      // [k][lane] 1/(1e-8 + size)  (R/plaid.R:75-76)
+  const double* meta_k;      // [k][lane] size
   int32_t stat;
   double alpha, beta;
   const double* alpha_div;  // device scalar: alpha /= *alpha_div (global max(rX)), may be null
   double* S;
   int64_t lds;
   uint32_t* flags;
+  unsigned long long* dbg;   // ABLATE==4 only: per (workgroup, wave) {stage, gather, tail-wait, total} cycles
 };
 
 __device__ __forceinline__ void publish_flags(uint32_t f, uint32_t* flags) {
@@ -52,70 +60,268 @@ __device__ __forceinline__ void publish_flags(uint32_t f, uint32_t* flags) {
   }
 }
 
-template <bool CSC_X>
-__global__ void __launch_bounds__(1024)
+// u16 gene id (low / high half of a dword) -> LDS byte offset id*8.  Written so that the
+// backend's SDWA peephole folds each into ONE v_lshlrev_b32_sdwa (sub-dword source select).
+// Inline asm is avoided on purpose: next to asm statements hipcc stops counting vmcnt and
+// drains the whole index ring (s_waitcnt vmcnt(0)) before every new load.
+__device__ __forceinline__ uint32_t off_lo(uint32_t q) {
+  // instcombine turns (q & 0xffff) << 3 into (q << 3) & 0x7fff8, which the peephole misses: spell it
+  uint32_t r;
+  asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+      : "=v"(r) : "v"(q));
+  return r;
+}
+__device__ __forceinline__ uint32_t off_hi(uint32_t q) { return (q >> 16) << 3; }
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const double lds_cf64;
+// The kernel has no static LDS, so the dynamic region starts at LDS address 0 and a byte
+// offset into the column IS the LDS address (checked once at kernel entry).
+template <int ABLATE = 0>
+__device__ __forceinline__ double lds_at(uint32_t byte_off) {
+  if constexpr (ABLATE == 1) return __longlong_as_double((long long)byte_off);
+  return *reinterpret_cast<lds_cf64*>(static_cast<uintptr_t>(byte_off));
+}
+
+// the prefetched column lives in NAMED registers (an indexed array ends up in scratch)
+#define PLAIDHIP_ITEMS(M) \
+  M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19)
+
+// ABLATE (diagnostic builds only, selected by tools/ through plaidhip_debug_set_ablation):
+//   0 product kernel; 1 no LDS gathers (index stream + VALU only); 2 no index loads (synthetic
+//   conflict-free ids: LDS + VALU only); 3 no column prefetch / staging.  Modes 1-3 give wrong
+//   scores by construction and exist to price one pipe at a time.
+template <bool CSC_X, int BLOCK, int ABLATE = 0>
+__global__ void __launch_bounds__(BLOCK)
 spmm_colgather_f64(SpmmArgs a) {
+  // f64x2 registers per thread holding the prefetched next column
+  constexpr int ITEMS2 = (BLOCK == 1024) ? 10 : (BLOCK == 512 ? 20 : 4);
+  static_assert(BLOCK * ITEMS2 * 2 >= (BLOCK == 256 ? 2048 : kMaxLdsGenes), "prefetch span");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* col = reinterpret_cast<double*>(smem_raw);
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
+  }
 
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
 
-  for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
-    // ---- stage the sample column in LDS ------------------------------------------
+  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
+  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
+  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+
+  const int g2 = a.g >> 1;
+  const uint32_t lane_off16 = (uint32_t)tid * 16u;
+  const bool vec_ok = !CSC_X && g2 > 0 && ((a.ldx & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  f64x2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14, p15, p16, p17, p18, p19;
+  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = f64x2{0.0, 0.0};
+  p10 = p11 = p12 = p13 = p14 = p15 = p16 = p17 = p18 = p19 = f64x2{0.0, 0.0};
+
+// loads are "uniform base (SGPRs) + 32-bit lane offset": no per-load address registers
+#define PLAIDHIP_PF_ONE(k)                                                                      \
+  if constexpr (k < ITEMS2) {                                                                    \
+    if ((k + 1) * BLOCK <= g2) { /* wave-uniform: whole item in range */                         \
+      p##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xb_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+    } else if (k * BLOCK < g2) { /* boundary item */                                             \
+      if (tid + k * BLOCK < g2)                                                                  \
+        p##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xb_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+    }                                                                                            \
+  }
+#define PLAIDHIP_PREFETCH(cc)                                                                        \
+  do {                                                                                                \
+    const char* xb_ = reinterpret_cast<const char*>(a.X) + (int64_t)(cc) * a.ldx * 8;                 \
+    PLAIDHIP_ITEMS(PLAIDHIP_PF_ONE)                                                                   \
+  } while (0)
+#define PLAIDHIP_ST_ONE(k)                        \
+  if constexpr (k < ITEMS2) if (k * BLOCK < g2) {  \
+    const int i_ = tid + k * BLOCK;                \
+    if (i_ < g2) col2[i_] = p##k;                  \
+  }
+
+  int c = blockIdx.x;
+  if (ABLATE != 3 && vec_ok && c < a.n && g2 > 0) PLAIDHIP_PREFETCH(c);
+
+  unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
+  if constexpr (ABLATE == 4) t_all0 = __builtin_amdgcn_s_memtime();
+  for (; c < a.n; c += gridDim.x) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (ABLATE == 4) ts0 = __builtin_amdgcn_s_memtime();
+    // ---- stage the sample column in LDS ------------------------------------------------
     if constexpr (!CSC_X) {
       const double* xc = a.X + (int64_t)c * a.ldx;
-      if ((((uintptr_t)xc) & 15) == 0) {
-        const double2* xc2 = reinterpret_cast<const double2*>(xc);
-        double2* col2 = reinterpret_cast<double2*>(col);
-        const int g2 = a.g >> 1;
-        for (int i = tid; i < g2; i += nthr) col2[i] = xc2[i];
+      if (ABLATE == 3) {
+      } else if (vec_ok) {
+        f64x2* col2 = reinterpret_cast<f64x2*>(col);
+        PLAIDHIP_ITEMS(PLAIDHIP_ST_ONE)
         if ((a.g & 1) && tid == 0) col[a.g - 1] = xc[a.g - 1];
       } else {
-        for (int i = tid; i < a.g; i += nthr) col[i] = xc[i];
+        for (int i = tid; i < a.g; i += BLOCK) col[i] = xc[i];
       }
       if (tid < kPadSlots) col[a.g + tid] = 0.0;
     } else {
-      for (int i = tid; i < a.g + kPadSlots; i += nthr) col[i] = 0.0;
+      for (int i = tid; i < a.g + kPadSlots; i += BLOCK) col[i] = 0.0;
       __syncthreads();
       const int p0 = a.Xp[c], p1 = a.Xp[c + 1];
-      for (int p = p0 + tid; p < p1; p += nthr) col[a.Xi[p]] = a.Xx[p];
+      for (int p = p0 + tid; p < p1; p += BLOCK) col[a.Xi[p]] = a.Xx[p];
     }
     __syncthreads();
+    if constexpr (ABLATE == 4) ts1 = __builtin_amdgcn_s_memtime();
+    const int cnext = c + gridDim.x;
+    const bool want_pf = ABLATE != 3 && vec_ok && cnext < a.n;
 
-    // ---- gather: one tile of 64 sets per wave -------------------------------------
-    for (int t = wave; t < a.tiles; t += nwaves) {
-      const int c0 = a.tile_chunk_off[t], c1 = a.tile_chunk_off[t + 1];
-      const uint4* ip = a.tile_idx + (int64_t)c0 * 64 + lane;
+    // ---- gather: this wave's tile stream ---------------------------------------------------
+    if (ch_begin < ch_end) {
+      const char* ibase = reinterpret_cast<const char*>(a.tile_idx) + (int64_t)ch_begin * 1024;  // uniform
+      const uint32_t ioff = (uint32_t)lane * 16u;
+#define PLAIDHIP_LOADQ(rel) \
+  (ABLATE == 2 ? make_uint4(lane | ((lane + 64u) << 16), (lane + 128u) | ((lane + 192u) << 16), \
+                            (lane + 256u) | ((lane + 320u) << 16), (lane + 384u) | ((lane + 448u + (rel)) << 16)) \
+               : *reinterpret_cast<const uint4*>(ibase + (int64_t)(rel) * 1024 + ioff))
+#define PLAIDHIP_GATHER8(V, q)                                               \
+  V##0 = lds_at<ABLATE>(off_lo((q).x)); V##1 = lds_at<ABLATE>(off_hi((q).x)); \
+  V##2 = lds_at<ABLATE>(off_lo((q).y)); V##3 = lds_at<ABLATE>(off_hi((q).y)); \
+  V##4 = lds_at<ABLATE>(off_lo((q).z)); V##5 = lds_at<ABLATE>(off_hi((q).z)); \
+  V##6 = lds_at<ABLATE>(off_lo((q).w)); V##7 = lds_at<ABLATE>(off_hi((q).w));
+#define PLAIDHIP_ADD8(V)                       \
+  s0 += V##0; s1 += V##1; s2 += V##2; s3 += V##3; \
+  s0 += V##4; s1 += V##5; s2 += V##6; s3 += V##7;
+#define PLAIDHIP_TILE_END(chv)                                                                 \
+  if ((chv) + 1 == next_end) { /* wave-uniform: tile finished -> epilogue */                   \
+    const double sum = (s0 + s1) + (s2 + s3);                                                  \
+    if (mj >= 0) {                                                                             \
+      const double w = (a.stat == PLAIDHIP_STAT_MEAN) ? mw : 1.0;                              \
+      const double v = alpha * (sum * w) + a.beta * (mk * w);                                  \
+      __builtin_nontemporal_store(v, &a.S[(int64_t)c * a.lds + mj]);                           \
+      f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                             \
+      f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                           \
+      f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                              \
+    }                                                                                          \
+    ++k;                                                                                       \
+    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
+    /* metadata of the next tile: issued now, consumed a whole tile later */                   \
+    mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
+    mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
+    mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
+    s0 = s1 = s2 = s3 = 0.0;                                                                   \
+  }
+      // Software pipeline: 4 index chunks (4 KiB per wave) in flight from L2, and the LDS
+      // gathers of chunk i+1 are issued BEFORE the adds of chunk i, so a wave never sits on
+      // its own LDS latency.  The pipeline over-reads up to 5 chunks past the stream (spare
+      // chunks exist behind the array; the gathered values are never added).
+      uint4 qa = PLAIDHIP_LOADQ(0);
+      uint4 qb = PLAIDHIP_LOADQ(1);
+      uint4 qc = PLAIDHIP_LOADQ(2);
+      uint4 qd = PLAIDHIP_LOADQ(3);
+      int k = tk_begin;
+      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int ch = c0; ch < c1; ++ch, ip += 64) {
-        const uint4 q = *ip;
-        s0 += col[q.x & 0xffffu];
-        s1 += col[q.x >> 16];
-        s2 += col[q.y & 0xffffu];
-        s3 += col[q.y >> 16];
-        s0 += col[q.z & 0xffffu];
-        s1 += col[q.z >> 16];
-        s2 += col[q.w & 0xffffu];
-        s3 += col[q.w >> 16];
+      const uint32_t moff4 = (uint32_t)lane * 4u, moff8 = (uint32_t)lane * 8u;
+      int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
+      double mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);
+      double mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
+      double va0, va1, va2, va3, va4, va5, va6, va7;
+      double vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7;
+
+      if constexpr (BLOCK == 1024) {
+        // 16 waves per CU: thread-level parallelism hides the LDS latency; keep the loop lean
+        // (128-VGPR budget).  4 index chunks in flight.
+        int ch = ch_begin;
+        ibase += 4 * 1024;
+        for (; ch + 3 < ch_end; ch += 4, ibase += 4 * 1024) {
+          PLAIDHIP_GATHER8(va, qa)
+          qa = PLAIDHIP_LOADQ(0);
+          PLAIDHIP_ADD8(va)
+          PLAIDHIP_TILE_END(ch)
+          PLAIDHIP_GATHER8(va, qb)
+          qb = PLAIDHIP_LOADQ(1);
+          PLAIDHIP_ADD8(va)
+          PLAIDHIP_TILE_END(ch + 1)
+          PLAIDHIP_GATHER8(va, qc)
+          qc = PLAIDHIP_LOADQ(2);
+          PLAIDHIP_ADD8(va)
+          PLAIDHIP_TILE_END(ch + 2)
+          PLAIDHIP_GATHER8(va, qd)
+          qd = PLAIDHIP_LOADQ(3);
+          PLAIDHIP_ADD8(va)
+          PLAIDHIP_TILE_END(ch + 3)
+        }
+        if (ch < ch_end) { PLAIDHIP_GATHER8(va, qa) PLAIDHIP_ADD8(va) PLAIDHIP_TILE_END(ch) ++ch; }
+        if (ch < ch_end) { PLAIDHIP_GATHER8(va, qb) PLAIDHIP_ADD8(va) PLAIDHIP_TILE_END(ch) ++ch; }
+        if (ch < ch_end) { PLAIDHIP_GATHER8(va, qc) PLAIDHIP_ADD8(va) PLAIDHIP_TILE_END(ch) ++ch; }
+      } else {
+      PLAIDHIP_GATHER8(va, qa)
+      qa = PLAIDHIP_LOADQ(4);
+      int ch = ch_begin;
+      ibase += 5 * 1024;   // LOADQ(rel) below: rel counted from chunk ch+5
+      for (; ch + 3 < ch_end; ch += 4, ibase += 4 * 1024) {
+        PLAIDHIP_GATHER8(vb, qb)
+        qb = PLAIDHIP_LOADQ(0);
+        PLAIDHIP_ADD8(va)
+        PLAIDHIP_TILE_END(ch)
+        PLAIDHIP_GATHER8(va, qc)
+        qc = PLAIDHIP_LOADQ(1);
+        PLAIDHIP_ADD8(vb)
+        PLAIDHIP_TILE_END(ch + 1)
+        PLAIDHIP_GATHER8(vb, qd)
+        qd = PLAIDHIP_LOADQ(2);
+        PLAIDHIP_ADD8(va)
+        PLAIDHIP_TILE_END(ch + 2)
+        PLAIDHIP_GATHER8(va, qa)
+        qa = PLAIDHIP_LOADQ(3);
+        PLAIDHIP_ADD8(vb)
+        PLAIDHIP_TILE_END(ch + 3)
       }
-      const double sum = (s0 + s1) + (s2 + s3);
-      const int j = a.lane_set[t * 64 + lane];
-      if (j >= 0) {
-        const double k = (double)a.set_size[j];
-        const double w = (a.stat == PLAIDHIP_STAT_MEAN) ? 1.0 / (1e-8 + k) : 1.0;
-        const double v = alpha * (sum * w) + a.beta * (k * w);
-        a.S[(int64_t)c * a.lds + j] = v;
-        f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;
-        f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;
-        f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;
+      if (ch < ch_end) {
+        PLAIDHIP_GATHER8(vb, qb)
+        PLAIDHIP_ADD8(va)
+        PLAIDHIP_TILE_END(ch)
+        ++ch;
+        if (ch < ch_end) {
+          PLAIDHIP_GATHER8(va, qc)
+          PLAIDHIP_ADD8(vb)
+          PLAIDHIP_TILE_END(ch)
+          ++ch;
+          if (ch < ch_end) {
+            PLAIDHIP_ADD8(va)
+            PLAIDHIP_TILE_END(ch)
+          }
+        }
       }
+      }  // BLOCK != 1024
+      // next column: issued when this wave's stream is done (older waves finish first and
+      // their loads fly while the younger ones still gather); no VMEM inside the hot loop
+      // besides the index ring, which keeps hipcc's vmcnt counting exact.
+      if (want_pf) PLAIDHIP_PREFETCH(cnext);
+    } else if (want_pf) {
+      PLAIDHIP_PREFETCH(cnext);
     }
+    if constexpr (ABLATE == 4) ts2 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // column is overwritten by the next iteration
+    if constexpr (ABLATE == 4) {
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      t_stage += ts1 - ts0;
+      t_gather += ts2 - ts1;
+      t_wait += ts3 - ts2;
+    }
+  }
+  if constexpr (ABLATE == 4) {
+    if (lane == 0 && a.dbg != nullptr) {
+      unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (BLOCK / 64) + wave) * 4;
+      d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
+    }
   }
   publish_flags(f, a.flags);
+#undef PLAIDHIP_GATHER8
+#undef PLAIDHIP_ADD8
+#undef PLAIDHIP_TILE_END
+#undef PLAIDHIP_LOADQ
+#undef PLAIDHIP_PREFETCH
+#undef PLAIDHIP_PF_ONE
+#undef PLAIDHIP_ST_ONE
 }
 
 // Fallback for g beyond the LDS-resident limit: one thread per (set, column), gene values
@@ -144,22 +350,56 @@ spmm_global_f64(const double* X, int64_t ldx, int32_t n, int32_t m, const int32_
   publish_flags(f, flags);
 }
 
-static int block_for_genes(int32_t g) { return g > 8192 ? 1024 : (g > 2048 ? 512 : 256); }
+static int g_ablate = 0;
+static unsigned long long* g_dbg = nullptr;
+void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_cast<unsigned long long*>(dbg); }
+
+template <bool CSC_X, int BLOCK>
+static int launch_one(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs& a) {
+  const size_t smem = (size_t)(gs->g + kPadSlots) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<CSC_X, BLOCK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    attr_set = true;
+  }
+  // persistent: as many workgroups as fit on the chip at once (LDS- or wave-limited)
+  int per_cu = (int)(kLdsBytes / smem);
+  const int wave_cap = 2048 / BLOCK;
+  if (per_cu > wave_cap) per_cu = wave_cap;
+  if (per_cu < 1) per_cu = 1;
+  int grid = ctx->num_cu * per_cu;
+  if (grid > a.n) grid = a.n;
+  if constexpr (!CSC_X && BLOCK >= 512) {
+    if (g_ablate != 0) {   // diagnostic kernels (tools/ only)
+      a.dbg = g_dbg;
+#define PLAIDHIP_ABL(N)                                                                              \
+  if (g_ablate == N) {                                                                                \
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<false, BLOCK, N>),   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));               \
+    hipLaunchKernelGGL((spmm_colgather_f64<false, BLOCK, N>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a); \
+  }
+      PLAIDHIP_ABL(1) PLAIDHIP_ABL(2) PLAIDHIP_ABL(3) PLAIDHIP_ABL(4)
+#undef PLAIDHIP_ABL
+      PH_HIP(hipGetLastError());
+      return PLAIDHIP_OK;
+    }
+  }
+  hipLaunchKernelGGL((spmm_colgather_f64<CSC_X, BLOCK>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
 
 template <bool CSC_X>
 static int launch_colgather(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs& a) {
-  const size_t smem = (size_t)(gs->g + kPadSlots) * sizeof(double);
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[CSC_X]) {
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<CSC_X>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set[CSC_X] = true;
+  const int block = spmm_block_for_genes(gs->g);
+  if (block != gs->waves * 64) {
+    set_error("spmm: geneset plan was built for %d waves, kernel wants %d", gs->waves, block / 64);
+    return PLAIDHIP_EINVAL;
   }
-  const int block = block_for_genes(gs->g);
-  const int grid = a.n;
-  hipLaunchKernelGGL(spmm_colgather_f64<CSC_X>, dim3(grid), dim3(block), smem, ctx->stream, a);
-  PH_HIP(hipGetLastError());
-  return PLAIDHIP_OK;
+  if (block == 1024) return launch_one<CSC_X, 1024>(ctx, gs, a);
+  if (block == 512) return launch_one<CSC_X, 512>(ctx, gs, a);
+  return launch_one<CSC_X, 256>(ctx, gs, a);
 }
 
 static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int stat, double alpha,
@@ -168,11 +408,13 @@ static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int st
   a.g = gs->g;
   a.n = n;
   a.m = gs->m;
-  a.tiles = gs->tiles;
   a.tile_idx = reinterpret_cast<const uint4*>(gs->d_tile_idx);
-  a.tile_chunk_off = gs->d_tile_chunk_off;
-  a.lane_set = gs->d_lane_set;
-  a.set_size = gs->d_set_size;
+  a.wave_chunk_off = gs->d_wave_chunk_off;
+  a.wave_tile_off = gs->d_wave_tile_off;
+  a.wtile_end = gs->d_wtile_end;
+  a.meta_j = gs->d_meta_j;
+  a.meta_w = gs->d_meta_w;
+  a.meta_k = gs->d_meta_k;
   a.stat = stat;
   a.alpha = alpha;
   a.beta = beta;

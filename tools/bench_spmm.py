@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single kernels (for rocprofv3 --pmc passes and A/B work):
+   python tools/bench_spmm.py [--kernel spmm|medians|ranks] [--genes G --samples N --sets M] [--iters K]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="spmm")
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--sets", type=int, default=5000)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ties", default="average")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..3 (wrong results by design)")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    import plaid_amd
+    from plaid_amd import synth
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    dbg = None
+    if a.ablate:
+        import ctypes
+        dbg = torch.zeros(4096 * 16 * 4, dtype=torch.int64, device=dev)
+        ctx.lib.plaidhip_debug_set_ablation.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        ctx.lib.plaidhip_debug_set_ablation(a.ablate, dbg.data_ptr())
+    g, n, m = a.genes, a.samples, a.sets
+    t0 = time.perf_counter()
+    Gp, Gi = synth.geneset_csc(g, m)
+    t1 = time.perf_counter()
+    gs = ctx.geneset(g, Gp, Gi)
+    t2 = time.perf_counter()
+    info = gs.info()
+    print(f"geneset: gen {t1 - t0:.2f}s prepare {t2 - t1:.2f}s info {info} "
+          f"slot efficiency {info['z'] / max(info['padded_slots'], 1):.3f}")
+    X = torch.randn((n, g), dtype=torch.float64, device=dev) * 2 + 8
+    if a.kernel == "ranks":
+        X = torch.round(X * 10) / 10
+    S = torch.empty((n, m), dtype=torch.float64, device=dev)
+    R = torch.empty_like(X) if a.kernel == "ranks" else None
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    med = torch.empty(n, dtype=torch.float64, device=dev)
+    with torch.cuda.stream(stream):
+        ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+    for k in range(a.iters):
+        with torch.cuda.stream(stream):
+            ev[k][0].record(stream)
+            if a.kernel == "spmm":
+                ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
+            elif a.kernel == "medians":
+                ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            elif a.kernel == "ranks":
+                ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, a.ties, False, 1.0, None)
+            ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    ms = [e[0].elapsed_time(e[1]) for e in ev]
+    print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
+    if a.ablate == 4:
+        waves = info["waves"]
+        nwg = min(n, 256)
+        d = dbg.cpu().numpy()[: nwg * waves * 4].reshape(nwg, waves, 4).astype(float)
+        tot = d[:, :, 3].mean()
+        print(f"  stamps (mean over {nwg} WGs x {waves} waves, cycles per launch): stage {d[:,:,0].mean():.0f} "
+              f"({100*d[:,:,0].mean()/tot:.1f}%) gather {d[:,:,1].mean():.0f} ({100*d[:,:,1].mean()/tot:.1f}%) "
+              f"end-barrier wait {d[:,:,2].mean():.0f} ({100*d[:,:,2].mean()/tot:.1f}%) total {tot:.0f}")
+        print("  per-wave gather cycles, WG 0:", d[0, :, 1].astype(int).tolist())
+        print("  per-wave wait   cycles, WG 0:", d[0, :, 2].astype(int).tolist())
+    if a.kernel == "spmm":
+        z = int(Gp[-1])
+        b = g * n * 8 + 4 * z + 4 * (m + 1) + m * n * 8
+        print(f"  algorithmic {b / 1e9:.3f} GB -> {b / min(ms) / 1e6:.1f} GB/s; "
+              f"wave-gathers/column {info['padded_slots'] // 64} -> "
+              f"{min(ms) * 1e-3 * 2.4e9 / (n / 256) / (info['padded_slots'] / 64):.2f} cycles per wave-gather per CU @2.4GHz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+#!/bin/bash
+# rocprofv3 PMC passes for one kernel micro-benchmark (run on the GPU box via gpurun).
+# usage: tools/pmc_spmm.sh <outdir> [bench_spmm.py args...]
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p $out
+python3 tools/bench_spmm.py "$@" > $out/plain.log 2>&1
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -- python3 tools/bench_spmm.py "$@" > $out/pmc$i.log 2>&1
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/pmc_summary.txt", "w") as fh:
+    for k, d in agg.items():
+        fh.write(k + "\n")
+        for c, v in sorted(d.items()):
+            fh.write(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+print(open(out + "/pmc_summary.txt").read())
+print(open(out + "/plain.log").read())
+PY

@@ -1,0 +1,102 @@
+// Instruction issue-cost microbenchmark (gfx950): shader cycles (s_memtime) per wave-instruction
+// per SIMD for the ops of the SpMM inner loop, and for the fused gather loop itself.
+// hipcc --offload-arch=gfx950 -O3 valu_cost.hip -o valu_cost
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define SDWA_LO(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(q))
+#define SDWA_HI(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(q))
+
+template <int MODE>
+__global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iters) {
+  extern __shared__ double lds[];
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
+  __syncthreads();
+  double a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+  const double x = out[threadIdx.x & 7];
+  const unsigned lane = threadIdx.x & 63;
+  unsigned q0 = lane | ((lane + 64) << 16), q1 = (lane + 128) | ((lane + 192) << 16), q2 = (lane + 256) | ((lane + 320) << 16), q3 = (lane + 384) | ((lane + 448) << 16);
+  unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 0) {
+      asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                   "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));
+    } else if (MODE == 1) {
+      SDWA_LO(r0, q0); SDWA_HI(r1, q0); SDWA_LO(r2, q1); SDWA_HI(r3, q1); SDWA_LO(r4, q2); SDWA_HI(r5, q2); SDWA_LO(r6, q3); SDWA_HI(r7, q3);
+    } else if (MODE == 2) {
+      asm volatile("v_lshlrev_b32 %0, 3, %8\n v_lshlrev_b32 %1, 3, %9\n v_lshlrev_b32 %2, 3, %10\n v_lshlrev_b32 %3, 3, %11\n"
+                   "v_lshlrev_b32 %4, 4, %8\n v_lshlrev_b32 %5, 4, %9\n v_lshlrev_b32 %6, 4, %10\n v_lshlrev_b32 %7, 4, %11\n"
+                   : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
+                   : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+    } else if (MODE == 3) {
+      asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                   "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                   : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(q0));
+    } else if (MODE == 4) {  // ds_read_b64 only (conflict-free, fixed addresses), 8 per iter
+      double v0, v1, v2, v3, v4, v5, v6, v7;
+      asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
+                   "ds_read_b64 %4, %8 offset:4096\n ds_read_b64 %5, %9 offset:4096\n ds_read_b64 %6, %10 offset:4096\n ds_read_b64 %7, %11 offset:4096\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                   : "v"(lane * 8), "v"(lane * 8 + 512), "v"(lane * 8 + 1024), "v"(lane * 8 + 1536));
+      a0 += v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;  // keeps them live; adds cost too (see MODE 5 for the loop proper)
+    } else if (MODE == 5) {  // the fused inner loop: 8 x (sdwa, ds_read_b64), then 8 adds
+      unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+      SDWA_LO(o0, q0); SDWA_HI(o1, q0); SDWA_LO(o2, q1); SDWA_HI(o3, q1); SDWA_LO(o4, q2); SDWA_HI(o5, q2); SDWA_LO(o6, q3); SDWA_HI(o7, q3);
+      typedef __attribute__((address_space(3))) const double ld;
+      const double v0 = *(ld*)(uintptr_t)o0, v1 = *(ld*)(uintptr_t)o1, v2 = *(ld*)(uintptr_t)o2, v3 = *(ld*)(uintptr_t)o3;
+      const double v4 = *(ld*)(uintptr_t)o4, v5 = *(ld*)(uintptr_t)o5, v6 = *(ld*)(uintptr_t)o6, v7 = *(ld*)(uintptr_t)o7;
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3; a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+      q0 += 0x00010001u * (i & 1);  // keep the addresses loop-variant
+    } else if (MODE == 6) {  // ds_read only, no adds: LDS issue rate
+      double v0, v1, v2, v3, v4, v5, v6, v7;
+      asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
+                   "ds_read_b64 %4, %8 offset:4096\n ds_read_b64 %5, %9 offset:4096\n ds_read_b64 %6, %10 offset:4096\n ds_read_b64 %7, %11 offset:4096\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                   : "v"(lane * 8), "v"(lane * 8 + 512), "v"(lane * 8 + 1024), "v"(lane * 8 + 1536));
+      asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  outu[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name, int threads) {
+  double* d; unsigned* u; unsigned long long* c;
+  (void)hipMalloc(&d, 256 * 1024 * 8 * 2); (void)hipMalloc(&u, 256 * 1024 * 4 * 2); (void)hipMalloc(&c, 256 * 16 * 8);
+  (void)hipMemset(d, 0, 256 * 1024 * 8);
+  const int iters = 20000;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) k<MODE><<<256, threads, 65536>>>(d, u, c, iters);   // warm the clocks
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  k<MODE><<<256, threads, 65536>>>(d, u, c, iters);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(256 * threads / 64);
+  (void)hipMemcpy(h.data(), c, h.size() * 8, hipMemcpyDeviceToHost);
+  std::sort(h.begin(), h.end());
+  const double wave_cycles = (double)h[h.size() / 2];
+  const double wps = threads / 64.0 / 4.0;
+  printf("%-12s %4d thr (%.0f waves/SIMD): %.3f ms, median wave %.0f cyc -> %.2f cyc per wave-instr-group-of-8 per wave, "
+         "%.2f cyc per instr per SIMD, clock %.2f GHz\n", name, threads, wps, ms, wave_cycles, wave_cycles / iters,
+         wave_cycles / iters / 8.0 / wps, wave_cycles / (ms * 1e-3) / 1e9);
+  (void)hipFree(d); (void)hipFree(u); (void)hipFree(c);
+}
+
+int main() {
+  for (int t : {256, 512, 1024}) {
+    run<0>("v_add_f64", t); run<1>("lshl_sdwa", t); run<2>("v_lshlrev", t); run<3>("v_add_f32", t);
+    run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
+  }
+  return 0;
+}
