@@ -6,6 +6,8 @@
 //                 (R/plaid.R:562-565), all-masked column -> 0 (R/plaid.R:566).  Even count:
 //                 mean of the two middle order statistics (matrixStats::colMedians).
 //   shift       : (x - med[col]) + add, add = mean(medx)                      (R/plaid.R:572)
+#include <cstdlib>
+
 #include "common.h"
 #include "device_sort.h"
 
@@ -78,6 +80,123 @@ col_medians_lds_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int
       med[c] = r;
     }
     __syncthreads();
+  }
+}
+
+// m <= BLOCK*ITEMS: register-resident bitwise selection.  The column is read coalesced; every
+// thread keeps ITEMS 32-bit key words in registers and the k-th order statistic is found by
+// binary search on the key VALUE, one bit per pass: count(word < candidate) is ITEMS x
+// (v_cmp + ballot popcount) per wave plus one tiny cross-wave sum.  64-bit keys are resolved
+// in two 32-pass phases (high words, then the low words of the keys that share the selected
+// high word), so the register cost is one dword per element.  For an even count the second
+// middle value is either the same key (ties) or the smallest key above it (one more sweep).
+template <int BLOCK, int ITEMS>
+__global__ void __launch_bounds__(BLOCK)
+col_medians_bits_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                        int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                        double* __restrict__ med) {
+  constexpr int NW = BLOCK / 64;
+  __shared__ uint32_t s_cnt[2][NW];
+  __shared__ unsigned long long s_min[NW];
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int parity = 0;
+  uint32_t w[ITEMS];
+
+  // block-wide count of words below `cand` (one barrier; the two s_cnt buffers alternate)
+  auto count_below = [&](uint32_t cand, bool inclusive) -> uint32_t {
+    uint32_t wc = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+      wc += (uint32_t)__popcll(__ballot(inclusive ? (w[j] <= cand) : (w[j] < cand)));
+    if (lane == 0) s_cnt[parity][wave] = wc;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) tot += s_cnt[parity][k];
+    parity ^= 1;
+    return tot;
+  };
+  // value of rank k (0-based) among the words: largest v with count(word < v) <= k
+  auto select_word = [&](uint32_t k) -> uint32_t {
+    uint32_t v = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = v | (1u << bit);
+      if (count_below(cand, false) <= k) v = cand;
+    }
+    return v;
+  };
+
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* sc = S + (int64_t)c * lds;
+    // ---- phase 1: high words -------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int i = tid + j * BLOCK;
+      const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
+      w[j] = (uint32_t)(key >> 32);
+      if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");   // bound the live 64-bit temporaries
+    }
+    const uint32_t cnt = count_below(0xffffffffu, false);   // valid keys never have an all-ones high word
+    double r;
+    if (cnt == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+      const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
+      const uint32_t H = select_word(k_lo);
+      const uint32_t below_H = count_below(H, false);
+      // ---- phase 2: low words of the keys whose high word is H --------------------
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int i = tid + j * BLOCK;
+        const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
+        w[j] = ((uint32_t)(key >> 32) == H) ? (uint32_t)key : 0xffffffffu;
+        if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");
+      }
+      const uint32_t L = select_word(k_lo - below_H);
+      const uint64_t V = ((uint64_t)H << 32) | L;
+      uint64_t V2 = V;
+      if (k_hi != k_lo) {
+        // keys <= V: below_H + (same high word, low word <= L).  A key with another high word
+        // carries 0xffffffff here and is only (wrongly) counted when L is 0xffffffff itself;
+        // then every key of the H group is <= V and the group size is the exact count.
+        uint32_t le_V;
+        if (L != 0xffffffffu) {
+          le_V = below_H + count_below(L, true);
+        } else {
+          le_V = 0;   // resolved by the sweep below (count keys <= V exactly)
+        }
+        bool need_sweep = (L == 0xffffffffu) || (le_V <= k_hi);
+        if (need_sweep) {
+          // ---- phase 3: smallest key above V (and the exact count of keys <= V) ----
+          uint64_t mn = ~0ull;
+          uint32_t le = 0;
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const int i = tid + j * BLOCK;
+            const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
+            le += (uint32_t)__popcll(__ballot(key <= V));
+            if (key > V && key < mn) mn = key;
+            if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");
+          }
+          for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mn, off, 64);
+            mn = o < mn ? o : mn;
+          }
+          if (lane == 0) { s_min[wave] = mn; s_cnt[parity][wave] = le; }
+          __syncthreads();
+          uint64_t bm = ~0ull;
+          uint32_t tot = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) { bm = s_min[k] < bm ? s_min[k] : bm; tot += s_cnt[parity][k]; }
+          parity ^= 1;
+          V2 = (tot > k_hi) ? V : bm;
+          __syncthreads();   // s_min is reused by the next column
+        }
+      }
+      r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
+    }
+    if (tid == 0) med[c] = r;
   }
 }
 
@@ -209,10 +328,29 @@ int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t*
   return PLAIDHIP_OK;
 }
 
+template <int BLOCK, int ITEMS>
+static void launch_bits(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
+                        int ignore_zero, const uint32_t* flags, double* med) {
+  // one workgroup per column; cap the grid and let workgroups walk columns
+  const int cap = ctx->num_cu * (2048 / BLOCK) * 4;
+  const int grid = n < cap ? n : cap;
+  hipLaunchKernelGGL((col_medians_bits_kernel<BLOCK, ITEMS>), dim3(grid), dim3(BLOCK), 0, ctx->stream, S, lds,
+                     m, n, ignore_zero, flags, med);
+}
+
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                        int ignore_zero, const uint32_t* flags, double* med) {
   if (n == 0) return PLAIDHIP_OK;
-  if (m <= kMaxLdsGenes) {
+  static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");   // tools/: "sort" | "select" | unset
+  const bool want_sort = force && force[0] == 's' && force[1] == 'o';
+  const bool want_select = force && force[0] == 's' && force[1] == 'e';
+  if (!want_sort && !want_select && m <= 65536) {
+    if (m <= 2048) launch_bits<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 6144) launch_bits<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 16384) launch_bits<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 32768) launch_bits<1024, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else launch_bits<1024, 64>(ctx, S, lds, m, n, ignore_zero, flags, med);
+  } else if (!want_select && m <= kMaxLdsGenes) {
     static bool attr_set = false;
     if (!attr_set) {
       PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col_medians_lds_kernel),

@@ -239,3 +239,34 @@ def test_c2_full_size_properties(hip_ctx):
     close(med, np.full(n, med.mean()))
     N2, _ = hip_ctx.normalize_medians(N1)
     close(N2, N1)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 64, 2048, 2049, 5000, 6144, 6145, 16384, 20000, 33000, 50000, 65536, 65537, 70000])
+def test_medians_every_kernel_size_class(hip_ctx, m):
+    """column lengths across the register-resident classes (<=2048/6144/16384/32768/65536), the
+    radix-select fallback beyond, heavy ties, both parities of the valid count"""
+    rng = np.random.default_rng(m)
+    n = 5
+    S = np.round(rng.normal(size=(m, n)), 2)            # many ties
+    S[rng.random(S.shape) < 0.15] = 0.0
+    S[:, 1] = np.abs(S[:, 1])
+    if m > 3:
+        S[:, 2] = 0.0                                    # all masked under ignore.zero
+        S[: m // 2, 3] = 7.25                            # the two middle values tie
+        S[m // 2:, 3] = -1.5
+    for iz in (True, False):
+        exp, _ = _oracle().normalize_medians(S, iz)
+        got, med = hip_ctx.normalize_medians(S, iz)
+        close(got, exp)
+
+
+def test_medians_extreme_keys(hip_ctx):
+    """low word all ones, +-inf, tiny differences in the last bit"""
+    a = np.float64(1.0)
+    vals = np.array([a, np.nextafter(a, 2), np.nextafter(a, 0), np.inf, -np.inf, 1e-310, -1e-310,
+                     np.frombuffer(np.uint64(0x3FF00000FFFFFFFF).tobytes(), dtype=np.float64)[0],
+                     np.frombuffer(np.uint64(0x3FF00000FFFFFFFF).tobytes(), dtype=np.float64)[0], 2.0])
+    S = np.stack([vals, vals[::-1], np.sort(vals)], axis=1)
+    exp, _ = _oracle().normalize_medians(S, False)
+    with np.errstate(all="ignore"):
+        close(hip_ctx.normalize_medians(S, False)[0], exp)
