@@ -270,3 +270,33 @@ def test_medians_extreme_keys(hip_ctx):
     exp, _ = _oracle().normalize_medians(S, False)
     with np.errstate(all="ignore"):
         close(hip_ctx.normalize_medians(S, False)[0], exp)
+
+
+def test_device_level_chain_hip_phase_engine():
+    """The device-pointer path bench.py and the sharded host use (no host round trips):
+    torch tensors -> C ABI dev_* calls on torch's stream, world size 1."""
+    import torch
+    import plaid_amd
+    from plaid_amd import sharded, synth as sy
+    g, n, m = 5000, 300, 200
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=300)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    eng = sharded.HipPhaseEngine(ctx, gs, dev)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+    with torch.cuda.stream(stream):
+        S = sharded.sharded_plaid(eng, Xd)
+        Ssing = sharded.sharded_sing(eng, Xd)
+        Sss = sharded.sharded_ssgsea(eng, Xd, alpha=0.25)
+    torch.cuda.synchronize()
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    po = _oracle()
+    close(S.cpu().numpy().T, po.plaid(X, rn, G, rn))
+    close(Ssing.cpu().numpy().T, po.replaid_sing(X, rn, G, rn))
+    close(Sss.cpu().numpy().T, po.replaid_ssgsea(X, rn, G, rn, alpha=0.25))
+    gs.close()
+    ctx.close()

@@ -1,0 +1,119 @@
+"""The sample-sharded host path (plaid_amd/sharded.py) under gloo with world_size 2 on CPU.
+
+The collectives (flag MAX, {sum,count} SUM, max(rX) MAX, peer->root gather) are the product
+code; the per-shard arithmetic is supplied by a stand-in phase engine built on the CPU oracle,
+so this checks exactly what cannot be checked on a 1-GPU box: that shards + scalar
+all-reduces reproduce the unsharded result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import plaid_oracle as po
+from plaid_amd import sharded, synth
+
+
+class OraclePhaseEngine:
+    """Same phase interface as sharded.HipPhaseEngine, on CPU tensors, via the oracle."""
+
+    def __init__(self, g, Gp, Gi):
+        self.g, self.m = g, len(Gp) - 1
+        self.G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, self.m))
+        self.k = np.diff(Gp).astype(np.float64)
+
+    def new_flags(self):
+        return torch.zeros(4, dtype=torch.int32)
+
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None):
+        Xn = X.numpy().T                                        # g x n_local
+        raw = np.asarray(self.G.T @ Xn)
+        w = 1.0 / (1e-8 + self.k) if stat == "mean" else np.ones_like(self.k)
+        a = alpha / float(alpha_div.item()) if alpha_div is not None else alpha
+        S = a * (raw * w[:, None]) + beta * (self.k * w)[:, None]
+        if flags is not None and S.size:
+            flags[0] = max(int(flags[0]), int((S < 0).any()))
+            flags[1] = max(int(flags[1]), int((S == 0).any()))
+            flags[2] = max(int(flags[2]), int(np.isnan(S).any()))
+        return torch.from_numpy(np.ascontiguousarray(S.T))
+
+    def colranks(self, X, ties="average", signed=False, power=1.0):
+        R = po.colranks(X.numpy().T, signed=signed, ties_method=ties) if X.shape[0] else np.zeros((self.g, 0))
+        R = R ** power if power != 1.0 else R
+        gmax = torch.tensor([R.max() if R.size else -np.inf], dtype=torch.float64)
+        return torch.from_numpy(np.ascontiguousarray(R.T)), gmax
+
+    def medians(self, S, flags):
+        ignore_zero = bool(flags[1]) and not bool(flags[0])
+        if S.shape[0] == 0:
+            return torch.zeros(1, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+        _, med = po.normalize_medians(S.numpy().T, ignore_zero)
+        ok = ~np.isnan(med)
+        return torch.from_numpy(med), torch.tensor([med[ok].sum(), float(ok.sum())], dtype=torch.float64)
+
+    def shift(self, S, med, red):
+        if S.shape[0]:
+            S.sub_(med[:, None]).add_(float(red[0] / red[1]))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, case, out_path):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g, m = 300, 41
+        Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=60)
+        X = np.round(synth.dense_columns(g, 0, n), 1)
+        if case == "zeros":
+            X[:, :] = np.abs(X - 8.0)
+            Gi = Gi.copy()
+        lo, hi = sharded.shard_bounds(n, world, rank)
+        Xl = torch.from_numpy(np.ascontiguousarray(X[:, lo:hi].T))
+        eng = OraclePhaseEngine(g, Gp, Gi)
+        res = {}
+        res["plaid"] = sharded.sharded_plaid(eng, Xl)
+        res["sing"] = sharded.sharded_sing(eng, Xl)
+        res["ssgsea"] = sharded.sharded_ssgsea(eng, Xl, alpha=0.25)
+        full = {k: sharded.gather_scores(v, n, dst=0) for k, v in res.items()}
+        if rank == 0:
+            np.savez(out_path, **{k: v.numpy().T for k, v in full.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,case", [(11, "plain"), (8, "plain"), (1, "plain"), (7, "zeros")])
+def test_sharded_equals_unsharded_gloo(tmp_path, n, case):
+    world = 2
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n, case, out), nprocs=world, join=True)
+    got = np.load(out)
+    g, m = 300, 41
+    Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=60)
+    X = np.round(synth.dense_columns(g, 0, n), 1)
+    if case == "zeros":
+        X[:, :] = np.abs(X - 8.0)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    np.testing.assert_allclose(got["plaid"], po.plaid(X, rn, G, rn), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(got["sing"], po.replaid_sing(X, rn, G, rn), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(got["ssgsea"], po.replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-10, atol=1e-12)
+
+
+def test_single_process_path_needs_no_process_group():
+    g, m, n = 120, 9, 5
+    Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=30)
+    X = synth.dense_columns(g, 0, n)
+    eng = OraclePhaseEngine(g, Gp, Gi)
+    S = sharded.sharded_plaid(eng, torch.from_numpy(np.ascontiguousarray(X.T)))
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    np.testing.assert_allclose(S.numpy().T, po.plaid(X, rn, G, rn), rtol=1e-12)
+    assert sharded.gather_scores(S, n) is S
