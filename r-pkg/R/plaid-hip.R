@@ -1,0 +1,95 @@
+## R-side of the drop-in: the reference's signatures (R/plaid.R:60, :213, :244, :554, :589,
+## :631 of bigomics/plaid) with bodies that hand the arithmetic to libplaidhip.so through
+## .Call().  Gene-name alignment and dimnames stay in R; nothing numeric is computed here.
+## A maintainer of the reference would add `useDynLib(plaidhip, .registration = TRUE)` to
+## NAMESPACE and replace the bodies of the functions below (see INTEGRATION.md).
+
+.stat_code <- function(stats) match(stats[1], c("mean", "sum")) - 1L
+.ties_code <- function(ties.method) {
+  code <- match(ties.method, c("average", "min", "max"))
+  if (is.na(code)) stop("ties.method '", ties.method, "' is not built (average/min/max)")
+  code - 1L
+}
+
+## intersect + binarise (reference R/plaid.R:65-73) WITHOUT copying X: the membership pattern
+## is re-indexed into X's row space; returns NULL when nothing overlaps.
+.aligned_pattern <- function(X, matG) {
+  G <- methods::as(methods::as(matG, "CsparseMatrix"), "generalMatrix")
+  first <- !duplicated(rownames(G))
+  to_x <- match(rownames(G), rownames(X))          # first match in X, NA if absent
+  to_x[!first] <- NA
+  if (all(is.na(to_x))) return(NULL)
+  col <- rep.int(seq_len(ncol(G)), diff(G@p))
+  new_i <- to_x[G@i + 1L]
+  keep <- !is.na(new_i) & G@x != 0
+  list(Gp = c(0L, cumsum(tabulate(col[keep], nbins = ncol(G)))),
+       Gi = as.integer(new_i[keep] - 1L))
+}
+
+plaid <- function(X, matG, stats = c("mean", "sum"), chunk = NULL, normalize = TRUE) {
+  stats <- stats[1]
+  if (NCOL(X) == 1) X <- cbind(X)
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) {
+    message("[plaid] ERROR. No overlapping features.")
+    return(NULL)
+  }
+  if (inherits(X, "CsparseMatrix")) {
+    S <- .Call("R_plaidhip_plaid_csc", X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi,
+               .stat_code(stats), normalize, PACKAGE = "plaidhip")
+  } else {
+    storage.mode(X) <- "double"
+    S <- .Call("R_plaidhip_plaid_dense", X, pat$Gp, pat$Gi, .stat_code(stats), normalize,
+               PACKAGE = "plaidhip")
+  }
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}
+
+normalize_medians <- function(x, ignore.zero = NULL) {
+  x <- as.matrix(x); storage.mode(x) <- "double"
+  iz <- if (is.null(ignore.zero)) NA else as.logical(ignore.zero)
+  out <- .Call("R_plaidhip_normalize_medians", x, iz, PACKAGE = "plaidhip")
+  dimnames(out) <- dimnames(x)
+  out
+}
+
+sparse_colranks <- function(X, signed = FALSE, ties.method = "average") {
+  X <- methods::as(X, "CsparseMatrix")
+  rX <- X
+  rX@x <- .Call("R_plaidhip_colranks_csc", X@p, as.double(X@x), .ties_code(ties.method), signed,
+                PACKAGE = "plaidhip")
+  rX
+}
+
+colranks <- function(X, sparse = NULL, signed = FALSE, keep.zero = FALSE, ties.method = "average") {
+  if (is.null(sparse)) sparse <- inherits(X, "CsparseMatrix")
+  if (sparse && keep.zero) return(sparse_colranks(X, signed = signed, ties.method = ties.method))
+  D <- as.matrix(X); storage.mode(D) <- "double"
+  rX <- .Call("R_plaidhip_colranks_dense", D, .ties_code(ties.method), signed, PACKAGE = "plaidhip")
+  dimnames(rX) <- dimnames(X)
+  rX
+}
+
+replaid.sing <- function(X, matG) {
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  D <- as.matrix(X); storage.mode(D) <- "double"
+  S <- .Call("R_plaidhip_sing_dense", D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}
+
+replaid.ssgsea <- function(X, matG, alpha = 0) {
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  if (inherits(X, "CsparseMatrix")) {
+    S <- .Call("R_plaidhip_ssgsea_csc", X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi,
+               as.double(alpha), PACKAGE = "plaidhip")
+  } else {
+    D <- as.matrix(X); storage.mode(D) <- "double"
+    S <- .Call("R_plaidhip_ssgsea_dense", D, pat$Gp, pat$Gi, as.double(alpha), PACKAGE = "plaidhip")
+  }
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}

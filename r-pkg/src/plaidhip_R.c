@@ -1,0 +1,121 @@
+/* .Call() shim between R and the C ABI of include/plaidhip.h.
+ *
+ * Argument unpacking only: every number is produced by libplaidhip.so.  Not compiled in the
+ * build container (R is absent there); it needs only R's headers and -lplaidhip.
+ * Error contract: the C ABI never throws or longjmps; a non-zero status is turned into
+ * Rf_error() here, after the library call has returned (no C++ frames to unwind).
+ * Threading: .Call arrives on R's main thread; the library synchronises before returning.
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+
+#include "plaidhip.h"
+
+static plaidhip_ctx* g_ctx = NULL;
+
+static plaidhip_ctx* ctx(void) {
+  if (g_ctx == NULL) {
+    int rc = plaidhip_init(0, NULL, &g_ctx);
+    if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
+  }
+  return g_ctx;
+}
+
+static void check(int rc) {
+  if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
+}
+
+/* plaid(): X numeric matrix g x n; Gp/Gi integer vectors = aligned membership pattern in
+ * X's row space (built in R/plaid-hip.R); returns an m x n numeric matrix. */
+SEXP R_plaidhip_plaid_dense(SEXP X, SEXP Gp, SEXP Gi, SEXP stat, SEXP normalize) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_plaid_dense(ctx(), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, Rf_asInteger(stat),
+                             Rf_asLogical(normalize), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+/* same for a dgCMatrix: slots @p, @i, @x and nrow */
+SEXP R_plaidhip_plaid_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi, SEXP stat, SEXP normalize) {
+  const int n = LENGTH(Xp) - 1, m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_plaid_csc(ctx(), INTEGER(Xp), INTEGER(Xi), REAL(Xx), Rf_asInteger(g), n, INTEGER(Gp),
+                           INTEGER(Gi), m, Rf_asInteger(stat), Rf_asLogical(normalize), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+/* normalize_medians(x, ignore.zero): ignore_zero = NA (NULL in R) / FALSE / TRUE */
+SEXP R_plaidhip_normalize_medians(SEXP x, SEXP ignore_zero) {
+  const int m = Rf_nrows(x), n = Rf_ncols(x);
+  SEXP S = PROTECT(Rf_duplicate(x));
+  const int iz = Rf_asLogical(ignore_zero);
+  check(plaidhip_normalize_medians(ctx(), REAL(S), m, n, iz == NA_LOGICAL ? PLAIDHIP_IGNORE_ZERO_AUTO : iz, NULL));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_colranks_dense(SEXP X, SEXP ties, SEXP is_signed) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X);
+  SEXP R = PROTECT(Rf_allocMatrix(REALSXP, g, n));
+  check(plaidhip_colranks_dense(ctx(), REAL(X), g, n, Rf_asInteger(ties), Rf_asLogical(is_signed), REAL(R)));
+  UNPROTECT(1);
+  return R;
+}
+
+/* sparse_colranks(): returns the new @x vector; the caller keeps @i/@p (R/plaid.R:645-646) */
+SEXP R_plaidhip_colranks_csc(SEXP Xp, SEXP Xx, SEXP ties, SEXP is_signed) {
+  const int n = LENGTH(Xp) - 1;
+  SEXP R = PROTECT(Rf_allocVector(REALSXP, XLENGTH(Xx)));
+  check(plaidhip_colranks_csc(ctx(), INTEGER(Xp), REAL(Xx), n, Rf_asInteger(ties), Rf_asLogical(is_signed), REAL(R)));
+  UNPROTECT(1);
+  return R;
+}
+
+SEXP R_plaidhip_sing_dense(SEXP X, SEXP Gp, SEXP Gi) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_sing_dense(ctx(), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_ssgsea_dense(SEXP X, SEXP Gp, SEXP Gi, SEXP alpha) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_ssgsea_dense(ctx(), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, Rf_asReal(alpha), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_ssgsea_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi, SEXP alpha) {
+  const int n = LENGTH(Xp) - 1, m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_ssgsea_csc(ctx(), INTEGER(Xp), INTEGER(Xi), REAL(Xx), Rf_asInteger(g), n, INTEGER(Gp),
+                            INTEGER(Gi), m, Rf_asReal(alpha), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
+    {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
+    {"R_plaidhip_normalize_medians", (DL_FUNC)&R_plaidhip_normalize_medians, 2},
+    {"R_plaidhip_colranks_dense", (DL_FUNC)&R_plaidhip_colranks_dense, 3},
+    {"R_plaidhip_colranks_csc", (DL_FUNC)&R_plaidhip_colranks_csc, 4},
+    {"R_plaidhip_sing_dense", (DL_FUNC)&R_plaidhip_sing_dense, 3},
+    {"R_plaidhip_ssgsea_dense", (DL_FUNC)&R_plaidhip_ssgsea_dense, 4},
+    {"R_plaidhip_ssgsea_csc", (DL_FUNC)&R_plaidhip_ssgsea_csc, 7},
+    {NULL, NULL, 0}};
+
+void R_init_plaidhip(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
+
+void R_unload_plaidhip(DllInfo* dll) {
+  (void)dll;
+  if (g_ctx) { plaidhip_finalize(g_ctx); g_ctx = NULL; }
+}

@@ -41,6 +41,18 @@ def main():
     info = gs.info()
     print(f"geneset: gen {t1 - t0:.2f}s prepare {t2 - t1:.2f}s info {info} "
           f"slot efficiency {info['z'] / max(info['padded_slots'], 1):.3f}")
+    if a.kernel == "host_plaid":
+        # PCIe-inclusive rate of the host-pointer entry point (what R's .Call binds)
+        Xh = np.asfortranarray(np.random.default_rng(0).normal(8, 2, size=(g, n)))
+        ctx.plaid_dense(Xh[:, :64], Gp, Gi)
+        t = []
+        for _ in range(a.iters):
+            t0 = time.perf_counter()
+            ctx.plaid_dense(Xh, Gp, Gi)
+            t.append(time.perf_counter() - t0)
+        print(f"host_plaid (H2D X + G prep + kernels + D2H S): min {min(t)*1e3:.1f} ms -> {m*n/min(t):.3e} scores/s "
+              f"({(g*n*8 + m*n*8)/min(t)/1e9:.1f} GB/s over PCIe incl. everything)")
+        return
     X = torch.randn((n, g), dtype=torch.float64, device=dev) * 2 + 8
     if a.kernel == "ranks":
         X = torch.round(X * 10) / 10
