@@ -66,6 +66,72 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t n) {
   }
 }
 
+// Same network on DOUBLES: a compare-exchange is v_min_f64 + v_max_f64 (two VALU ops, no
+// 64-bit integer compare / select chain).  Callers must have removed NaN (mapped to +inf and
+// counted) and canonicalised -0 to +0.  Block/pair indices use shifts (k, h are powers of two)
+// and the pair loop stops at the last comparator that touches a real element.
+__device__ __forceinline__ void bitonic_sort_f64_lds(double* keys, uint32_t n) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nthr = blockDim.x;
+  const uint32_t N = next_pow2(n);
+  __syncthreads();
+  for (uint32_t lk = 1; (1u << lk) <= N; ++lk) {
+    const uint32_t k = 1u << lk;
+    {
+      // flip: element t of a k-block pairs with k-1-t.  A pair is real iff its upper index < n.
+      const uint32_t lh = lk - 1, half = k >> 1;
+      // pairs of full blocks + pairs of the last partial block whose partner exists
+      const uint32_t full = n >> lk, rem = n & (k - 1);
+      const uint32_t extra = rem > half ? rem - half : 0;   // r = base + k-1-t < n  <=>  t >= k - rem
+      const uint32_t npairs = (full << lh) + extra;
+      for (uint32_t q = tid; q < npairs; q += nthr) {
+        uint32_t blk = q >> lh, t = q & (half - 1);
+        if (blk == full) t += (k - rem);                   // partial block: only t in [k-rem, half)
+        const uint32_t l = (blk << lk) + t;
+        const uint32_t r = (blk << lk) + (k - 1 - t);
+        const double a = keys[l], b = keys[r];
+        keys[l] = fmin(a, b);
+        keys[r] = fmax(a, b);
+      }
+      __syncthreads();
+    }
+    for (uint32_t lh = lk >= 2 ? lk - 2 : 0, go = lk >= 2; go; go = lh > 0, lh = lh ? lh - 1 : 0) {
+      const uint32_t h = 1u << lh;
+      // disperse: l = blk*2h + t, r = l + h, real iff r < n
+      const uint32_t full = n >> (lh + 1), rem = n & ((h << 1) - 1);
+      const uint32_t extra = rem > h ? rem - h : 0;
+      const uint32_t npairs = (full << lh) + extra;
+      for (uint32_t q = tid; q < npairs; q += nthr) {
+        const uint32_t blk = q >> lh, t = q & (h - 1);
+        const uint32_t l = (blk << (lh + 1)) + t;
+        const uint32_t r = l + h;
+        const double a = keys[l], b = keys[r];
+        keys[l] = fmin(a, b);
+        keys[r] = fmax(a, b);
+      }
+      __syncthreads();
+      if (lh == 0) break;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_f64(const double* sorted, uint32_t n, double x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_f64(const double* sorted, uint32_t n, double x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sorted[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // number of keys < key / <= key in sorted[0..n)
 __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* sorted, uint32_t n, uint64_t key) {
   uint32_t lo = 0, hi = n;

@@ -2,10 +2,10 @@
 // matrixStats::colRanks) and sparse_colranks() (R/plaid.R:631-650 -> base::rank over the
 // stored non-zeros of each CSC column).  gfx950 / wave64 only.
 //
-// Kernel shape: one workgroup per column.  The column's values are mapped to
-// order-preserving 64-bit keys (exact IEEE double order, -0 == +0, NaN last) and sorted IN
-// PLACE in LDS (20k doubles = 160 KB fill the CU's LDS exactly, so the sort carries no
-// payload).  Ranks are then recovered by binary search of each element's key in the sorted
+// Kernel shape: one workgroup per column.  The column's doubles (exact IEEE order, -0
+// canonicalised to +0, NaN parked at +inf and counted) are sorted IN PLACE in LDS (20k
+// doubles = 160 KB fill the CU's LDS exactly, so the sort carries no payload) by a bitonic
+// network whose compare-exchange is v_min_f64 + v_max_f64.  Ranks are then recovered by binary search of each element's key in the sorted
 // keys: lb = #{x_j < x_i}, ub = #{x_j <= x_i};
 //   min = lb + 1,  max = ub,  average = (lb + 1 + ub) / 2      (bit-exact half-integers)
 // which is the definition of rank(ties.method=) for NaN-free input.  NaN inputs return NaN
@@ -36,15 +36,15 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
 
-  uint64_t* keys;
+  double* keys;
   uint32_t* s_u32;
   double* s_f64;
   if constexpr (GLOBAL_KEYS) {
-    keys = gkeys + (int64_t)blockIdx.x * gkeys_stride;
+    keys = reinterpret_cast<double*>(gkeys) + (int64_t)blockIdx.x * gkeys_stride;
     s_u32 = reinterpret_cast<uint32_t*>(smem_raw);
     s_f64 = reinterpret_cast<double*>(smem_raw + 16);
   } else {
-    keys = reinterpret_cast<uint64_t*>(smem_raw);
+    keys = reinterpret_cast<double*>(smem_raw);
     // scratch sits behind the keys; offset supplied through gkeys_stride (in keys)
     s_u32 = reinterpret_cast<uint32_t*>(smem_raw + gkeys_stride * 8);
     s_f64 = reinterpret_cast<double*>(smem_raw + gkeys_stride * 8 + 16);
@@ -70,25 +70,24 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
     for (uint32_t i = tid; i < cnt; i += nthr) {
       double x = xc[i];
       if (is_signed) x = fabs(x);
-      const uint64_t k = f64_to_key(x);
-      my_nan += (k == ~0ull);
-      keys[i] = k;
+      const bool isnan_ = (x != x);
+      my_nan += isnan_;
+      keys[i] = isnan_ ? INFINITY : (x + 0.0);   // NaN sorts last (counted); -0 -> +0
     }
     if (my_nan) atomicAdd(&s_u32[0], my_nan);
-    bitonic_sort_lds(keys, cnt);  // starts and ends with a barrier
+    bitonic_sort_f64_lds(keys, cnt);  // starts and ends with a barrier
     const uint32_t nvalid = cnt - s_u32[0];
 
     double vmax = -INFINITY;
     for (uint32_t i = tid; i < cnt; i += nthr) {
       const double x0 = xc[i];
       const double x = is_signed ? fabs(x0) : x0;
-      const uint64_t k = f64_to_key(x);
       double r;
-      if (k == ~0ull) {
+      if (x != x) {
         r = __longlong_as_double(0x7ff8000000000000ll);
       } else {
-        const uint32_t lb = lower_bound_lds(keys, nvalid, k);
-        const uint32_t ub = upper_bound_lds(keys, nvalid, k);
+        const uint32_t lb = lower_bound_f64(keys, nvalid, x);
+        const uint32_t ub = upper_bound_f64(keys, nvalid, x);
         r = rank_from_bounds(lb, ub, ties);
         if (power != 1.0) r = pow(r, power);
         if (is_signed) r *= sign_of(x0);

@@ -53,6 +53,17 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
       const double v4 = *(ld*)(uintptr_t)o4, v5 = *(ld*)(uintptr_t)o5, v6 = *(ld*)(uintptr_t)o6, v7 = *(ld*)(uintptr_t)o7;
       a0 += v0; a1 += v1; a2 += v2; a3 += v3; a0 += v4; a1 += v5; a2 += v6; a3 += v7;
       q0 += 0x00010001u * (i & 1);  // keep the addresses loop-variant
+    } else if (MODE == 7) {  // v_mul_f32_sdwa by 8.0 on a u16 half: (denormal) bits * 8 == integer << 3
+      asm volatile("v_mul_f32_sdwa %0, %12, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+                   "v_mul_f32_sdwa %1, %12, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                   "v_mul_f32_sdwa %2, %12, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+                   "v_mul_f32_sdwa %3, %12, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                   "v_mul_f32_sdwa %4, %12, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+                   "v_mul_f32_sdwa %5, %12, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                   "v_mul_f32_sdwa %6, %12, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+                   "v_mul_f32_sdwa %7, %12, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                   : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
+                   : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(8.0f));
     } else if (MODE == 6) {  // ds_read only, no adds: LDS issue rate
       double v0, v1, v2, v3, v4, v5, v6, v7;
       asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
@@ -94,9 +105,11 @@ void run(const char* name, int threads) {
 }
 
 int main() {
+  // value check of the denormal trick is done by the kernel tests (addresses must match)
+
   for (int t : {256, 512, 1024}) {
     run<0>("v_add_f64", t); run<1>("lshl_sdwa", t); run<2>("v_lshlrev", t); run<3>("v_add_f32", t);
-    run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
+    run<7>("mul_f32_sdwa", t); run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
   }
   return 0;
 }
