@@ -59,14 +59,11 @@ struct plaidhip_ctx {
 //   meta_j/meta_w/meta_k[k*64 + lane] : per lane of wave-stream tile k: set id (or -1),
 //                       1/(1e-8 + size) and size -- everything the epilogue needs, one
 //                       coalesced load each, fetched a tile ahead
-struct plaidhip_geneset {
-  plaidhip_ctx* ctx = nullptr;
-  int32_t g = 0, m = 0;
-  int64_t z = 0;
-  int32_t tiles = 0;
+// one gene slice (g0 .. g0+gs) of the prepared membership; g <= kMaxLdsGenes needs one slice
+struct plaidhip_slice {
+  int32_t g0 = 0, gs = 0;
   int32_t waves = 0;           // wavefronts per workgroup the plan was built for
-  int64_t chunks = 0;          // total 8-step chunks over all tiles
-  // device
+  int64_t chunks = 0;          // 8-step chunks over all tiles of this slice
   uint16_t* d_tile_idx = nullptr;
   int32_t* d_wave_chunk_off = nullptr;
   int32_t* d_wave_tile_off = nullptr;
@@ -74,9 +71,15 @@ struct plaidhip_geneset {
   int32_t* d_meta_j = nullptr;
   double* d_meta_w = nullptr;
   double* d_meta_k = nullptr;
-  int32_t* d_Gp = nullptr;     // plain CSC copy (fallback kernel, large-g path)
-  int32_t* d_Gi = nullptr;
-  bool lds_ok = false;         // g <= kMaxLdsGenes
+};
+
+struct plaidhip_geneset {
+  plaidhip_ctx* ctx = nullptr;
+  int32_t g = 0, m = 0;
+  int64_t z = 0;
+  int32_t tiles = 0;
+  int64_t chunks = 0;          // total over slices
+  std::vector<plaidhip_slice> slices;   // the column is consumed slice by slice when g > kMaxLdsGenes
 };
 
 namespace plaidhip {

@@ -151,7 +151,8 @@ struct HostPlan {
   int64_t chunks = 0;
 };
 
-void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, int waves, HostPlan& hp) {
+void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, const int32_t* total_size,
+                int waves, HostPlan& hp) {
   std::vector<int32_t> order(m);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(),
@@ -226,7 +227,7 @@ void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, int 
     for (int l = 0; l < 64; ++l) {
       const int32_t j = hp.lane_set[(size_t)hp.wtile_id[k] * 64 + l];
       if (j < 0) continue;
-      const double size = (double)(Gp[j + 1] - Gp[j]);
+      const double size = (double)total_size[j];   // the WHOLE set (all slices): colSums(G)
       hp.meta_j[k * 64 + l] = j;
       hp.meta_w[k * 64 + l] = 1.0 / (1e-8 + size);   // R/plaid.R:75-76
       hp.meta_k[k * 64 + l] = size;
@@ -276,29 +277,48 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
   gs->g = g;
   gs->m = m;
   gs->z = z;
-  gs->lds_ok = g <= kMaxLdsGenes;
   gs->tiles = (m + 63) / 64;
 
   int rc = PLAIDHIP_OK;
-  std::vector<int32_t> hGp(Gp, Gp + m + 1), hGi(Gi, Gi + z);
-  if ((rc = upload(ctx, hGp, &gs->d_Gp)) != PLAIDHIP_OK) goto fail;
-  if ((rc = upload(ctx, hGi, &gs->d_Gi)) != PLAIDHIP_OK) goto fail;
-  if (gs->lds_ok && m > 0) {
-    HostPlan hp;
-    gs->waves = spmm_block_for_genes(g) / 64;
-    build_plan(g, m, Gp, Gi, gs->waves, hp);
-    gs->chunks = hp.chunks;
-    if ((rc = upload(ctx, hp.idx, &gs->d_tile_idx)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.wave_chunk_off, &gs->d_wave_chunk_off)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.wave_tile_off, &gs->d_wave_tile_off)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.wtile_end, &gs->d_wtile_end)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.meta_j, &gs->d_meta_j)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.meta_w, &gs->d_meta_w)) != PLAIDHIP_OK) goto fail;
-    if ((rc = upload(ctx, hp.meta_k, &gs->d_meta_k)) != PLAIDHIP_OK) goto fail;
-    // host vectors die at scope exit: make sure the copies have landed
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
+  std::vector<int32_t> total(m);
+  for (int32_t j = 0; j < m; ++j) total[j] = Gp[j + 1] - Gp[j];
+  if (m > 0) {
+    // gene slices: the LDS holds at most kMaxLdsGenes 8-byte entries; wider matrices are consumed
+    // slice by slice (equal widths, even starts so 16-byte column loads stay aligned)
+    const int32_t nsl = (g + kMaxLdsGenes - 1) / kMaxLdsGenes;
+    int32_t width = (g + nsl - 1) / nsl;
+    width = (width + 1) & ~1;
+    for (int32_t g0 = 0; g0 < g; g0 += width) {
+      const int32_t gsz = std::min(width, g - g0);
+      // sub-pattern of this slice, rows re-based to the slice
+      std::vector<int32_t> sp(m + 1, 0), si;
+      si.reserve((size_t)z / nsl + 16);
+      for (int32_t j = 0; j < m; ++j) {
+        for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p)
+          if (Gi[p] >= g0 && Gi[p] < g0 + gsz) si.push_back(Gi[p] - g0);
+        sp[j + 1] = (int32_t)si.size();
+      }
+      HostPlan hp;
+      plaidhip_slice sl;
+      sl.g0 = g0;
+      sl.gs = gsz;
+      sl.waves = spmm_block_for_genes(gsz) / 64;
+      build_plan(gsz, m, sp.data(), si.data(), total.data(), sl.waves, hp);
+      sl.chunks = hp.chunks;
+      gs->chunks += hp.chunks;
+      gs->slices.push_back(sl);
+      plaidhip_slice& d = gs->slices.back();
+      if ((rc = upload(ctx, hp.idx, &d.d_tile_idx)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.wave_chunk_off, &d.d_wave_chunk_off)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.wave_tile_off, &d.d_wave_tile_off)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.wtile_end, &d.d_wtile_end)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.meta_j, &d.d_meta_j)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.meta_w, &d.d_meta_w)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, hp.meta_k, &d.d_meta_k)) != PLAIDHIP_OK) goto fail;
+      // host vectors die at scope exit: make sure the copies have landed
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
+    }
   }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   *out = gs;
   return PLAIDHIP_OK;
 fail:
@@ -308,15 +328,15 @@ fail:
 
 extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   if (!gs) return PLAIDHIP_OK;
-  hipFree(gs->d_tile_idx);
-  hipFree(gs->d_wave_chunk_off);
-  hipFree(gs->d_wave_tile_off);
-  hipFree(gs->d_wtile_end);
-  hipFree(gs->d_meta_j);
-  hipFree(gs->d_meta_w);
-  hipFree(gs->d_meta_k);
-  hipFree(gs->d_Gp);
-  hipFree(gs->d_Gi);
+  for (plaidhip_slice& d : gs->slices) {
+    hipFree(d.d_tile_idx);
+    hipFree(d.d_wave_chunk_off);
+    hipFree(d.d_wave_tile_off);
+    hipFree(d.d_wtile_end);
+    hipFree(d.d_meta_j);
+    hipFree(d.d_meta_w);
+    hipFree(d.d_meta_k);
+  }
   delete gs;
   return PLAIDHIP_OK;
 }
@@ -329,7 +349,7 @@ extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]
   info[2] = gs->z;
   info[3] = gs->chunks * 64 * 8;
   info[4] = gs->tiles;
-  info[5] = gs->lds_ok ? 1 : 0;
-  info[6] = gs->waves;
+  info[5] = (int64_t)gs->slices.size();   // gene slices (1 when the whole column fits the LDS)
+  info[6] = gs->slices.empty() ? 0 : gs->slices[0].waves;
   return PLAIDHIP_OK;
 }

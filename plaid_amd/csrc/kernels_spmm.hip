@@ -17,6 +17,8 @@
 //   * fp64 accumulation (4 partial sums per lane), epilogue per set:
 //       alpha * (sum * w) + beta * (k * w),  w = 1/(1e-8 + k) or 1,
 //     plus the min(x)==0 bookkeeping normalize_medians needs (R/plaid.R:556-557).
+//   * g > 20448 genes: the column is consumed in equal gene slices, one launch per slice;
+//     partial sums rest in S between launches (acc_mode), the epilogue runs in the last one.
 // Algorithmic HBM bytes per column: 8 g (X) + 8 m (S); the index lists (2 B per membership
 // slot) come from L2 once per column.
 #include "common.h"
@@ -29,7 +31,9 @@ struct SpmmArgs {
   const int32_t* Xp;
   const int32_t* Xi;
   const double* Xx;
-  int32_t g, n, m;
+  int32_t g, n, m;   // g: genes of THIS slice
+  int32_t g0;        // first gene of the slice (CSC rows are filtered / re-based by it)
+  int32_t acc_mode;  // 0 single slice; 1 first (store raw sum); 2 middle (S += sum); 3 last (S + sum, then epilogue)
   const uint4* tile_idx;
   const int32_t* wave_chunk_off;
   const int32_t* wave_tile_off;
@@ -166,7 +170,10 @@ spmm_colgather_f64(SpmmArgs a) {
       for (int i = tid; i < a.g + kPadSlots; i += BLOCK) col[i] = 0.0;
       __syncthreads();
       const int p0 = a.Xp[c], p1 = a.Xp[c + 1];
-      for (int p = p0 + tid; p < p1; p += BLOCK) col[a.Xi[p]] = a.Xx[p];
+      for (int p = p0 + tid; p < p1; p += BLOCK) {
+        const int r = a.Xi[p] - a.g0;
+        if (r >= 0 && r < a.g) col[r] = a.Xx[p];
+      }
     }
     __syncthreads();
     if constexpr (ABLATE == 4) ts1 = __builtin_amdgcn_s_memtime();
@@ -191,14 +198,20 @@ spmm_colgather_f64(SpmmArgs a) {
   s0 += V##4; s1 += V##5; s2 += V##6; s3 += V##7;
 #define PLAIDHIP_TILE_END(chv)                                                                 \
   if ((chv) + 1 == next_end) { /* wave-uniform: tile finished -> epilogue */                   \
-    const double sum = (s0 + s1) + (s2 + s3);                                                  \
+    double sum = (s0 + s1) + (s2 + s3);                                                        \
     if (mj >= 0) {                                                                             \
-      const double w = (a.stat == PLAIDHIP_STAT_MEAN) ? mw : 1.0;                              \
-      const double v = alpha * (sum * w) + a.beta * (mk * w);                                  \
-      __builtin_nontemporal_store(v, &a.S[(int64_t)c * a.lds + mj]);                           \
-      f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                             \
-      f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                           \
-      f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                              \
+      double* sp_ = &a.S[(int64_t)c * a.lds + mj];                                             \
+      if (a.acc_mode >= 2) sum += *sp_;               /* partial sums of earlier gene slices */ \
+      if (a.acc_mode == 1 || a.acc_mode == 2) {                                                \
+        *sp_ = sum;                                                                            \
+      } else {                                                                                 \
+        const double w = (a.stat == PLAIDHIP_STAT_MEAN) ? mw : 1.0;                            \
+        const double v = alpha * (sum * w) + a.beta * (mk * w);                                \
+        __builtin_nontemporal_store(v, sp_);                                                   \
+        f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                           \
+        f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                         \
+        f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                            \
+      }                                                                                        \
     }                                                                                          \
     ++k;                                                                                       \
     next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
@@ -324,39 +337,13 @@ spmm_colgather_f64(SpmmArgs a) {
 #undef PLAIDHIP_ST_ONE
 }
 
-// Fallback for g beyond the LDS-resident limit: one thread per (set, column), gene values
-// gathered straight from global memory (the column is L2-resident).  Correctness path.
-__global__ void __launch_bounds__(256)
-spmm_global_f64(const double* X, int64_t ldx, int32_t n, int32_t m, const int32_t* Gp,
-                const int32_t* Gi, int32_t stat, double alpha, const double* alpha_div, double beta,
-                double* S, int64_t lds, uint32_t* flags) {
-  uint32_t f = 0;
-  if (alpha_div != nullptr) alpha /= *alpha_div;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y;
-  if (j < m) {
-    const double* xc = X + (int64_t)c * ldx;
-    const int p0 = Gp[j], p1 = Gp[j + 1];
-    double s = 0.0;
-    for (int p = p0; p < p1; ++p) s += xc[Gi[p]];
-    const double k = (double)(p1 - p0);
-    const double w = (stat == PLAIDHIP_STAT_MEAN) ? 1.0 / (1e-8 + k) : 1.0;
-    const double v = alpha * (s * w) + beta * (k * w);
-    S[(int64_t)c * lds + j] = v;
-    f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;
-    f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;
-    f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;
-  }
-  publish_flags(f, flags);
-}
-
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_cast<unsigned long long*>(dbg); }
 
 template <bool CSC_X, int BLOCK>
-static int launch_one(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs& a) {
-  const size_t smem = (size_t)(gs->g + kPadSlots) * sizeof(double);
+static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) {
+  const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<CSC_X, BLOCK>),
@@ -390,31 +377,39 @@ static int launch_one(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs& a
   return PLAIDHIP_OK;
 }
 
+// One launch per gene slice; with several slices the partial sums live in S between launches.
 template <bool CSC_X>
-static int launch_colgather(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs& a) {
-  const int block = spmm_block_for_genes(gs->g);
-  if (block != gs->waves * 64) {
-    set_error("spmm: geneset plan was built for %d waves, kernel wants %d", gs->waves, block / 64);
-    return PLAIDHIP_EINVAL;
+static int launch_colgather(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs a) {
+  const int ns = (int)gs->slices.size();
+  const double* Xbase = a.X;
+  for (int si = 0; si < ns; ++si) {
+    const plaidhip_slice& sl = gs->slices[si];
+    a.g = sl.gs;
+    a.g0 = sl.g0;
+    a.acc_mode = ns == 1 ? 0 : (si == 0 ? 1 : (si == ns - 1 ? 3 : 2));
+    if (!CSC_X) a.X = Xbase + sl.g0;
+    a.tile_idx = reinterpret_cast<const uint4*>(sl.d_tile_idx);
+    a.wave_chunk_off = sl.d_wave_chunk_off;
+    a.wave_tile_off = sl.d_wave_tile_off;
+    a.wtile_end = sl.d_wtile_end;
+    a.meta_j = sl.d_meta_j;
+    a.meta_w = sl.d_meta_w;
+    a.meta_k = sl.d_meta_k;
+    const int block = sl.waves * 64;
+    int rc;
+    if (block == 1024) rc = launch_one<CSC_X, 1024>(ctx, sl, a);
+    else if (block == 512) rc = launch_one<CSC_X, 512>(ctx, sl, a);
+    else rc = launch_one<CSC_X, 256>(ctx, sl, a);
+    if (rc != PLAIDHIP_OK) return rc;
   }
-  if (block == 1024) return launch_one<CSC_X, 1024>(ctx, gs, a);
-  if (block == 512) return launch_one<CSC_X, 512>(ctx, gs, a);
-  return launch_one<CSC_X, 256>(ctx, gs, a);
+  return PLAIDHIP_OK;
 }
 
 static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int stat, double alpha,
                       const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
   a.alpha_div = alpha_div;
-  a.g = gs->g;
   a.n = n;
   a.m = gs->m;
-  a.tile_idx = reinterpret_cast<const uint4*>(gs->d_tile_idx);
-  a.wave_chunk_off = gs->d_wave_chunk_off;
-  a.wave_tile_off = gs->d_wave_tile_off;
-  a.wtile_end = gs->d_wtile_end;
-  a.meta_j = gs->d_meta_j;
-  a.meta_w = gs->d_meta_w;
-  a.meta_k = gs->d_meta_k;
   a.stat = stat;
   a.alpha = alpha;
   a.beta = beta;
@@ -427,29 +422,17 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (gs->lds_ok) {
-    SpmmArgs a{};
-    a.X = X;
-    a.ldx = ldx;
-    fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
-    return launch_colgather<false>(ctx, gs, a);
-  }
-  dim3 grid((gs->m + 255) / 256, n);
-  hipLaunchKernelGGL(spmm_global_f64, grid, dim3(256), 0, ctx->stream, X, ldx, n, gs->m, gs->d_Gp,
-                     gs->d_Gi, stat, alpha, alpha_div, beta, S, lds, flags);
-  PH_HIP(hipGetLastError());
-  return PLAIDHIP_OK;
+  SpmmArgs a{};
+  a.X = X;
+  a.ldx = ldx;
+  fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  return launch_colgather<false>(ctx, gs, a);
 }
 
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (!gs->lds_ok) {
-    set_error("spmm_csc: g=%d exceeds the LDS-resident limit %d (sparse-X large-g path not built yet)",
-              gs->g, kMaxLdsGenes);
-    return PLAIDHIP_EUNSUPPORTED;
-  }
   SpmmArgs a{};
   a.Xp = Xp;
   a.Xi = Xi;

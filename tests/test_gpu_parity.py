@@ -144,15 +144,22 @@ def test_spmm_seeded_vs_oracle_20k(hip_ctx):
     close(hip_ctx.plaid_dense(X, Gp, Gi), exp)
 
 
-def test_spmm_large_g_fallback(hip_ctx):
-    """g above the LDS-resident limit takes the global-gather kernel."""
+@pytest.mark.parametrize("g", [20449, 30001, 45000])
+def test_spmm_gene_sliced(hip_ctx, g):
+    """g above the LDS-resident limit: the column is consumed in 2-3 gene slices (dense and CSC X)"""
     from plaid_amd import synth as sy
-    g, n, m = 30000, 32, 150
+    n, m = 24, 150
     Gp, Gi = sy.geneset_csc(g, m)
     X = sy.dense_columns(g, 0, n)
     rn = [str(k) for k in range(g)]
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
-    close(hip_ctx.plaid_dense(X, Gp, Gi), _oracle().plaid(X, rn, G, rn))
+    exp = _oracle().plaid(X, rn, G, rn)
+    close(hip_ctx.plaid_dense(X, Gp, Gi), exp)
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "sum", False), _oracle().plaid(X, rn, G, rn, stats="sum", normalize=False))
+    Xz = X.copy()
+    Xz[np.random.default_rng(1).random(X.shape) < 0.9] = 0.0
+    Xs = sp.csc_matrix(Xz)
+    close(hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi), _oracle().plaid(Xs, rn, G, rn))
 
 
 @pytest.mark.parametrize("g", [1, 2, 63, 64, 65, 1000, 4097, 20000, 20448, 20449, 33000])

@@ -92,7 +92,7 @@ def main():
         b = g * n * 8 + 4 * z + 4 * (m + 1) + m * n * 8
         print(f"  algorithmic {b / 1e9:.3f} GB -> {b / min(ms) / 1e6:.1f} GB/s; "
               f"wave-gathers/column {info['padded_slots'] // 64} -> "
-              f"{min(ms) * 1e-3 * 2.4e9 / (n / 256) / (info['padded_slots'] / 64):.2f} cycles per wave-gather per CU @2.4GHz")
+              f"{min(ms) * 1e-3 * 2.4e9 / (n / 256) / max(info['padded_slots'] / 64, 1):.2f} cycles per wave-gather per CU @2.4GHz")
 
 
 if __name__ == "__main__":
