@@ -122,6 +122,13 @@ int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ld
 int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
                                   int ties, int is_signed, double power, void* Rx, void* colmax);
 
+/* colranks() on a dgCMatrix WITHOUT keep.zero (R/plaid.R:602-609 -> sparseMatrixStats::colRanks):
+ * the zeros are ranked too and the result is DENSE g x n -- same numbers as the dense branch on
+ * the densified matrix, computed from the CSC arrays on the device.                        */
+int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx,
+                                        int32_t g, int32_t n, int ties, int is_signed, double power,
+                                        void* R, int64_t ldr, void* colmax);
+
 /* normalize_medians() (R/plaid.R:554-575) in three phases so that a sample-sharded host
  * can all-reduce between them:
  *   1. flags  : plaidhip_dev_minflags   (or the SpMM epilogue's `flags`)  -> ignore.zero
@@ -160,6 +167,9 @@ int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32
 /* sparse_colranks(X, signed, ties.method), R/plaid.R:631-650: Rx_out has Xp[n] entries */
 int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
                           int ties, int is_signed, double* Rx_out);
+/* colranks(X sparse, keep.zero=FALSE), R/plaid.R:602-609: dense g x n result from CSC input */
+int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                                int32_t g, int32_t n, int ties, int is_signed, double* R_out);
 /* replaid.sing body, R/plaid.R:215-217 (dense X; G aligned to X's rows as above)         */
 int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                         const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out);

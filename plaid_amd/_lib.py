@@ -44,6 +44,7 @@ SIGNATURES = {
     "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _int, _int, _f64, _vp, _vp],
+    "plaidhip_dev_colranks_csc_dense_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_minflags": [_vp, _vp, _i64, _vp],
     "plaidhip_dev_col_medians": [_vp, _vp, _i64, _i32, _i32, _int, _vp, _vp],
     "plaidhip_dev_sum": [_vp, _vp, _i64, _vp],
@@ -54,6 +55,7 @@ SIGNATURES = {
     "plaidhip_normalize_medians": [_vp, _vp, _i32, _i32, _int, _vp],
     "plaidhip_colranks_dense": [_vp, _vp, _i32, _i32, _int, _int, _vp],
     "plaidhip_colranks_csc": [_vp, _vp, _vp, _i32, _int, _int, _vp],
+    "plaidhip_colranks_csc_dense": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _vp],
     "plaidhip_sing_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_ssgsea_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_ssgsea_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],

@@ -177,9 +177,13 @@ def colranks(X, sparse=None, signed=False, keep_zero=False, ties_method="average
     if sparse and keep_zero:
         return sparse_colranks(X, signed=signed, ties_method=ties_method, ctx=ctx)   # :600-601
     ctx = ctx or default_context()
-    # sparse without keep.zero: the reference's result is dense with the zeros ranked
-    # (sparseMatrixStats::colRanks, :603-609) -- same numbers as the dense branch (:612-618)
-    R = ctx.colranks_dense(X.dense(), ties_method, signed)
+    if X.is_sparse:
+        # sparse without keep.zero: the reference's result is dense with the zeros ranked
+        # (sparseMatrixStats::colRanks, :603-609) -- computed from the CSC arrays on the device
+        V = X.values
+        R = ctx.colranks_csc_dense(V.indptr, V.indices, V.data, X.shape[0], ties_method, signed)
+    else:
+        R = ctx.colranks_dense(X.values, ties_method, signed)                            # :612-618
     return NamedMatrix(R, X.rownames, X.colnames)
 
 

@@ -254,6 +254,18 @@ int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void*
                                  static_cast<double*>(colmax));
 }
 
+int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx,
+                                        int32_t g, int32_t n, int ties, int is_signed, double power,
+                                        void* R, int64_t ldr, void* colmax) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
+  PH_REQUIRE(n == 0 || g == 0 || (Xp && R), "colranks_csc_dense: null Xp/R");
+  return launch_colranks_csc_dense_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
+                                       static_cast<const double*>(Xx), g, n, ties, is_signed, power,
+                                       static_cast<double*>(R), ldr, static_cast<double*>(colmax));
+}
+
 int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags) {
   PH_CTX(ctx);
   PH_REQUIRE(flags != nullptr && count >= 0, "minflags: bad arguments");
@@ -407,6 +419,29 @@ int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx
   PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, ties, is_signed, 1.0,
                                  dR.as<double>(), nullptr));
   PH_HIP(hipMemcpyAsync(Rx_out, dR.p, (size_t)zx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                                int32_t g, int32_t n, int ties, int is_signed, double* R_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(g >= 0 && n >= 0 && Xp != nullptr, "colranks_csc_dense: bad arguments");
+  if ((int64_t)g * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(R_out != nullptr, "colranks_csc_dense: null R_out");
+  const int64_t zx = Xp[n];
+  DevBuf dXp, dXi, dXx, dR;
+  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
+  PH_TRY(dXi.alloc((size_t)zx * 4));
+  PH_TRY(dXx.alloc((size_t)zx * 8));
+  PH_TRY(dR.alloc((size_t)g * n * 8));
+  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
+  PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
+  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
+  PH_TRY(launch_colranks_csc_dense_f64(ctx, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), g, n, ties,
+                                       is_signed, 1.0, dR.as<double>(), g, nullptr));
+  PH_HIP(hipMemcpyAsync(R_out, dR.p, (size_t)g * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
 }

@@ -101,6 +101,9 @@ int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, i
                               double* colmax);
 int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
                             int ties, int is_signed, double power, double* Rx, double* colmax);
+int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                                  int32_t g, int32_t n, int ties, int is_signed, double power, double* R,
+                                  int64_t ldr, double* colmax);
 // kernels_norm.hip
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags);
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,

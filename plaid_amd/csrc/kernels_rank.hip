@@ -31,7 +31,9 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
                     int64_t ldx, int32_t g_dense,   // dense: column stride / length
                     const int32_t* __restrict__ Xp, // CSC: column pointers (nullptr for dense)
                     int32_t n, int ties, int is_signed, double power, double* __restrict__ R,
-                    int64_t ldr, double* __restrict__ colmax, uint64_t* gkeys, int64_t gkeys_stride) {
+                    int64_t ldr, double* __restrict__ colmax, uint64_t* gkeys, int64_t gkeys_stride,
+                    const int32_t* __restrict__ Xi_dense,  // non-null: CSC input, DENSE result (zeros ranked)
+                    double* __restrict__ dense_scratch) {  // g_dense doubles per workgroup
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
@@ -54,7 +56,20 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
     const double* xc;
     double* rc;
     uint32_t cnt;
-    if (Xp != nullptr) {
+    if (Xi_dense != nullptr) {
+      // colranks(sparse X, keep.zero=FALSE): the reference ranks the densified column
+      // (sparseMatrixStats::colRanks, R/plaid.R:603-609).  Densify into this workgroup's
+      // scratch column, then proceed exactly like the dense branch.
+      double* dcol = dense_scratch + (int64_t)blockIdx.x * g_dense;
+      for (int i = tid; i < g_dense; i += nthr) dcol[i] = 0.0;
+      __syncthreads();
+      const int p0 = Xp[c], p1 = Xp[c + 1];
+      for (int p = p0 + tid; p < p1; p += nthr) dcol[Xi_dense[p]] = Xv[p];
+      __syncthreads();
+      cnt = (uint32_t)g_dense;
+      xc = dcol;
+      rc = R + (int64_t)c * ldr;
+    } else if (Xp != nullptr) {
       const int p0 = Xp[c];
       cnt = (uint32_t)(Xp[c + 1] - p0);
       xc = Xv + p0;
@@ -124,8 +139,17 @@ __global__ void max_col_nnz_kernel(const int32_t* Xp, int32_t n, int32_t* out) {
 
 static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense,
                         const int32_t* Xp, int32_t n, int32_t max_len, int ties, int is_signed,
-                        double power, double* R, int64_t ldr, double* colmax) {
+                        double power, double* R, int64_t ldr, double* colmax,
+                        const int32_t* Xi_dense = nullptr) {
   if (n == 0 || max_len == 0) return PLAIDHIP_OK;
+  // CSC input with dense result: persistent grid, one scratch column per workgroup
+  double* dscratch = nullptr;
+  int grid_cap = n;
+  size_t ws_off = 0;
+  if (Xi_dense != nullptr) {
+    grid_cap = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
+    ws_off = (size_t)grid_cap * (size_t)g_dense * 8;
+  }
   const int block = max_len > 8192 ? 1024 : (max_len > 2048 ? 512 : 256);
   const size_t scratch = 16 + 16 * sizeof(double);
   if (max_len <= kMaxLdsGenes) {
@@ -137,18 +161,25 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
     }
     const int64_t key_slots = ((int64_t)max_len + 1) & ~1ll;  // keep scratch 16-B aligned
     const size_t smem = (size_t)key_slots * 8 + scratch;
-    hipLaunchKernelGGL(colranks_f64_kernel<false>, dim3(n), dim3(block), smem, ctx->stream, Xv, ldx,
+    if (Xi_dense != nullptr) {
+      int rc = ensure_workspace(ctx, ws_off);
+      if (rc != PLAIDHIP_OK) return rc;
+      dscratch = reinterpret_cast<double*>(ctx->ws);
+    }
+    hipLaunchKernelGGL(colranks_f64_kernel<false>, dim3(grid_cap), dim3(block), smem, ctx->stream, Xv, ldx,
                        g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, (uint64_t*)nullptr,
-                       key_slots);
+                       key_slots, Xi_dense, dscratch);
   } else {
     // large columns: keys live in a global scratch slice per workgroup (L2-resident)
     const int grid = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
     const int64_t stride = ((int64_t)max_len + 1) & ~1ll;
-    int rc = ensure_workspace(ctx, (size_t)grid * stride * 8);
+    int rc = ensure_workspace(ctx, ws_off + (size_t)grid * stride * 8);
     if (rc != PLAIDHIP_OK) return rc;
+    if (Xi_dense != nullptr) dscratch = reinterpret_cast<double*>(ctx->ws);
     hipLaunchKernelGGL(colranks_f64_kernel<true>, dim3(grid), dim3(1024), scratch, ctx->stream, Xv,
                        ldx, g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax,
-                       reinterpret_cast<uint64_t*>(ctx->ws), stride);
+                       reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ctx->ws) + ws_off), stride,
+                       Xi_dense, dscratch);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
@@ -158,6 +189,12 @@ int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, i
                               int ties, int is_signed, double power, double* R, int64_t ldr,
                               double* colmax) {
   return launch_ranks(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax);
+}
+
+int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                                  int32_t g, int32_t n, int ties, int is_signed, double power, double* R,
+                                  int64_t ldr, double* colmax) {
+  return launch_ranks(ctx, Xx, 0, g, Xp, n, g, ties, is_signed, power, R, ldr, colmax, Xi);
 }
 
 int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,

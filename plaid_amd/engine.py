@@ -172,6 +172,16 @@ class Context:
                                              int(bool(signed)), _np_ptr(R)))
         return R
 
+    def colranks_csc_dense(self, Xp, Xi, Xx, g: int, ties="average", signed=False) -> np.ndarray:
+        """colranks(sparse X, keep.zero=FALSE): zeros ranked, dense g x n result (R/plaid.R:602-609)"""
+        Xp, Xi = _as_i32(Xp), _as_i32(Xi)
+        Xx = np.ascontiguousarray(Xx, dtype=np.float64)
+        n = len(Xp) - 1
+        R = np.empty((int(g), n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_colranks_csc_dense(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n,
+                                                   TIES[ties], int(bool(signed)), _np_ptr(R)))
+        return R
+
     def sing_dense(self, X, Gp, Gi) -> np.ndarray:
         X = _as_f64_fortran(X)
         g, n = X.shape

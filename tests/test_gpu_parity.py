@@ -307,3 +307,20 @@ def test_device_level_chain_hip_phase_engine():
     close(Sss.cpu().numpy().T, po.replaid_ssgsea(X, rn, G, rn, alpha=0.25))
     gs.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("g", [300, 7728, 25000])
+def test_colranks_csc_dense_result(hip_ctx, g):
+    """colranks(sparse X, keep.zero=FALSE): zeros are ranked, dense result (R/plaid.R:602-609);
+    g=25000 also exercises the beyond-LDS key scratch together with the densify scratch"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(g)
+    X = np.round(rng.gamma(2.0, 1.0, size=(g, 7)), 1)
+    X[rng.random(X.shape) < 0.9] = 0.0
+    X[:, 3] = 0.0
+    X[::3, 5] *= -1.0
+    Xs = sp.csc_matrix(X)
+    for tm in ("average", "min"):
+        for signed in (False, True):
+            got = hip_ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, tm, signed)
+            assert np.array_equal(got, c_oracle.colranks_dense(X, tm, signed))
