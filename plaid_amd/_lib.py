@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libplaidhip.so")
+LIB_PATH = os.environ.get("PLAIDHIP_LIB") or os.path.join(_HERE, "csrc", "libplaidhip.so")   # override: A/B builds in tools/
 
 OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ENODEVICE = range(6)
 STAT = {"mean": 0, "sum": 1}

@@ -115,6 +115,179 @@ __device__ __forceinline__ void bitonic_sort_f64_lds(double* keys, uint32_t n) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-blocked version of the same normalised bitonic network for LDS-resident columns.
+// The workgroup has T = N/32 threads (N = network size, a power of two >= 2048); every pass a
+// thread pulls 32 keys into registers, runs up to FIVE network substages on them
+// (v_min_f64 / v_max_f64 compare-exchanges) and writes them back: 26 LDS round trips for
+// N = 32768 instead of 120.  Which 32 keys a thread owns changes per pass:
+//   pass A    : 32 contiguous keys            -> all of merge levels 1..5
+//   pass F(k) : keys { b ^ (c << (lk-5)), (b ^ (c << (lk-5))) ^ (k-1) },  c = 0..15
+//               -> flip(k) and the disperse substages of bits lk-2 .. lk-5
+//   pass D(b) : keys { base | (s << b_lo) }, s = 0..31, b_lo = max(0, b-4)
+//               -> the disperse substages of bits b .. b_lo
+// LDS positions are XOR-swizzled, phys(i) = i ^ ((i >> 5) & 31): every access pattern above is
+// bank-conflict free, and because phys() is GF(2)-linear an element address is
+// phys(base) ^ constant, i.e. one v_xor per key (the constants live in SGPRs).  Keys with index
+// >= n are virtual +inf: never stored, materialised on load.
+__device__ __forceinline__ uint32_t swz(uint32_t i) { return i ^ ((i >> 5) & 31u); }
+
+// compare-exchange = exactly v_min_f64 + v_max_f64.  (fmin()/fmax() make hipcc canonicalise
+// both inputs first -- v_max_f64 x, x -- which doubles the VALU work; the keys are never NaN.)
+#define PLAIDHIP_CE(a, b)                                                                         \
+  {                                                                                               \
+    double lo_, hi_;                                                                              \
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo_), "=&v"(hi_) : "v"(a), "v"(b)); \
+    a = lo_;                                                                                      \
+    b = hi_;                                                                                      \
+  }
+
+__device__ __forceinline__ double lds_key_load(const unsigned char* lds, uint32_t byte_addr, bool ok) {
+  return ok ? *reinterpret_cast<const double*>(lds + byte_addr) : INFINITY;
+}
+
+// disperse substages on local bits jmax..0 of a 32-key register block
+__device__ __forceinline__ void regs_disperse32(double (&v)[32], int jmax) {
+  if (jmax >= 4) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) PLAIDHIP_CE(v[s], v[s + 16])
+  }
+  if (jmax >= 3) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) if ((s & 8) == 0) PLAIDHIP_CE(v[s], v[s + 8])
+  }
+  if (jmax >= 2) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) if ((s & 4) == 0) PLAIDHIP_CE(v[s], v[s + 4])
+  }
+  if (jmax >= 1) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) if ((s & 2) == 0) PLAIDHIP_CE(v[s], v[s + 2])
+  }
+#pragma unroll
+  for (int s = 0; s < 32; s += 2) PLAIDHIP_CE(v[s], v[s + 1])
+}
+
+// pass A on a contiguous block: merge levels lk = 1..5 (flip + disperses each)
+__device__ __forceinline__ void regs_sort32(double (&v)[32]) {
+#pragma unroll
+  for (int s = 0; s < 32; s += 2) PLAIDHIP_CE(v[s], v[s + 1])                       // lk=1
+#pragma unroll
+  for (int b = 0; b < 32; b += 4) { PLAIDHIP_CE(v[b], v[b + 3]) PLAIDHIP_CE(v[b + 1], v[b + 2]) }   // flip(4)
+#pragma unroll
+  for (int s = 0; s < 32; s += 2) PLAIDHIP_CE(v[s], v[s + 1])
+#pragma unroll
+  for (int b = 0; b < 32; b += 8) {                                                    // flip(8)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) PLAIDHIP_CE(v[b + t], v[b + 7 - t])
+  }
+  regs_disperse32(v, 1);
+#pragma unroll
+  for (int b = 0; b < 32; b += 16) {                                                   // flip(16)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) PLAIDHIP_CE(v[b + t], v[b + 15 - t])
+  }
+  regs_disperse32(v, 2);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) PLAIDHIP_CE(v[t], v[31 - t])                            // flip(32)
+  regs_disperse32(v, 3);
+}
+
+// NATURAL: store to un-swizzled positions.  Only legal when the thread owns a whole aligned
+// 32-key group (b_lo == 0): the swizzle permutes inside such groups only, so no other thread
+// reads or writes these slots in the same pass.  Used for the very last pass of the sort.
+template <bool CHECK, bool NATURAL = false>
+__device__ __forceinline__ void bitonic_pass_D(unsigned char* lds, uint32_t n, uint32_t tid, int b_top) {
+  const int b_lo = b_top >= 4 ? b_top - 4 : 0;
+  const uint32_t t_lo = tid & ((1u << b_lo) - 1u), t_hi = tid >> b_lo;
+  const uint32_t base = (t_hi << (b_lo + 5)) | t_lo;
+  const uint32_t P0 = swz(base) << 3;
+  double v[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const uint32_t f = (uint32_t)s << b_lo;               // wave-uniform -> SALU
+    v[s] = lds_key_load(lds, P0 ^ (swz(f) << 3), !CHECK || (base | f) < n);
+  }
+  regs_disperse32(v, b_top - b_lo);
+  // recompute addresses / predicates for the store (opaque copies stop the compiler from keeping
+  // 32 address registers and 32 lane masks alive across the compare-exchange network -> spills)
+  uint32_t P1 = P0, base1 = base;
+  asm volatile("" : "+v"(P1), "+v"(base1));
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const uint32_t f = (uint32_t)s << b_lo;
+    if (!CHECK || (base1 | f) < n)
+      *reinterpret_cast<double*>(lds + (NATURAL ? ((base1 | f) << 3) : (P1 ^ (swz(f) << 3)))) = v[s];
+  }
+}
+
+template <bool CHECK>
+__device__ __forceinline__ void bitonic_pass_F(unsigned char* lds, uint32_t n, uint32_t tid, int lk) {
+  const int sh = lk - 5;
+  const uint32_t M = (1u << lk) - 1u;
+  const uint32_t t_lo = tid & ((1u << sh) - 1u), t_hi = tid >> sh;
+  const uint32_t base = (t_hi << lk) | t_lo;
+  const uint32_t P0 = swz(base) << 3, KM = swz(M) << 3;
+  double v[32];   // v[c] = key(base | c<<sh), v[16+c] = its flip partner key((base | c<<sh) ^ M)
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t f = (uint32_t)c << sh;
+    const uint32_t K = swz(f) << 3;
+    v[c] = lds_key_load(lds, P0 ^ K, !CHECK || (base | f) < n);
+    v[16 + c] = lds_key_load(lds, P0 ^ K ^ KM, !CHECK || ((base | f) ^ M) < n);
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) PLAIDHIP_CE(v[c], v[16 + c])                           // flip(k)
+  // disperse bits lk-2 .. lk-5 = local bits 3..0 of c.  In the partner half the index is the
+  // complement, so the LOWER index is the one with the local bit SET.
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if ((c & (1 << j)) == 0) {
+        PLAIDHIP_CE(v[c], v[c | (1 << j)])
+        PLAIDHIP_CE(v[16 + (c | (1 << j))], v[16 + c])
+      }
+  }
+  uint32_t P1 = P0, base1 = base;
+  asm volatile("" : "+v"(P1), "+v"(base1));
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t f = (uint32_t)c << sh;
+    const uint32_t K = swz(f) << 3;
+    if (!CHECK || (base1 | f) < n) *reinterpret_cast<double*>(lds + (P1 ^ K)) = v[c];
+    if (!CHECK || ((base1 | f) ^ M) < n) *reinterpret_cast<double*>(lds + (P1 ^ K ^ KM)) = v[16 + c];
+  }
+}
+
+// Sorts the n keys already placed at swizzled positions by pass A (see the rank kernel) -- i.e.
+// runs merge levels lk = 6 .. L for the network size N = 2^L = 32 * blockDim.x.  On return the
+// sorted keys sit at their NATURAL positions lds[0..n).
+__device__ __forceinline__ void bitonic_finish_regs(unsigned char* lds, uint32_t n, int L) {
+  for (int lk = 6; lk <= L; ++lk) {
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));     // opaque per level: no hoisting of per-thread address sets out of the loops
+    __syncthreads();
+    // a k-block that lies entirely below n needs no bounds checks (wave-uniform decision is not
+    // possible in general: threads of one wave sit in one block only when 2^lk >= 2048 -> decide
+    // per thread, both branches are the same code apart from the predicates)
+    const uint32_t blk_beg = (tid >> (lk - 5)) << lk, blk_end = blk_beg + (1u << lk);
+    if (blk_end <= n) bitonic_pass_F<false>(lds, n, tid, lk);
+    else if (blk_beg < n) bitonic_pass_F<true>(lds, n, tid, lk);      // else: only virtual +inf keys
+    for (int b_top = lk - 6; b_top >= 0; b_top -= 5) {
+      __syncthreads();
+      const int b_lo = b_top >= 4 ? b_top - 4 : 0;
+      const uint32_t span_beg = (tid >> b_lo) << (b_lo + 5), span_end = span_beg + (32u << b_lo);
+      if (lk == L && b_top < 5) {          // last pass of the whole sort: leave the keys in natural order
+        if (span_end <= n) bitonic_pass_D<false, true>(lds, n, tid, b_top);
+        else if (span_beg < n) bitonic_pass_D<true, true>(lds, n, tid, b_top);
+      } else if (span_end <= n) bitonic_pass_D<false>(lds, n, tid, b_top);
+      else if (span_beg < n) bitonic_pass_D<true>(lds, n, tid, b_top);
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t lower_bound_f64(const double* sorted, uint32_t n, double x) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {

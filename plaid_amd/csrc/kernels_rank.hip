@@ -5,7 +5,8 @@
 // Kernel shape: one workgroup per column.  The column's doubles (exact IEEE order, -0
 // canonicalised to +0, NaN parked at +inf and counted) are sorted IN PLACE in LDS (20k
 // doubles = 160 KB fill the CU's LDS exactly, so the sort carries no payload) by a bitonic
-// network whose compare-exchange is v_min_f64 + v_max_f64.  Ranks are then recovered by binary search of each element's key in the sorted
+// network whose compare-exchange is v_min_f64 + v_max_f64; LDS-resident columns use the
+// register-blocked form (32 keys per thread, up to five substages per LDS round trip).  Ranks are then recovered by binary search of each element's key in the sorted
 // keys: lb = #{x_j < x_i}, ub = #{x_j <= x_i};
 //   min = lb + 1,  max = ub,  average = (lb + 1 + ub) / 2      (bit-exact half-integers)
 // which is the definition of rank(ties.method=) for NaN-free input.  NaN inputs return NaN
@@ -124,6 +125,149 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
   }
 }
 
+// LDS-resident columns: register-blocked sort (device_sort.h), T = N/32 threads, N = 2^L.
+__global__ void __launch_bounds__(1024)
+colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense,
+                     const int32_t* __restrict__ Xp, int32_t n, int ties, int is_signed, double power,
+                     double* __restrict__ R, int64_t ldr, double* __restrict__ colmax, int L,
+                     int32_t key_bytes, const int32_t* __restrict__ Xi_dense,
+                     double* __restrict__ dense_scratch) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  unsigned char* keys = smem_raw;
+  uint32_t* s_u32 = reinterpret_cast<uint32_t*>(smem_raw + key_bytes);
+  double* s_f64 = reinterpret_cast<double*>(smem_raw + key_bytes + 16);
+
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* xc;
+    double* rc;
+    uint32_t cnt;
+    if (Xi_dense != nullptr) {
+      double* dcol = dense_scratch + (int64_t)blockIdx.x * g_dense;
+      for (int i = tid; i < g_dense; i += nthr) dcol[i] = 0.0;
+      __syncthreads();
+      const int p0 = Xp[c], p1 = Xp[c + 1];
+      for (int p = p0 + tid; p < p1; p += nthr) dcol[Xi_dense[p]] = Xv[p];
+      __syncthreads();
+      cnt = (uint32_t)g_dense;
+      xc = dcol;
+      rc = R + (int64_t)c * ldr;
+    } else if (Xp != nullptr) {
+      const int p0 = Xp[c];
+      cnt = (uint32_t)(Xp[c + 1] - p0);
+      xc = Xv + p0;
+      rc = R + p0;
+    } else {
+      cnt = (uint32_t)g_dense;
+      xc = Xv + (int64_t)c * ldx;
+      rc = R + (int64_t)c * ldr;
+    }
+    if (tid == 0) s_u32[0] = 0;
+    __syncthreads();
+    // ---- coalesced load -> LDS (swizzled positions), canonicalise, count NaN ------------
+    {
+      uint32_t my_nan = 0;
+      for (uint32_t i = tid; i < cnt; i += nthr) {
+        double x = xc[i];
+        if (is_signed) x = fabs(x);
+        const bool isnan_ = (x != x);
+        my_nan += isnan_;
+        *reinterpret_cast<double*>(keys + (swz(i) << 3)) = isnan_ ? INFINITY : (x + 0.0);   // -0 -> +0
+      }
+      if (my_nan) atomicAdd(&s_u32[0], my_nan);
+    }
+    __syncthreads();
+    // ---- pass A: 32 contiguous keys per thread: merge levels 1..5 in registers ----------
+    {
+      uint32_t tid_ = (uint32_t)tid;
+      asm volatile("" : "+v"(tid_));   // per-column opaque copy: keeps LICM from hoisting (and spilling) 32 addresses
+      const uint32_t base = tid_ * 32u;
+      if (base < cnt) {
+        double v[32];
+        const uint32_t P0 = swz(base) << 3;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+          v[s] = lds_key_load(keys, P0 ^ ((uint32_t)s << 3), base + s < cnt);
+        regs_sort32(v);
+        uint32_t P1 = P0, base1 = base;
+        asm volatile("" : "+v"(P1), "+v"(base1));
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+          if (base1 + s < cnt) *reinterpret_cast<double*>(keys + (P1 ^ ((uint32_t)s << 3))) = v[s];
+      }
+    }
+    bitonic_finish_regs(keys, cnt, L);   // starts and ends with a barrier
+    const uint32_t nvalid = cnt - s_u32[0];
+
+    // ---- ranks: lb = #{keys < x} by a branch-free binary search with a fixed trip count (two
+    //      elements interleaved for ILP); ub = #{keys <= x} by galloping from lb (tie runs are
+    //      short unless the data is tie-heavy, and then the gallop is still logarithmic)
+    const double* sk = reinterpret_cast<const double*>(keys);
+    int steps = 0;
+    while ((1u << steps) <= nvalid) ++steps;              // ceil(log2(nvalid + 1))
+    double vmax = -INFINITY;
+    for (uint32_t i0 = tid; i0 < cnt; i0 += 2 * nthr) {
+      const uint32_t i1 = i0 + nthr;
+      const bool has1 = i1 < cnt;
+      const double xa0 = xc[i0], xb0 = has1 ? xc[i1] : 0.0;
+      const double xa = is_signed ? fabs(xa0) : xa0, xb = is_signed ? fabs(xb0) : xb0;
+      uint32_t la = 0, lb_ = 0;
+      for (int k = steps - 1; k >= 0; --k) {
+        const uint32_t h = 1u << k;
+        const uint32_t pa = la + h, pb = lb_ + h;
+        const bool oka = pa <= nvalid, okb = pb <= nvalid;
+        const double ka = oka ? sk[pa - 1] : INFINITY, kb = okb ? sk[pb - 1] : INFINITY;
+        la = (oka && ka < xa) ? pa : la;
+        lb_ = (okb && kb < xb) ? pb : lb_;
+      }
+      auto upper_from = [&](uint32_t lo, double x) -> uint32_t {
+        // smallest u >= lo with sk[u] > x (or nvalid): gallop, then bisect the last interval
+        uint32_t step = 1, u = lo;
+        while (u + step <= nvalid && sk[u + step - 1] <= x) { u += step; step <<= 1; }
+        for (step >>= 1; step >= 1; step >>= 1)
+          if (u + step <= nvalid && sk[u + step - 1] <= x) u += step;
+        return u;
+      };
+      {
+        double r;
+        if (xa != xa) {
+          r = __longlong_as_double(0x7ff8000000000000ll);
+        } else {
+          r = rank_from_bounds(la, upper_from(la, xa), ties);
+          if (power != 1.0) r = pow(r, power);
+          if (is_signed) r *= sign_of(xa0);
+          vmax = (r > vmax) ? r : vmax;
+        }
+        rc[i0] = r;
+      }
+      if (has1) {
+        double r;
+        if (xb != xb) {
+          r = __longlong_as_double(0x7ff8000000000000ll);
+        } else {
+          r = rank_from_bounds(lb_, upper_from(lb_, xb), ties);
+          if (power != 1.0) r = pow(r, power);
+          if (is_signed) r *= sign_of(xb0);
+          vmax = (r > vmax) ? r : vmax;
+        }
+        rc[i1] = r;
+      }
+    }
+    if (colmax != nullptr) {
+      vmax = wave_max_f64(vmax);
+      if (lane == 0) s_f64[wave] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        double v = s_f64[0];
+        for (int w = 1; w < nwaves; ++w) v = (s_f64[w] > v) ? s_f64[w] : v;
+        colmax[c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void max_col_nnz_kernel(const int32_t* Xp, int32_t n, int32_t* out) {
   int32_t v = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -152,12 +296,34 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
   }
   const int block = max_len > 8192 ? 1024 : (max_len > 2048 ? 512 : 256);
   const size_t scratch = 16 + 16 * sizeof(double);
-  if (max_len <= kMaxLdsGenes) {
+  if (max_len > 8192 && max_len <= kMaxLdsGenes) {
+    // long LDS-resident columns: register-blocked sort (measured faster from N = 16384 up;
+    // below that the plain LDS network with more workgroups per CU wins)
     static bool attr_set = false;
     if (!attr_set) {
-      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_f64_kernel<false>),
+      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_regs_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
       attr_set = true;
+    }
+    int L = 11;                                  // network size N = 2^L >= 2048, T = N/32 threads
+    while ((1 << L) < max_len) ++L;
+    const int threads = (1 << L) / 32;
+    const int32_t key_bytes = ((max_len + 31) & ~31) * 8;     // swizzle permutes inside 32-key groups
+    const size_t smem = (size_t)key_bytes + scratch;
+    if (Xi_dense != nullptr) {
+      int rc = ensure_workspace(ctx, ws_off);
+      if (rc != PLAIDHIP_OK) return rc;
+      dscratch = reinterpret_cast<double*>(ctx->ws);
+    }
+    hipLaunchKernelGGL(colranks_regs_kernel, dim3(grid_cap), dim3(threads), smem, ctx->stream, Xv, ldx,
+                       g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, L, key_bytes, Xi_dense,
+                       dscratch);
+  } else if (max_len <= kMaxLdsGenes) {
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_f64_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      attr_set2 = true;
     }
     const int64_t key_slots = ((int64_t)max_len + 1) & ~1ll;  // keep scratch 16-B aligned
     const size_t smem = (size_t)key_slots * 8 + scratch;

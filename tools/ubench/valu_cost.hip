@@ -64,6 +64,17 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
                    "v_mul_f32_sdwa %7, %12, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
                    : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
                    : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(8.0f));
+    } else if (MODE == 8) {  // v_min_f64 / v_max_f64 pairs (compare-exchange of the bitonic sort)
+      asm volatile("v_min_f64 %0, %0, %8\n v_max_f64 %1, %1, %8\n v_min_f64 %2, %2, %8\n v_max_f64 %3, %3, %8\n"
+                   "v_min_f64 %4, %4, %8\n v_max_f64 %5, %5, %8\n v_min_f64 %6, %6, %8\n v_max_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));
+    } else if (MODE == 9) {  // 64-bit integer compare + 2x v_cndmask pairs (the u64-key alternative)
+      unsigned long long k0 = __double_as_longlong(a0), k1 = __double_as_longlong(a1);
+      asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n"
+                   "v_cmp_lt_u64 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc\n v_cndmask_b32 %5, %5, %4, vcc\n"
+                   "v_cmp_lt_u64 vcc, %0, %1\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                   : "+v"(k0), "+v"(k1), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "vcc");
+      a0 = __longlong_as_double(k0); a1 = __longlong_as_double(k1);
     } else if (MODE == 6) {  // ds_read only, no adds: LDS issue rate
       double v0, v1, v2, v3, v4, v5, v6, v7;
       asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
@@ -109,7 +120,7 @@ int main() {
 
   for (int t : {256, 512, 1024}) {
     run<0>("v_add_f64", t); run<1>("lshl_sdwa", t); run<2>("v_lshlrev", t); run<3>("v_add_f32", t);
-    run<7>("mul_f32_sdwa", t); run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
+    run<8>("min/max_f64", t); run<9>("cmp_u64+cnd", t); run<7>("mul_f32_sdwa", t); run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
   }
   return 0;
 }
