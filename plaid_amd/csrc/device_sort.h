@@ -35,33 +35,38 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t n) {
   const uint32_t nthr = blockDim.x;
   const uint32_t N = next_pow2(n);
   __syncthreads();
-  for (uint32_t k = 2; k <= N; k <<= 1) {
-    // flip: within each block of k, element t pairs with k-1-t
+  for (uint32_t lk = 1; (1u << lk) <= N; ++lk) {
+    const uint32_t k = 1u << lk;
     {
-      const uint32_t half = k >> 1;
-      for (uint32_t q = tid; q < (N >> 1); q += nthr) {
-        const uint32_t blk = q / half, t = q - blk * half;
-        const uint32_t l = blk * k + t;
-        const uint32_t r = blk * k + (k - 1 - t);
-        if (r < n) {
-          const uint64_t a = keys[l], b = keys[r];
-          if (a > b) { keys[l] = b; keys[r] = a; }
-        }
+      // flip: element t of a k-block pairs with k-1-t; only comparators whose upper index is < n
+      const uint32_t lh = lk - 1, half = k >> 1;
+      const uint32_t full = n >> lk, rem = n & (k - 1);
+      const uint32_t extra = rem > half ? rem - half : 0;
+      const uint32_t npairs = (full << lh) + extra;
+      for (uint32_t q = tid; q < npairs; q += nthr) {
+        uint32_t blk = q >> lh, t = q & (half - 1);
+        if (blk == full) t += (k - rem);
+        const uint32_t l = (blk << lk) + t;
+        const uint32_t r = (blk << lk) + (k - 1 - t);
+        const uint64_t a = keys[l], b = keys[r];
+        if (a > b) { keys[l] = b; keys[r] = a; }
       }
       __syncthreads();
     }
-    // disperse: distances k/4, k/8, ..., 1
-    for (uint32_t h = k >> 2; h >= 1; h >>= 1) {
-      for (uint32_t q = tid; q < (N >> 1); q += nthr) {
-        const uint32_t blk = q / h, t = q - blk * h;
-        const uint32_t l = blk * (h << 1) + t;
+    for (uint32_t lh = lk >= 2 ? lk - 2 : 0, go = lk >= 2; go; go = lh > 0, lh = lh ? lh - 1 : 0) {
+      const uint32_t h = 1u << lh;
+      const uint32_t full = n >> (lh + 1), rem = n & ((h << 1) - 1);
+      const uint32_t extra = rem > h ? rem - h : 0;
+      const uint32_t npairs = (full << lh) + extra;
+      for (uint32_t q = tid; q < npairs; q += nthr) {
+        const uint32_t blk = q >> lh, t = q & (h - 1);
+        const uint32_t l = (blk << (lh + 1)) + t;
         const uint32_t r = l + h;
-        if (r < n) {
-          const uint64_t a = keys[l], b = keys[r];
-          if (a > b) { keys[l] = b; keys[r] = a; }
-        }
+        const uint64_t a = keys[l], b = keys[r];
+        if (a > b) { keys[l] = b; keys[r] = a; }
       }
       __syncthreads();
+      if (lh == 0) break;
     }
   }
 }

@@ -6,6 +6,7 @@
 //                 (R/plaid.R:562-565), all-masked column -> 0 (R/plaid.R:566).  Even count:
 //                 mean of the two middle order statistics (matrixStats::colMedians).
 //   shift       : (x - med[col]) + add, add = mean(medx)                      (R/plaid.R:572)
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -267,6 +268,145 @@ col_medians_select_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
   }
 }
 
+// Sample-bracket selection: the fast median path.  One workgroup per column, keys streamed
+// from global memory (the column was just written by the SpMM: L2 / Infinity Cache resident).
+//   1. count the valid keys c; take s = BLOCK*SP keys at a fixed stride as a sample, sort it
+//      in LDS;
+//   2. the sample quantiles 4 sigma either side of the middle rank give a bracket [lo, hi]
+//      that contains the middle order statistics with probability > 0.9999;
+//   3. one sweep counts keys < lo, == lo, == hi and collects the keys strictly inside
+//      (about 4/sqrt(s) of the column) into LDS, which are sorted there;
+//   4. the middle ranks are read off the segments [<lo][==lo][inside][==hi].  A miss (rank
+//      outside the bracket, or more inside keys than fit) falls back to the exact radix
+//      select -- the result is exact either way; ties are handled by the == counters.
+// ITEMS > 0: the column's keys are loaded ONCE into ITEMS 64-bit registers per thread (all
+// loads in flight together) and every sweep runs from registers (m <= BLOCK*ITEMS).
+// ITEMS == 0: keys are streamed from L2 in batches of 8 independent loads per thread.
+template <int BLOCK, int ITEMS>
+__global__ void __launch_bounds__(BLOCK)
+col_medians_sample_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                          int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                          double* __restrict__ med, int32_t sp, int32_t cap) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  const int tid = threadIdx.x;
+  const int ns = BLOCK * sp;                              // sample slots
+  uint64_t* sample = reinterpret_cast<uint64_t*>(smem_raw);
+  uint64_t* inside = sample + ns;
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(inside + cap);   // [0] valid [1] <lo [2] ==lo [3] inside [4] ==hi
+  uint32_t* hist = cnt + 8;                                // 256 + 2: radix-select fallback scratch
+  constexpr int NK = ITEMS > 0 ? ITEMS : 1;
+  uint64_t key[NK];
+
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* sc = S + (int64_t)c * lds;
+    if (tid < 8) cnt[tid] = 0;
+    if constexpr (ITEMS > 0) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int i = tid + j * BLOCK;
+        const double v = sc[i < m ? i : m - 1];              // clamped: unconditional loads, all in flight
+        key[j] = (i < m) ? masked_key(v, ignore_zero) : ~0ull;
+      }
+    }
+    __syncthreads();
+    // one sweep over the column's keys: FN(key) for every element this thread owns
+#define PLAIDHIP_SWEEP(FN)                                                              \
+    if constexpr (ITEMS > 0) {                                                          \
+      _Pragma("unroll") for (int j = 0; j < ITEMS; ++j) { FN(key[j]) }                  \
+    } else {                                                                            \
+      for (int i0 = tid; i0 < m; i0 += 8 * BLOCK) {                                     \
+        double v_[8];                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                 \
+          const int i = i0 + u * BLOCK;                                                 \
+          v_[u] = sc[i < m ? i : m - 1];                                                \
+        }                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                 \
+          const uint64_t k_ = (i0 + u * BLOCK < m) ? masked_key(v_[u], ignore_zero) : ~0ull; \
+          FN(k_)                                                                        \
+        }                                                                               \
+      }                                                                                 \
+    }
+    // ---- 1. valid count + strided sample ----------------------------------------------
+    uint32_t valid = 0;
+#define PLAIDHIP_FN_VALID(k) valid += ((k) != ~0ull);
+    PLAIDHIP_SWEEP(PLAIDHIP_FN_VALID)
+#undef PLAIDHIP_FN_VALID
+    for (int off = 32; off >= 1; off >>= 1) valid += __shfl_xor(valid, off, 64);
+    if ((tid & 63) == 0 && valid) atomicAdd(&cnt[0], valid);
+    for (int j = tid; j < ns; j += BLOCK) {
+      const int64_t i = ((int64_t)j * m) / ns;
+      sample[j] = (m >= ns || j < m) ? masked_key(sc[m >= ns ? i : j], ignore_zero) : ~0ull;
+    }
+    bitonic_sort_lds(sample, (uint32_t)ns);               // starts and ends with a barrier
+    const uint32_t cv = cnt[0];
+    double r;
+    if (cv == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+      const uint32_t k_lo = (cv - 1) >> 1, k_hi = cv >> 1;
+      // valid samples are the ones below the all-ones key (masked keys sorted last)
+      uint32_t sv = lower_bound_lds(sample, (uint32_t)ns, ~0ull);
+      uint64_t lo = 0, hi = ~0ull - 1;                     // defaults: bracket = every valid key
+      if ((int64_t)cv > cap && sv >= 64) {
+        const double q = (double)sv / (double)cv;
+        const int32_t delta = (int32_t)(2.0 * sqrt((double)sv)) + 1;
+        const int32_t p_lo = (int32_t)(q * k_lo) - delta, p_hi = (int32_t)(q * k_hi) + delta + 1;
+        if (p_lo >= 0) lo = sample[p_lo];
+        if (p_hi < (int32_t)sv) hi = sample[p_hi];
+      }
+      // ---- 3. sweep: segment counts + collect the inside keys ---------------------------
+      uint32_t below = 0, eqlo = 0, eqhi = 0;
+#define PLAIDHIP_FN_SEG(k)                                           \
+      if ((k) != ~0ull) {                                            \
+        if ((k) < lo) ++below;                                       \
+        else if ((k) == lo) ++eqlo;                                  \
+        else if ((k) < hi) {                                         \
+          const uint32_t pos = atomicAdd(&cnt[3], 1u);               \
+          if (pos < (uint32_t)cap) inside[pos] = (k);                \
+        } else if ((k) == hi) ++eqhi;                                \
+      }
+      PLAIDHIP_SWEEP(PLAIDHIP_FN_SEG)
+#undef PLAIDHIP_FN_SEG
+#undef PLAIDHIP_SWEEP
+      for (int off = 32; off >= 1; off >>= 1) {
+        below += __shfl_xor(below, off, 64);
+        eqlo += __shfl_xor(eqlo, off, 64);
+        eqhi += __shfl_xor(eqhi, off, 64);
+      }
+      if ((tid & 63) == 0) {
+        if (below) atomicAdd(&cnt[1], below);
+        if (eqlo) atomicAdd(&cnt[2], eqlo);
+        if (eqhi) atomicAdd(&cnt[4], eqhi);
+      }
+      __syncthreads();
+      const uint32_t nb = cnt[3], c_below = cnt[1], c_eqlo = cnt[2], c_eqhi = cnt[4];
+      const bool fits = nb <= (uint32_t)cap;
+      if (fits) bitonic_sort_lds(inside, nb);               // uniform branch (nb is block-wide)
+      // ---- 4. read the two middle ranks off the segments ---------------------------------
+      auto resolve = [&](uint32_t k, uint64_t& out) -> bool {
+        if (!fits || k < c_below) return false;
+        uint32_t kk = k - c_below;
+        if (kk < c_eqlo) { out = lo; return true; }
+        kk -= c_eqlo;
+        if (kk < nb) { out = inside[kk]; return true; }
+        kk -= nb;
+        if (kk < c_eqhi) { out = hi; return true; }
+        return false;
+      };
+      uint64_t v1 = 0, v2 = 0;
+      const bool ok1 = resolve(k_lo, v1), ok2 = resolve(k_hi, v2);
+      if ((!ok1 || !ok2) && tid == 0 && flags != nullptr)   // flags[3] (reserved word) counts bracket misses
+        atomicAdd(const_cast<uint32_t*>(&flags[3]), 1u);
+      if (!ok1) v1 = radix_select_global(sc, m, ignore_zero, k_lo, hist, hist + 256);   // rare
+      if (!ok2) v2 = (k_hi == k_lo) ? v1 : radix_select_global(sc, m, ignore_zero, k_hi, hist, hist + 256);
+      r = (v1 == v2) ? key_to_f64(v1) : 0.5 * (key_to_f64(v1) + key_to_f64(v2));
+    }
+    if (tid == 0) med[c] = r;
+    __syncthreads();
+  }
+}
+
 // deterministic single-workgroup reductions (n samples: tiny)
 __global__ void __launch_bounds__(1024)
 sum_kernel(const double* __restrict__ v, int64_t count, double* out) {
@@ -344,7 +484,36 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");   // tools/: "sort" | "select" | unset
   const bool want_sort = force && force[0] == 's' && force[1] == 'o';
   const bool want_select = force && force[0] == 's' && force[1] == 'e';
-  if (!want_sort && !want_select && m <= 65536) {
+  const bool want_bits = (force && force[0] == 'b') || (!force && m <= 16384);
+  const bool want_sample = (force && force[0] == 's' && force[1] == 'a') || (!force && m > 16384);
+  if (want_sample) {
+    // measured on MI355X: the bitwise register kernel wins up to ~16k sets per column (0.57 vs
+    // 0.78 ms at m = 5k), the sample-bracket kernel beyond (m = 50k: 2.5 vs 5.0 ms per 4,096 columns)
+    // sample-bracket selection: BLOCK 512 up to 16k sets, 1024 beyond; the sample grows with m so
+    // that the expected number of keys inside the bracket (4 m / sqrt(samples)) stays below cap/2
+    const int block = m <= 16384 ? 512 : 1024;
+    const int cap = block * 8;
+    int sp = 1;
+    while (sp < 16 && 4.0 * m / sqrt((double)block * sp) > cap / 2) sp *= 2;
+    const size_t smem = ((size_t)block * sp + cap) * 8 + 8 * 4 + 258 * 4 + 16;
+#define PLAIDHIP_LAUNCH_SAMPLE(B, I, PER_CU)                                                             \
+  {                                                                                                       \
+    static bool attr_ = false;                                                                            \
+    if (!attr_) {                                                                                         \
+      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col_medians_sample_kernel<B, I>),         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));                 \
+      attr_ = true;                                                                                       \
+    }                                                                                                     \
+    const int cap_grid = ctx->num_cu * PER_CU * 4;                                                        \
+    hipLaunchKernelGGL((col_medians_sample_kernel<B, I>), dim3(n < cap_grid ? n : cap_grid), dim3(B), smem, \
+                       ctx->stream, S, lds, m, n, ignore_zero, flags, med, sp, cap);                      \
+  }
+    if (m <= 4096) PLAIDHIP_LAUNCH_SAMPLE(512, 8, 4)
+    else if (m <= 8192) PLAIDHIP_LAUNCH_SAMPLE(512, 16, 4)
+    else if (m <= 16384) PLAIDHIP_LAUNCH_SAMPLE(512, 32, 2)
+    else PLAIDHIP_LAUNCH_SAMPLE(1024, 0, 2)
+#undef PLAIDHIP_LAUNCH_SAMPLE
+  } else if (want_bits && m <= 65536) {
     if (m <= 2048) launch_bits<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 6144) launch_bits<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 16384) launch_bits<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);

@@ -41,6 +41,54 @@ def main():
     info = gs.info()
     print(f"geneset: gen {t1 - t0:.2f}s prepare {t2 - t1:.2f}s info {info} "
           f"slot efficiency {info['z'] / max(info['padded_slots'], 1):.3f}")
+    if a.kernel in ("c3", "c4"):
+        # BASELINE configs 3 / 4 at a reduced sample count: replaid.ssgsea on sparse (C3: ranks of the
+        # non-zeros, CSC SpMM) or dense (C4: dense ranks ^1.25, SpMM) input, 50k-set collections
+        def ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        med = torch.empty(n, dtype=torch.float64, device=dev)
+        red = torch.zeros(4, dtype=torch.float64, device=dev)
+        colmax = torch.empty(n, dtype=torch.float64, device=dev)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        if a.kernel == "c3":
+            Xp, Xi, Xx = synth.sparse_columns(g, 0, n)
+            dXp = torch.from_numpy(Xp.astype(np.int32)).to(dev)
+            dXi = torch.from_numpy(Xi).to(dev)
+            dXx = torch.from_numpy(Xx).to(dev)
+            dRx = torch.empty_like(dXx)
+            print(f"sparse X: nnz {len(Xx)} ({len(Xx)/n:.0f} per cell)")
+        else:
+            X = torch.randn((n, g), dtype=torch.float64, device=dev) * 2 + 8
+            R = torch.empty_like(X)
+        for it in range(a.iters):
+            with torch.cuda.stream(stream):
+                flags.zero_()
+                e0 = ev()
+                if a.kernel == "c3":
+                    ctx.dev_colranks_csc(dXp.data_ptr(), dXx.data_ptr(), n, dRx.data_ptr(), "average", False, 1.25, colmax.data_ptr())
+                else:
+                    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, "average", False, 1.25, colmax.data_ptr())
+                ctx.dev_max(colmax.data_ptr(), n, red.data_ptr() + 16)
+                e1 = ev()
+                if a.kernel == "c3":
+                    ctx.dev_spmm_csc(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
+                                     flags.data_ptr(), red.data_ptr() + 16)
+                else:
+                    ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
+                                       red.data_ptr() + 16)
+                e2 = ev()
+                ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+                ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
+                ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
+                e3 = ev()
+            torch.cuda.synchronize()
+            print(f"{a.kernel} ({g}x{n}x{m}): rank {e0.elapsed_time(e1):.3f} ms  spmm {e1.elapsed_time(e2):.3f} ms  "
+                  f"normalize {e2.elapsed_time(e3):.3f} ms  total {e0.elapsed_time(e3):.3f} ms -> "
+                  f"{m*n/e0.elapsed_time(e3)/1e-3:.3e} scores/s")
+        return
     if a.kernel == "host_plaid":
         # PCIe-inclusive rate of the host-pointer entry point (what R's .Call binds)
         Xh = np.asfortranarray(np.random.default_rng(0).normal(8, 2, size=(g, n)))
@@ -77,6 +125,8 @@ def main():
     torch.cuda.synchronize()
     ms = [e[0].elapsed_time(e[1]) for e in ev]
     print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
+    if a.kernel == "medians":
+        print("  flags words (3 = bracket misses over all launches):", flags.cpu().tolist())
     if a.ablate == 4:
         waves = info["waves"]
         nwg = min(n, 256)
