@@ -60,8 +60,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     g, n, m = a.genes, a.samples, a.sets
@@ -95,11 +99,11 @@ def main():
             ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
             if k is not None:
                 ev[k][1].record(stream)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX)                  # min(x)==0 over all shards
             ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
             ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(red, op=dist.ReduceOp.SUM)                    # mean(medx) over all shards
             ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
             if k is not None:
@@ -107,17 +111,17 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -147,19 +151,19 @@ def main():
 
     # ---- optional gather of the score shards to rank 0 (reported, never in `value`) --------
     gather = None
-    if world > 1 and not a.no_gather:
+    if use_dist and not a.no_gather:
         try:
-            bufs = [torch.empty_like(S) for _ in range(world)] if rank == 0 else None
+            from plaid_amd import sharded
             dist.barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            dist.gather(S, bufs, dst=0)
+            full = sharded.gather_scores(S, world * n, dst=0)   # grouped peer->root irecv/isend
             torch.cuda.synchronize()
             dist.barrier()
             tg = time.perf_counter() - tg
+            del full
             nbytes = (world - 1) * S.numel() * 8
             gather = {"ms": round(1e3 * tg, 3), "GB/s_into_root": round(nbytes / tg / 1e9, 1)}
-            del bufs
         except Exception as exc:  # pragma: no cover
             gather = {"error": str(exc)[:200]}
 
@@ -204,7 +208,7 @@ def main():
         print(json.dumps(out))
     gs.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

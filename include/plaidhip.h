@@ -182,6 +182,27 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
                         int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                         double alpha, double* S_out);
 
+/* ---- "next" rows of the scope table: thin callers of the same two kernels --------------- */
+
+/* replaid.ucell(X, matG, rmax), R/plaid.R:276-282: rX = colranks(X, "average");
+ * rX = pmin(max(rX) - rX, rmax + 1); S = plaid(rX, matG); S = 1 - S/rmax + (k_full + 1)/(2 rmax).
+ * X dense (Xp == NULL: X_or_x is g x n doubles) or dgCMatrix (zeros are ranked, R/plaid.R:602-609).
+ * k_full[m] = colSums(matG != 0) of the UN-aligned matrix, exactly as R/plaid.R:280 uses it.   */
+int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                   const double* k_full, double rmax, double* S_out);
+/* replaid.aucell(X, matG, aucMaxRank), R/plaid.R:304-309:
+ * ww = 1.08 * pmax((rX - (max(rX) - K)) / K, 0); plaid(ww, matG, stats = "mean").             */
+int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                    int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                    double auc_max_rank, double* S_out);
+/* replaid.scse(X, matG, removeLog2, scoreMean), R/plaid.R:155-190.  remove_log2: -1 = NULL (auto:
+ * min(X) == 0 && max(X) < 20, :160-161), 0, 1.  score_mean: 0 -> sum statistic, x100 (:180-182);
+ * 1 -> mean statistic divided by colMeans(|X|) (:175-177).                                   */
+int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                  int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                  int remove_log2, int score_mean, double* S_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -329,10 +329,14 @@ def replaid_aucell(X, rownames_x, matG, rownames_g, auc_max_rank=None):
 def replaid_scse(X, rownames_x, matG, rownames_g, remove_log2=None, score_mean=False):
     """R/plaid.R:155-190."""
     Xd = X.copy()
-    vals = Xd.data if sp.issparse(Xd) else Xd
-    if remove_log2 is None:
-        mn = min(vals.min(), 0.0) if sp.issparse(Xd) and Xd.nnz < np.prod(Xd.shape) else vals.min()
-        remove_log2 = bool(mn == 0 and vals.max() < 20)   # :160-161
+    if remove_log2 is None:                               # :160-161, min/max over ALL entries
+        if sp.issparse(Xd):
+            has_implicit = Xd.nnz < Xd.shape[0] * Xd.shape[1]
+            mn = min(Xd.data.min(), 0.0) if (has_implicit and Xd.nnz) else (Xd.data.min() if Xd.nnz else 0.0)
+            mx = max(Xd.data.max(), 0.0) if (has_implicit and Xd.nnz) else (Xd.data.max() if Xd.nnz else 0.0)
+        else:
+            mn, mx = np.nanmin(Xd), np.nanmax(Xd)
+        remove_log2 = bool(mn == 0 and mx < 20)
     if remove_log2:
         if sp.issparse(Xd):
             Xd.data = 2.0 ** Xd.data                      # :166

@@ -59,6 +59,9 @@ SIGNATURES = {
     "plaidhip_sing_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_ssgsea_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_ssgsea_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
+    "plaidhip_ucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _f64, _vp],
+    "plaidhip_aucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
+    "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
 }
 
 _lib = None

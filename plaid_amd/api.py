@@ -214,3 +214,52 @@ def replaid_ssgsea(X, matG, alpha=0, ctx: Context | None = None):
     else:
         S = ctx.ssgsea_dense(X.values, pat[0], pat[1], float(alpha))
     return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+def _set_sizes_unaligned(matG: NamedMatrix) -> np.ndarray:
+    """Matrix::colSums(matG != 0) of the matrix as given (R/plaid.R:280 does not re-align)."""
+    G = sp.csc_matrix(matG.values)
+    col = np.repeat(np.arange(G.shape[1]), np.diff(G.indptr))
+    return np.bincount(col[G.data != 0], minlength=G.shape[1]).astype(np.float64)
+
+
+def replaid_ucell(X, matG, rmax=1500, ctx: Context | None = None):
+    """replaid.ucell(), R/plaid.R:276-282."""
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    S = ctx.ucell(X.values, pat[0], pat[1], _set_sizes_unaligned(matG), float(rmax))
+    return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+def replaid_aucell(X, matG, aucMaxRank=None, ctx: Context | None = None):
+    """replaid.aucell(), R/plaid.R:304-309; aucMaxRank defaults to ceiling(0.05 * nrow(X))."""
+    X, matG = as_named(X), as_named(matG)
+    if aucMaxRank is None:
+        aucMaxRank = int(np.ceil(0.05 * X.shape[0]))
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    S = ctx.aucell(X.values, pat[0], pat[1], float(aucMaxRank))
+    return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+def replaid_scse(X, matG, removeLog2=None, scoreMean=False, ctx: Context | None = None):
+    """replaid.scse(), R/plaid.R:155-190."""
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    if removeLog2 is None:
+        pass
+    elif removeLog2:
+        _message("[replaid.scse] Converting data to linear scale (removing log2)...")
+    S = ctx.scse(X.values, pat[0], pat[1], removeLog2, scoreMean)
+    return NamedMatrix(S, matG.colnames, X.colnames)

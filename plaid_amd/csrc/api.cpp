@@ -37,6 +37,14 @@ int ensure_workspace(plaidhip_ctx* ctx, size_t bytes) {
   return PLAIDHIP_OK;
 }
 
+int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask) {
+  const uint32_t bit = 1u << (ctx->device & 31);
+  if (*done_mask & bit) return PLAIDHIP_OK;
+  PH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+  *done_mask |= bit;
+  return PLAIDHIP_OK;
+}
+
 }  // namespace plaidhip
 
 using namespace plaidhip;
@@ -536,6 +544,162 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
   PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dRx.as<double>(), n,
                              PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5, dS.as<double>(), m, d_flags));
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+}  // extern "C"
+
+// ---- "next" rows: ucell / aucell / scse ---------------------------------------------------
+namespace {
+
+// uploads X (dense when Xp == nullptr, else CSC) and produces the dense average ranks on the device
+struct RankedInput {
+  DevBuf dX, dXp, dXi, dR, dsmall;
+  double* R = nullptr;
+  double* d_colmax = nullptr;
+  double* d_gmax = nullptr;     // device scalar max(rX)
+};
+
+int dense_average_ranks(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                        int32_t g, int32_t n, RankedInput& ri) {
+  PH_TRY(ri.dR.alloc((size_t)g * n * 8));
+  PH_TRY(ri.dsmall.alloc(64 + (size_t)n * 8));
+  ri.R = ri.dR.as<double>();
+  ri.d_gmax = ri.dsmall.as<double>();
+  ri.d_colmax = reinterpret_cast<double*>(ri.dsmall.as<char>() + 64);
+  if (Xp == nullptr) {
+    PH_TRY(ri.dX.alloc((size_t)g * n * 8));
+    PH_TRY(h2d(ctx, ri.dX.p, X_or_x, (size_t)g * n * 8));
+    PH_TRY(launch_colranks_dense_f64(ctx, ri.dX.as<double>(), g, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.R, g,
+                                     ri.d_colmax));
+  } else {
+    const int64_t zx = Xp[n];
+    PH_TRY(ri.dXp.alloc((size_t)(n + 1) * 4));
+    PH_TRY(ri.dXi.alloc((size_t)zx * 4));
+    PH_TRY(ri.dX.alloc((size_t)zx * 8));
+    PH_TRY(h2d(ctx, ri.dXp.p, Xp, (size_t)(n + 1) * 4));
+    PH_TRY(h2d(ctx, ri.dXi.p, Xi, (size_t)zx * 4));
+    PH_TRY(h2d(ctx, ri.dX.p, X_or_x, (size_t)zx * 8));
+    PH_TRY(launch_colranks_csc_dense_f64(ctx, ri.dXp.as<int32_t>(), ri.dXi.as<int32_t>(), ri.dX.as<double>(), g, n,
+                                         PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.R, g, ri.d_colmax));
+  }
+  PH_TRY(launch_max(ctx, ri.d_colmax, n, ri.d_gmax));
+  return PLAIDHIP_OK;
+}
+
+int plaid_on_device(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* dX, int32_t g, int32_t n, int32_t m,
+                    int stat, int normalize, double* dS, DevBuf& dsmall) {
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_dense_f64(ctx, gs, dX, g, n, stat, 1.0, nullptr, 0.0, dS, m, d_flags));
+  if (normalize) PH_TRY(normalize_on_device(ctx, dS, m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
+  return PLAIDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                   const double* k_full, double rmax, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(rmax > 0, "ucell: rmax must be positive");
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X_or_x && S_out && k_full, "ucell: null X/S_out/k_full");
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  RankedInput ri;
+  PH_TRY(dense_average_ranks(ctx, Xp, Xi, X_or_x, g, n, ri));
+  PH_TRY(launch_map(ctx, ri.R, (int64_t)g * n, 0, rmax + 1.0, ri.d_gmax));            // R/plaid.R:278
+  DevBuf dS, dsmall, dadd;
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(plaid_on_device(ctx, gh.gs, ri.R, g, n, m, PLAIDHIP_STAT_MEAN, 1, dS.as<double>(), dsmall));   // :279
+  std::vector<double> add(m);
+  for (int32_t j = 0; j < m; ++j) add[j] = 1.0 + (k_full[j] + 1.0) / (2.0 * rmax);   // :280
+  PH_TRY(dadd.alloc((size_t)m * 8));
+  PH_TRY(h2d(ctx, dadd.p, add.data(), (size_t)m * 8));
+  PH_TRY(launch_affine(ctx, dS.as<double>(), m, m, n, -1.0 / rmax, nullptr, 1.0, dadd.as<double>(), 0.0));
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                    int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                    double auc_max_rank, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(auc_max_rank > 0, "aucell: aucMaxRank must be positive");
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X_or_x && S_out, "aucell: null X/S_out");
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  RankedInput ri;
+  PH_TRY(dense_average_ranks(ctx, Xp, Xi, X_or_x, g, n, ri));
+  PH_TRY(launch_map(ctx, ri.R, (int64_t)g * n, 1, auc_max_rank, ri.d_gmax));         // R/plaid.R:306
+  DevBuf dS, dsmall;
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(plaid_on_device(ctx, gh.gs, ri.R, g, n, m, PLAIDHIP_STAT_MEAN, 1, dS.as<double>(), dsmall));   // :307
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                  int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
+                  int remove_log2, int score_mean, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X_or_x && S_out, "scse: null X/S_out");
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  const bool sparse = Xp != nullptr;
+  const int64_t nvals = sparse ? (int64_t)Xp[n] : (int64_t)g * n;
+  DevBuf dX, dXp, dXi, dS, dsmall, dcol;
+  PH_TRY(dX.alloc((size_t)nvals * 8));
+  PH_TRY(h2d(ctx, dX.p, X_or_x, (size_t)nvals * 8));
+  if (sparse) {
+    PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
+    PH_TRY(dXi.alloc((size_t)nvals * 4));
+    PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
+    PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)nvals * 4));
+  }
+  PH_TRY(dcol.alloc(64 + (size_t)n * 8));
+  double* d_mm = dcol.as<double>();
+  double* d_colsum = reinterpret_cast<double*>(dcol.as<char>() + 64);
+  if (remove_log2 < 0) {                                        // R/plaid.R:160-161
+    PH_TRY(launch_minmax(ctx, dX.as<double>(), nvals, d_mm));
+    double mm[2];
+    PH_HIP(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (sparse && nvals < (int64_t)g * n) {                     // implicit zeros take part in min / max
+      mm[0] = mm[0] < 0.0 ? mm[0] : 0.0;
+      mm[1] = mm[1] > 0.0 ? mm[1] : 0.0;
+    }
+    remove_log2 = (mm[0] == 0.0 && mm[1] < 20.0) ? 1 : 0;
+  }
+  if (remove_log2) PH_TRY(launch_map(ctx, dX.as<double>(), nvals, sparse ? 3 : 2, 0.0, nullptr));   // :163-171
+  PH_TRY(launch_col_abs_sums(ctx, dX.as<double>(), g, g, sparse ? dXp.as<int32_t>() : nullptr, n, d_colsum));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  const int stat = score_mean ? PLAIDHIP_STAT_MEAN : PLAIDHIP_STAT_SUM;
+  if (sparse) {
+    PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dX.as<double>(), n, stat, 1.0,
+                               nullptr, 0.0, dS.as<double>(), m, nullptr));
+  } else {
+    PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), g, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m,
+                                 nullptr));
+  }
+  // mean: sX / (colMeans|X| + 1e-8) (:176-177); sum: sX / (colSums|X| + 1e-8) * 100 (:181-182)
+  PH_TRY(launch_affine(ctx, dS.as<double>(), m, m, n, score_mean ? 1.0 : 100.0, d_colsum,
+                       score_mean ? 1.0 / (double)g : 1.0, nullptr, 0.0));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;

@@ -85,6 +85,14 @@ struct plaidhip_geneset {
 namespace plaidhip {
 
 int ensure_workspace(plaidhip_ctx* ctx, size_t bytes);
+// opt a kernel into the full 160 KiB of dynamic LDS, once per (kernel, device)
+int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask);
+#define PH_FULL_LDS(ctx, kernel)                                                          \
+  do {                                                                                    \
+    static uint32_t mask_ = 0;                                                            \
+    int rc_l_ = ::plaidhip::allow_full_lds((ctx), reinterpret_cast<const void*>(kernel), &mask_); \
+    if (rc_l_ != PLAIDHIP_OK) return rc_l_;                                               \
+  } while (0)
 int spmm_block_for_genes(int32_t g);   // workgroup size of the column-resident SpMM kernel
 
 // kernels_spmm.hip
@@ -112,5 +120,13 @@ int launch_sum(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,
                          const double* med, double add, const double* red);
+
+// element-wise / column helpers (replaid.ucell / aucell / scse)
+int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar);
+int launch_col_abs_sums(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t len, const int32_t* Xp,
+                        int32_t n, double* out);
+int launch_affine(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n, double mul,
+                  const double* col_div, double div_scale, const double* row_add, double add);
+int launch_minmax(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 
 }  // namespace plaidhip

@@ -459,6 +459,108 @@ shift_columns_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
   }
 }
 
+// ---- element-wise / column helpers for the rank-transform callers -------------------------
+// (replaid.ucell R/plaid.R:276-282, replaid.aucell :304-309, replaid.scse :155-190)
+__global__ void __launch_bounds__(256)
+map_kernel(double* __restrict__ v, int64_t count, int op, double p0, const double* __restrict__ scalar) {
+  const double sc = scalar != nullptr ? *scalar : 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    double x = v[i];
+    if (op == 0) x = fmin(sc - x, p0);                                 // pmin(max(rX) - rX, rmax + 1)
+    else if (op == 1) x = 1.08 * fmax((x - (sc - p0)) / p0, 0.0);      // 1.08 * pmax((rX - (max - K)) / K, 0)
+    else if (op == 2) x = (x > 0.0) ? exp2(x) : x;                     // X[X > 0] <- 2 ** X[X > 0]
+    else x = exp2(x);                                                  // X@x <- 2 ** X@x
+    v[i] = x;
+  }
+}
+
+// out[c] = sum |X[, c]| over a dense column (len rows) or the stored values of a CSC column
+__global__ void __launch_bounds__(256)
+col_abs_sums_kernel(const double* __restrict__ X, int64_t ldx, int32_t len, const int32_t* __restrict__ Xp,
+                    int32_t n, double* __restrict__ out) {
+  __shared__ double s_part[4];
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* xc = Xp ? X + Xp[c] : X + (int64_t)c * ldx;
+    const int cnt = Xp ? Xp[c + 1] - Xp[c] : len;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 256) s += fabs(xc[i]);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    __syncthreads();
+  }
+}
+
+// S[j, c] = S[j, c] * mul / (col_div ? col_div[c] * div_scale + 1e-8 : 1) + (row_add ? row_add[j] : 0) + add
+__global__ void __launch_bounds__(256)
+affine_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n, double mul,
+              const double* __restrict__ col_div, double div_scale, const double* __restrict__ row_add, double add) {
+  for (int c = blockIdx.y; c < n; c += gridDim.y) {
+    double* sc = S + (int64_t)c * lds;
+    const double f = col_div ? mul / (col_div[c] * div_scale + 1e-8) : mul;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+      sc[i] = sc[i] * f + (row_add ? row_add[i] : 0.0) + add;
+  }
+}
+
+// out[0] = min, out[1] = max over non-NaN values (single workgroup, deterministic)
+__global__ void __launch_bounds__(1024)
+minmax_kernel(const double* __restrict__ v, int64_t count, double* out) {
+  __shared__ double s_mn[1024], s_mx[1024];
+  const int tid = threadIdx.x;
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = tid; i < count; i += 1024) {
+    const double x = v[i];
+    if (x == x) { mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+  }
+  s_mn[tid] = mn; s_mx[tid] = mx;
+  __syncthreads();
+  for (int h = 512; h >= 1; h >>= 1) {
+    if (tid < h) {
+      s_mn[tid] = s_mn[tid + h] < s_mn[tid] ? s_mn[tid + h] : s_mn[tid];
+      s_mx[tid] = s_mx[tid + h] > s_mx[tid] ? s_mx[tid + h] : s_mx[tid];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = s_mn[0]; out[1] = s_mx[0]; }
+}
+
+int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar) {
+  if (count == 0) return PLAIDHIP_OK;
+  int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(map_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, v, count, op, p0, scalar);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_col_abs_sums(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t len, const int32_t* Xp,
+                        int32_t n, double* out) {
+  if (n == 0) return PLAIDHIP_OK;
+  hipLaunchKernelGGL(col_abs_sums_kernel, dim3(n < 8192 ? n : 8192), dim3(256), 0, ctx->stream, X, ldx, len, Xp, n, out);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_affine(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n, double mul,
+                  const double* col_div, double div_scale, const double* row_add, double add) {
+  if (n == 0 || m == 0) return PLAIDHIP_OK;
+  int bx = (m + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(affine_kernel, dim3(bx, n < 32768 ? n : 32768), dim3(256), 0, ctx->stream, S, lds, m, n, mul,
+                     col_div, div_scale, row_add, add);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_minmax(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
+  hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, count, out);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags) {
   if (count == 0) return PLAIDHIP_OK;
   int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
@@ -498,12 +600,7 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
     const size_t smem = ((size_t)block * sp + cap) * 8 + 8 * 4 + 258 * 4 + 16;
 #define PLAIDHIP_LAUNCH_SAMPLE(B, I, PER_CU)                                                             \
   {                                                                                                       \
-    static bool attr_ = false;                                                                            \
-    if (!attr_) {                                                                                         \
-      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col_medians_sample_kernel<B, I>),         \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));                 \
-      attr_ = true;                                                                                       \
-    }                                                                                                     \
+    PH_FULL_LDS(ctx, (&col_medians_sample_kernel<B, I>));                                                 \
     const int cap_grid = ctx->num_cu * PER_CU * 4;                                                        \
     hipLaunchKernelGGL((col_medians_sample_kernel<B, I>), dim3(n < cap_grid ? n : cap_grid), dim3(B), smem, \
                        ctx->stream, S, lds, m, n, ignore_zero, flags, med, sp, cap);                      \
@@ -520,12 +617,7 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
     else if (m <= 32768) launch_bits<1024, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_bits<1024, 64>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (!want_select && m <= kMaxLdsGenes) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col_medians_lds_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      attr_set = true;
-    }
+    PH_FULL_LDS(ctx, &col_medians_lds_kernel);
     const int block = m > 8192 ? 1024 : (m > 2048 ? 512 : 256);
     const int32_t key_slots = (m + 1) & ~1;
     const size_t smem = (size_t)key_slots * 8 + 16;

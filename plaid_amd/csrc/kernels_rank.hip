@@ -299,12 +299,7 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
   if (max_len > 8192 && max_len <= kMaxLdsGenes) {
     // long LDS-resident columns: register-blocked sort (measured faster from N = 16384 up;
     // below that the plain LDS network with more workgroups per CU wins)
-    static bool attr_set = false;
-    if (!attr_set) {
-      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_regs_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      attr_set = true;
-    }
+    PH_FULL_LDS(ctx, &colranks_regs_kernel);
     int L = 11;                                  // network size N = 2^L >= 2048, T = N/32 threads
     while ((1 << L) < max_len) ++L;
     const int threads = (1 << L) / 32;
@@ -319,12 +314,7 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
                        g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, L, key_bytes, Xi_dense,
                        dscratch);
   } else if (max_len <= kMaxLdsGenes) {
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-      PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&colranks_f64_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      attr_set2 = true;
-    }
+    PH_FULL_LDS(ctx, &colranks_f64_kernel<false>);
     const int64_t key_slots = ((int64_t)max_len + 1) & ~1ll;  // keep scratch 16-B aligned
     const size_t smem = (size_t)key_slots * 8 + scratch;
     if (Xi_dense != nullptr) {

@@ -344,12 +344,7 @@ void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_c
 template <bool CSC_X, int BLOCK>
 static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) {
   const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<CSC_X, BLOCK>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set = true;
-  }
+  PH_FULL_LDS(ctx, (&spmm_colgather_f64<CSC_X, BLOCK>));
   // persistent: as many workgroups as fit on the chip at once (LDS- or wave-limited)
   int per_cu = (int)(kLdsBytes / smem);
   const int wave_cap = 2048 / BLOCK;

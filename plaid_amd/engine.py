@@ -213,6 +213,54 @@ class Context:
         return S
 
 
+def _x_args(X):
+    """(Xp, Xi, values, g, n, keepalive) for a dense ndarray or a scipy CSC matrix."""
+    import scipy.sparse as sp
+    if sp.issparse(X):
+        X = sp.csc_matrix(X)
+        Xp, Xi = _as_i32(X.indptr), _as_i32(X.indices)
+        Xx = np.ascontiguousarray(X.data, dtype=np.float64)
+        return _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), X.shape[0], X.shape[1], (Xp, Xi, Xx)
+    Xd = _as_f64_fortran(X)
+    return None, None, _np_ptr(Xd), Xd.shape[0], Xd.shape[1], (Xd,)
+
+
+def _ucell(self, X, Gp, Gi, k_full, rmax=1500.0):
+    xp, xi, xv, g, n, keep = _x_args(X)
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    kf = np.ascontiguousarray(k_full, dtype=np.float64)
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    check(self.lib.plaidhip_ucell(self.handle, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m, _np_ptr(kf),
+                                  float(rmax), _np_ptr(S)))
+    return S
+
+
+def _aucell(self, X, Gp, Gi, auc_max_rank):
+    xp, xi, xv, g, n, keep = _x_args(X)
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    check(self.lib.plaidhip_aucell(self.handle, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m,
+                                   float(auc_max_rank), _np_ptr(S)))
+    return S
+
+
+def _scse(self, X, Gp, Gi, remove_log2=None, score_mean=False):
+    xp, xi, xv, g, n, keep = _x_args(X)
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    rl = -1 if remove_log2 is None else int(bool(remove_log2))
+    check(self.lib.plaidhip_scse(self.handle, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m, rl,
+                                 int(bool(score_mean)), _np_ptr(S)))
+    return S
+
+
+Context.ucell = _ucell
+Context.aucell = _aucell
+Context.scse = _scse
+
 _default_ctx: Context | None = None
 
 

@@ -93,3 +93,40 @@ replaid.ssgsea <- function(X, matG, alpha = 0) {
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }
+
+## X as the argument triple the shim expects: (p, i, values) for a dgCMatrix, (NULL, NULL, matrix) otherwise
+.x_args <- function(X) {
+  if (inherits(X, "CsparseMatrix")) list(X@p, X@i, as.double(X@x))
+  else { D <- as.matrix(X); storage.mode(D) <- "double"; list(NULL, NULL, D) }
+}
+
+replaid.ucell <- function(X, matG, rmax = 1500) {
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  xa <- .x_args(X)
+  S <- .Call("R_plaidhip_ucell", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
+             as.double(Matrix::colSums(matG != 0)), as.double(rmax), PACKAGE = "plaidhip")
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}
+
+replaid.aucell <- function(X, matG, aucMaxRank = ceiling(0.05 * nrow(X))) {
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  xa <- .x_args(X)
+  S <- .Call("R_plaidhip_aucell", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
+             as.double(aucMaxRank), PACKAGE = "plaidhip")
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}
+
+replaid.scse <- function(X, matG, removeLog2 = NULL, scoreMean = FALSE) {
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  xa <- .x_args(X)
+  S <- .Call("R_plaidhip_scse", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
+             if (is.null(removeLog2)) NA else as.logical(removeLog2), as.logical(scoreMean),
+             PACKAGE = "plaidhip")
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}

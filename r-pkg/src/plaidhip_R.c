@@ -99,6 +99,37 @@ SEXP R_plaidhip_ssgsea_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi, 
   return S;
 }
 
+/* X: numeric matrix or NULL; for a dgCMatrix pass Xp/Xi/Xx (else R_NilValue) */
+static const int* int_or_null(SEXP x) { return Rf_isNull(x) ? NULL : INTEGER(x); }
+
+SEXP R_plaidhip_ucell(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP kfull, SEXP rmax) {
+  const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  check(plaidhip_ucell(ctx(), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g), nn, INTEGER(Gp),
+                       INTEGER(Gi), m, REAL(kfull), Rf_asReal(rmax), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_aucell(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP auc_max_rank) {
+  const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  check(plaidhip_aucell(ctx(), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g), nn, INTEGER(Gp),
+                        INTEGER(Gi), m, Rf_asReal(auc_max_rank), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_scse(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP remove_log2, SEXP score_mean) {
+  const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
+  const int rl = Rf_asLogical(remove_log2);
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  check(plaidhip_scse(ctx(), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g), nn, INTEGER(Gp),
+                      INTEGER(Gi), m, rl == NA_LOGICAL ? -1 : rl, Rf_asLogical(score_mean), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
@@ -108,6 +139,9 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_sing_dense", (DL_FUNC)&R_plaidhip_sing_dense, 3},
     {"R_plaidhip_ssgsea_dense", (DL_FUNC)&R_plaidhip_ssgsea_dense, 4},
     {"R_plaidhip_ssgsea_csc", (DL_FUNC)&R_plaidhip_ssgsea_csc, 7},
+    {"R_plaidhip_ucell", (DL_FUNC)&R_plaidhip_ucell, 9},
+    {"R_plaidhip_aucell", (DL_FUNC)&R_plaidhip_aucell, 8},
+    {"R_plaidhip_scse", (DL_FUNC)&R_plaidhip_scse, 9},
     {NULL, NULL, 0}};
 
 void R_init_plaidhip(DllInfo* dll) {

@@ -324,3 +324,32 @@ def test_colranks_csc_dense_result(hip_ctx, g):
         for signed in (False, True):
             got = hip_ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, tm, signed)
             assert np.array_equal(got, c_oracle.colranks_dense(X, tm, signed))
+
+
+def _small_named(sparse):
+    import plaid_amd
+    rng = np.random.default_rng(21)
+    g, n, m = 900, 17, 31
+    X = np.round(rng.gamma(2.0, 1.5, size=(g, n)), 1)
+    X[rng.random(X.shape) < (0.85 if sparse else 0.3)] = 0.0
+    rn = [f"g{k}" for k in range(g)]
+    grn = [f"g{k}" for k in range(0, g + 60, 1)][30:]          # partial overlap with X's genes
+    Gd = (rng.random((len(grn), m)) < 0.04).astype(float)
+    Xn = plaid_amd.NamedMatrix(sp.csc_matrix(X) if sparse else X, rn, [f"s{k}" for k in range(n)])
+    Gn = plaid_amd.NamedMatrix(sp.csc_matrix(Gd), grn, [f"set{k}" for k in range(m)])
+    return Xn, Gn, (sp.csc_matrix(X) if sparse else X), rn, sp.csc_matrix(Gd), grn
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_replaid_ucell_aucell_scse(hip_ctx, sparse):
+    """the thin callers of SURVEY.md 8f-1 (R/plaid.R:155-190, 276-309) against the oracle"""
+    import plaid_amd
+    po = _oracle()
+    Xn, Gn, X, rn, G, grn = _small_named(sparse)
+    close(plaid_amd.replaid_ucell(Xn, Gn, rmax=200).values, po.replaid_ucell(X, rn, G, grn, rmax=200))
+    close(plaid_amd.replaid_aucell(Xn, Gn).values, po.replaid_aucell(X, rn, G, grn))
+    close(plaid_amd.replaid_aucell(Xn, Gn, aucMaxRank=120).values, po.replaid_aucell(X, rn, G, grn, auc_max_rank=120))
+    for rl in (None, True, False):
+        for sm in (False, True):
+            close(plaid_amd.replaid_scse(Xn, Gn, removeLog2=rl, scoreMean=sm).values,
+                  po.replaid_scse(X, rn, G, grn, remove_log2=rl, score_mean=sm))
