@@ -41,9 +41,14 @@ __device__ __forceinline__ int resolve_ignore_zero(int ignore_zero, const uint32
   return (flags[1] != 0u && flags[0] == 0u) ? 1 : 0;
 }
 
+// order-preserving key of v, or the all-ones key when v is masked (NaN: na.rm = TRUE; exact zero
+// when ignore_zero).  Branch-free on purpose: with control flow hipcc waits for every load
+// before issuing the next one and the column sweeps serialise on L2 latency.
 __device__ __forceinline__ uint64_t masked_key(double v, int ignore_zero) {
-  if (ignore_zero && v == 0.0) return ~0ull;
-  return f64_to_key(v);  // NaN -> ~0 as well (na.rm = TRUE)
+  const uint64_t u = (uint64_t)__double_as_longlong(v + 0.0);          // -0 -> +0
+  const uint64_t key = u ^ ((u >> 63) ? ~0ull : 0x8000000000000000ull);
+  const bool masked = (v != v) | ((ignore_zero != 0) & (v == 0.0));
+  return masked ? ~0ull : key;
 }
 
 // m <= kMaxLdsGenes: the column is sorted in LDS.
