@@ -103,6 +103,7 @@ col_medians_bits_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
                         double* __restrict__ med) {
   constexpr int NW = BLOCK / 64;
   __shared__ uint32_t s_cnt[2][NW];
+  __shared__ uint32_t s_mm[2][2][NW];
   __shared__ unsigned long long s_min[NW];
   const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,10 +124,32 @@ col_medians_bits_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
     parity ^= 1;
     return tot;
   };
-  // value of rank k (0-based) among the words: largest v with count(word < v) <= k
-  auto select_word = [&](uint32_t k) -> uint32_t {
-    uint32_t v = 0;
-    for (int bit = 31; bit >= 0; --bit) {
+  // block-wide {min, max} of per-thread values (same alternating-buffer discipline)
+  auto block_minmax = [&](uint32_t mn, uint32_t mx, uint32_t& omn, uint32_t& omx) {
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t a = __shfl_xor(mn, off, 64), b2 = __shfl_xor(mx, off, 64);
+      mn = a < mn ? a : mn;
+      mx = b2 > mx ? b2 : mx;
+    }
+    if (lane == 0) { s_mm[parity][0][wave] = mn; s_mm[parity][1][wave] = mx; }
+    __syncthreads();
+    omn = 0xffffffffu; omx = 0u;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      omn = s_mm[parity][0][k] < omn ? s_mm[parity][0][k] : omn;
+      omx = s_mm[parity][1][k] > omx ? s_mm[parity][1][k] : omx;
+    }
+    parity ^= 1;
+  };
+  // value of rank k (0-based) among the words, all of which lie in [mn, mx] (inactive words are
+  // 0xffffffff): the bits above the highest bit in which mn and mx differ are common to every
+  // candidate, so the binary search on the value starts below them -- and is skipped entirely when
+  // mn == mx (one key, or all ties).
+  auto select_word = [&](uint32_t k, uint32_t mn, uint32_t mx) -> uint32_t {
+    if (mn == mx) return mn;
+    const int top = 31 - __clz((int)(mn ^ mx));
+    uint32_t v = (top == 31) ? 0u : (mn & ~((2u << top) - 1u));
+    for (int bit = top; bit >= 0; --bit) {
       const uint32_t cand = v | (1u << bit);
       if (count_below(cand, false) <= k) v = cand;
     }
@@ -135,55 +158,76 @@ col_medians_bits_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
 
   for (int c = blockIdx.x; c < n; c += gridDim.x) {
     const double* sc = S + (int64_t)c * lds;
-    // ---- phase 1: high words -------------------------------------------------------
+    // ---- the column is read ONCE: 64-bit keys stay in registers (ITEMS <= 32), the 32-bit
+    //      working words w[] are re-derived from them per phase ---------------------------
+    constexpr bool KEEP = ITEMS <= 32;
+    uint32_t khi[KEEP ? ITEMS : 1], klo[KEEP ? ITEMS : 1];
+    uint32_t tmn = 0xffffffffu, tmx = 0u;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const int i = tid + j * BLOCK;
-      const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
+      const uint64_t key = (i < m) ? masked_key(sc[i < m ? i : m - 1], ignore_zero) : ~0ull;
       w[j] = (uint32_t)(key >> 32);
+      if constexpr (KEEP) { khi[j] = w[j]; klo[j] = (uint32_t)key; }
+      const bool valid = key != ~0ull;
+      tmn = (valid && w[j] < tmn) ? w[j] : tmn;
+      tmx = (valid && w[j] > tmx) ? w[j] : tmx;
       if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");   // bound the live 64-bit temporaries
     }
+    uint32_t hmn, hmx;
+    block_minmax(tmn, tmx, hmn, hmx);
     const uint32_t cnt = count_below(0xffffffffu, false);   // valid keys never have an all-ones high word
     double r;
     if (cnt == 0) {
       r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
     } else {
       const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
-      const uint32_t H = select_word(k_lo);
+      const uint32_t H = select_word(k_lo, hmn, hmx);
       const uint32_t below_H = count_below(H, false);
       // ---- phase 2: low words of the keys whose high word is H --------------------
+      tmn = 0xffffffffu; tmx = 0u;
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
-        const int i = tid + j * BLOCK;
-        const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
-        w[j] = ((uint32_t)(key >> 32) == H) ? (uint32_t)key : 0xffffffffu;
-        if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");
+        uint32_t hw, lw;
+        if constexpr (KEEP) { hw = khi[j]; lw = klo[j]; }
+        else {
+          const int i = tid + j * BLOCK;
+          const uint64_t key = (i < m) ? masked_key(sc[i < m ? i : m - 1], ignore_zero) : ~0ull;
+          hw = (uint32_t)(key >> 32); lw = (uint32_t)key;
+          if ((j & 15) == 15) asm volatile("" ::: "memory");
+        }
+        const bool act = (hw == H) && !(hw == 0xffffffffu && lw == 0xffffffffu);
+        w[j] = act ? lw : 0xffffffffu;
+        tmn = (act && lw < tmn) ? lw : tmn;
+        tmx = (act && lw > tmx) ? lw : tmx;
       }
-      const uint32_t L = select_word(k_lo - below_H);
+      uint32_t lmn, lmx;
+      block_minmax(tmn, tmx, lmn, lmx);
+      const uint32_t L = select_word(k_lo - below_H, lmn, lmx);
       const uint64_t V = ((uint64_t)H << 32) | L;
       uint64_t V2 = V;
       if (k_hi != k_lo) {
         // keys <= V: below_H + (same high word, low word <= L).  A key with another high word
         // carries 0xffffffff here and is only (wrongly) counted when L is 0xffffffff itself;
-        // then every key of the H group is <= V and the group size is the exact count.
-        uint32_t le_V;
-        if (L != 0xffffffffu) {
-          le_V = below_H + count_below(L, true);
-        } else {
-          le_V = 0;   // resolved by the sweep below (count keys <= V exactly)
-        }
-        bool need_sweep = (L == 0xffffffffu) || (le_V <= k_hi);
+        // then the sweep below counts exactly.
+        uint32_t le_V = 0;
+        if (L != 0xffffffffu) le_V = below_H + count_below(L, true);
+        const bool need_sweep = (L == 0xffffffffu) || (le_V <= k_hi);
         if (need_sweep) {
           // ---- phase 3: smallest key above V (and the exact count of keys <= V) ----
           uint64_t mn = ~0ull;
           uint32_t le = 0;
 #pragma unroll
           for (int j = 0; j < ITEMS; ++j) {
-            const int i = tid + j * BLOCK;
-            const uint64_t key = (i < m) ? masked_key(sc[i], ignore_zero) : ~0ull;
+            uint64_t key;
+            if constexpr (KEEP) key = ((uint64_t)khi[j] << 32) | klo[j];
+            else {
+              const int i = tid + j * BLOCK;
+              key = (i < m) ? masked_key(sc[i < m ? i : m - 1], ignore_zero) : ~0ull;
+              if ((j & 15) == 15) asm volatile("" ::: "memory");
+            }
             le += (uint32_t)__popcll(__ballot(key <= V));
-            if (key > V && key < mn) mn = key;
-            if (ITEMS > 32 && (j & 15) == 15) asm volatile("" ::: "memory");
+            mn = (key > V && key < mn) ? key : mn;
           }
           for (int off = 32; off >= 1; off >>= 1) {
             const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mn, off, 64);
