@@ -28,16 +28,16 @@ using namespace plaidhip;
 namespace {
 
 struct Edge {
-  uint8_t u, v;      // lane (0..31), slot (0..31)
+  uint8_t u, v;      // lane (0..31), slot vertex (0..31, or 0..63 with two read ports per slot)
   uint16_t gene;
   int32_t color;
 };
 
 // Proper edge colouring of a bipartite multigraph with D = max degree colours
 // (alternating-path / Koenig construction).  32 + 32 vertices.
-void color_bipartite(std::vector<Edge>& E, int D) {
+void color_bipartite(std::vector<Edge>& E, int D, int nV = 32) {
   if (E.empty()) return;
-  std::vector<int32_t> atU((size_t)32 * D, -1), atV((size_t)32 * D, -1);
+  std::vector<int32_t> atU((size_t)32 * D, -1), atV((size_t)nV * D, -1);
   std::vector<int32_t> path;
   auto first_free = [&](const std::vector<int32_t>& at, int x) {
     const int32_t* row = &at[(size_t)x * D];
@@ -94,23 +94,30 @@ struct TilePlan {
 
 // Schedule one tile (64 lanes; lane l handles set lane_set[l] or nothing).
 void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* lane_set, TilePlan& tp) {
+  // PLAIDHIP_SLOT_PORTS=2 (tuning knob): let every bank pair serve TWO lanes per step (a 2-way
+  // bank conflict, +1 LDS cycle) -- fewer, fuller steps when instruction issue, not the LDS
+  // pipe, is the limit.  Each slot then has two vertices; its reads alternate between them.
+  static const int ports = (getenv("PLAIDHIP_SLOT_PORTS") && atoi(getenv("PLAIDHIP_SLOT_PORTS")) == 2) ? 2 : 1;
   std::vector<Edge> half[2];
   int D[2] = {0, 0};
   for (int h = 0; h < 2; ++h) {
-    int degU[32] = {0}, degV[32] = {0};
+    int degU[32] = {0}, degV[64] = {0}, seen[32] = {0};
     for (int l = 0; l < 32; ++l) {
       const int32_t j = lane_set[h * 32 + l];
       if (j < 0) continue;
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
         const int32_t gene = Gi[p];
-        Edge e{(uint8_t)l, (uint8_t)(gene & 31), (uint16_t)gene, -1};
+        const int slot = gene & 31;
+        const int vtx = slot + 32 * ((seen[slot]++) % ports);
+        Edge e{(uint8_t)l, (uint8_t)vtx, (uint16_t)gene, -1};
         half[h].push_back(e);
         ++degU[l];
-        ++degV[gene & 31];
+        ++degV[vtx];
       }
     }
-    for (int k = 0; k < 32; ++k) D[h] = std::max(D[h], std::max(degU[k], degV[k]));
-    color_bipartite(half[h], D[h]);
+    for (int k = 0; k < 32; ++k) D[h] = std::max(D[h], degU[k]);
+    for (int k = 0; k < 64; ++k) D[h] = std::max(D[h], degV[k]);
+    color_bipartite(half[h], D[h], 64);
   }
   tp.steps = std::max(8, (std::max(D[0], D[1]) + 7) & ~7);   // >= 1 chunk: empty sets still get their 0 written
   tp.idx.assign((size_t)tp.steps * 64, 0);
@@ -121,7 +128,7 @@ void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* l
       const size_t s = (size_t)e.color;
       tp.idx[s * 64 + h * 32 + e.u] = e.gene;
       filled[s * 64 + h * 32 + e.u] = 1;
-      used[s * 64 + h * 32 + e.v] = 1;
+      used[s * 64 + h * 32 + (e.v & 31)] += 1;
     }
   // idle (lane, step) pairs read a zero entry behind the column (index g + r, r < 32) whose
   // bank-slot ((g + r) mod 32) nobody else uses in this step: #free slots == #idle lanes.
@@ -130,7 +137,8 @@ void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* l
       int slot = 0;
       for (int l = 0; l < 32; ++l) {
         if (filled[(size_t)s * 64 + h * 32 + l]) continue;
-        while (used[(size_t)s * 64 + h * 32 + slot]) ++slot;
+        while (slot < 32 && used[(size_t)s * 64 + h * 32 + slot]) ++slot;
+        if (slot >= 32) slot = l;          // two-port schedules can fill every slot: share one (zero entries, harmless)
         const int r = ((slot - g) % 32 + 32) % 32;
         tp.idx[(size_t)s * 64 + h * 32 + l] = (uint16_t)(g + r);
         ++slot;
