@@ -83,6 +83,17 @@ int h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return PLAIDHIP_OK;
 }
 
+// Dense host matrix (g x n, column-major) -> device with an EVEN leading dimension, so that both
+// columns of a pair start 16-byte aligned (the two-columns-per-pass SpMM kernel needs that).
+inline int64_t even_ld(int32_t g) { return (int64_t)g + (g & 1); }
+int h2d_cols(plaidhip_ctx* ctx, void* dst, int64_t ldd, const double* src, int32_t g, int32_t n) {
+  if ((int64_t)g * n == 0) return PLAIDHIP_OK;
+  if (ldd == g) return h2d(ctx, dst, src, (size_t)g * n * 8);
+  PH_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)g * 8, (size_t)g * 8, (size_t)n, hipMemcpyHostToDevice,
+                          ctx->stream));
+  return PLAIDHIP_OK;
+}
+
 // normalize_medians on a device-resident S (R/plaid.R:554-575), fully enqueued: ignore.zero is
 // resolved on the device from the flag words, mean(medx) from the {sum, count} pair.
 int normalize_on_device(plaidhip_ctx* ctx, double* dS, int32_t m, int32_t n, int ignore_zero,
@@ -324,15 +335,16 @@ int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t 
   GenesetHolder gh;
   PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dS, dsmall;
-  PH_TRY(dX.alloc((size_t)g * n * 8));
+  const int64_t ldg = even_ld(g);
+  PH_TRY(dX.alloc((size_t)ldg * n * 8));
   PH_TRY(dS.alloc((size_t)m * n * 8));
   PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
   uint32_t* d_flags = dsmall.as<uint32_t>();
   double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
   double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
-  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), g, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), ldg, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
   if (normalize)
     PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -463,13 +475,14 @@ int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   GenesetHolder gh;
   PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dR, dS;
-  PH_TRY(dX.alloc((size_t)g * n * 8));
-  PH_TRY(dR.alloc((size_t)g * n * 8));
+  const int64_t ldg = even_ld(g);
+  PH_TRY(dX.alloc((size_t)ldg * n * 8));
+  PH_TRY(dR.alloc((size_t)ldg * n * 8));
   PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
-  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), g, g, n, PLAIDHIP_TIES_MIN, 0, 1.0, dR.as<double>(), g, nullptr));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), g, n, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_MIN, 0, 1.0, dR.as<double>(), ldg, nullptr));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,
                                dS.as<double>(), m, nullptr));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
@@ -486,22 +499,23 @@ int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t
   GenesetHolder gh;
   PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dR, dS, dsmall;
-  PH_TRY(dX.alloc((size_t)g * n * 8));
-  PH_TRY(dR.alloc((size_t)g * n * 8));
+  const int64_t ldg = even_ld(g);
+  PH_TRY(dX.alloc((size_t)ldg * n * 8));
+  PH_TRY(dR.alloc((size_t)ldg * n * 8));
   PH_TRY(dS.alloc((size_t)m * n * 8));
   PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
   uint32_t* d_flags = dsmall.as<uint32_t>();
   double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
   double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
   double* d_colmax = d_med + n;
-  PH_TRY(h2d(ctx, dX.p, X, (size_t)g * n * 8));
+  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   // rX = colranks(X, ties="average")^(1+alpha) ; rX/max(rX) - 0.5 ; plaid(mean, normalize=TRUE)  (R/plaid.R:245-253)
-  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), g, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha,
-                                   dR.as<double>(), g, d_colmax));
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha,
+                                   dR.as<double>(), ldg, d_colmax));
   double* d_gmax = d_red + 2;   // max(rX), stays on the device
   PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), g, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5,
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5,
                                dS.as<double>(), m, d_flags));
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));

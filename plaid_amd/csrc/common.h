@@ -19,6 +19,10 @@ constexpr int kPadSlots = 32;
 constexpr int kMaxLdsGenes = kLdsBytes / 8 - kPadSlots;  // 20448
 // bitonic sort in LDS: 8-byte keys
 constexpr int kMaxLdsKeys = kLdsBytes / 8;               // 20480
+// pair kernel: 16-byte entries (two sample columns), 16 zero entries behind them
+constexpr int kPadSlotsPair = 16;
+constexpr int kMaxLdsGenesPair = kLdsBytes / 16 - kPadSlotsPair;   // 10224
+constexpr int kMaxPairSlices = 8;
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -73,6 +77,36 @@ struct plaidhip_slice {
   double* d_meta_k = nullptr;
 };
 
+// pair plan: gene slices of <= kMaxLdsGenesPair genes; tiles, tile->wave assignment and the
+// per-lane metadata are shared by all slices (see geneset.cpp)
+struct plaidhip_pair_slice {
+  int32_t g0 = 0, gs = 0;
+  uint16_t* d_tile_idx = nullptr;
+  int32_t* d_wave_chunk_off = nullptr;
+  int32_t* d_wtile_end = nullptr;
+};
+// what the kernel reads per slice (device array, scalar loads)
+struct plaidhip_pair_slice_dev {
+  const uint16_t* tile_idx;
+  const int32_t* wave_chunk_off;
+  const int32_t* wtile_end;
+  int32_t g0, gs;
+};
+struct plaidhip_pair_plan {
+  int32_t waves = 0;
+  int32_t ktiles = 0;                          // wave-stream tiles (all waves)
+  int64_t chunks = 0;
+  std::vector<plaidhip_pair_slice> slices;
+  plaidhip_pair_slice_dev* d_slices = nullptr;
+  // partial sums between gene slices: [workgroup][wave-stream tile + 1][lane] x {A, B}
+  double* d_partial = nullptr;
+  int32_t partial_wgs = 0;
+  int32_t* d_wave_tile_off = nullptr;
+  int32_t* d_meta_j = nullptr;
+  double* d_meta_w = nullptr;
+  double* d_meta_k = nullptr;
+};
+
 struct plaidhip_geneset {
   plaidhip_ctx* ctx = nullptr;
   int32_t g = 0, m = 0;
@@ -80,6 +114,7 @@ struct plaidhip_geneset {
   int32_t tiles = 0;
   int64_t chunks = 0;          // total over slices
   std::vector<plaidhip_slice> slices;   // the column is consumed slice by slice when g > kMaxLdsGenes
+  plaidhip_pair_plan pair;              // dense-X kernel: two columns per pass
 };
 
 namespace plaidhip {

@@ -25,6 +25,9 @@
 
 using namespace plaidhip;
 
+// measured on MI355X (tools/bench_spmm.py --ablate 4), see wave_weights()
+static const double kAgeShare16[4] = {1.3, 1.1, 0.9, 0.7};
+
 namespace {
 
 struct Edge {
@@ -159,6 +162,47 @@ struct HostPlan {
   int64_t chunks = 0;
 };
 
+
+// Share of the work a wavefront gets, by its age rank on its SIMD (wave w of a workgroup runs on
+// SIMD w % 4; w / 4 is its age there).  The SIMD arbiter serves the oldest ready wave first, so with
+// equal shares the older waves finish early and the youngest one ends up alone on the SIMD, which a
+// single wave cannot keep busy.  Shares proportional to the speed each age actually gets let all
+// waves reach the end-of-column barrier together.  PLAIDHIP_WAVE_WEIGHTS="a,b,c,d" overrides.
+void wave_weights(int waves, std::vector<double>& wt) {
+  double age[4] = {1.0, 1.0, 1.0, 1.0};
+  if (waves == 16) { age[0] = kAgeShare16[0]; age[1] = kAgeShare16[1]; age[2] = kAgeShare16[2]; age[3] = kAgeShare16[3]; }
+  if (const char* e = getenv("PLAIDHIP_WAVE_WEIGHTS")) {
+    double a, b, c, d;
+    if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4 && a > 0 && b > 0 && c > 0 && d > 0) {
+      age[0] = a; age[1] = b; age[2] = c; age[3] = d;
+    }
+  }
+  wt.resize(waves);
+  for (int w = 0; w < waves; ++w) wt[w] = age[std::min(3, w / 4)];
+}
+
+// longest-processing-time assignment of tiles (cost[t]) to wavefronts with capacity weights
+void assign_tiles(const std::vector<int64_t>& cost, int waves, std::vector<std::vector<int32_t>>& mine) {
+  const int32_t tiles = (int32_t)cost.size();
+  std::vector<double> wt;
+  wave_weights(waves, wt);
+  std::vector<int32_t> by_len(tiles);
+  std::iota(by_len.begin(), by_len.end(), 0);
+  std::stable_sort(by_len.begin(), by_len.end(), [&](int32_t a, int32_t b) { return cost[a] > cost[b]; });
+  mine.assign(waves, {});
+  std::vector<double> load(waves, 0.0);
+  for (int32_t t : by_len) {
+    int best = 0;
+    double bv = 1e300;
+    for (int w = 0; w < waves; ++w) {
+      const double v = (load[w] + (double)cost[t]) / wt[w];
+      if (v < bv) { bv = v; best = w; }
+    }
+    mine[best].push_back(t);
+    load[best] += (double)cost[t];
+  }
+}
+
 void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, const int32_t* total_size,
                 int waves, HostPlan& hp) {
   std::vector<int32_t> order(m);
@@ -185,16 +229,11 @@ void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, cons
   }
 
   // longest-processing-time assignment of tiles to wavefronts
-  std::vector<int32_t> by_len(tiles);
-  std::iota(by_len.begin(), by_len.end(), 0);
-  std::stable_sort(by_len.begin(), by_len.end(),
-                   [&](int32_t a, int32_t b) { return plans[a].steps > plans[b].steps; });
-  std::vector<std::vector<int32_t>> mine(waves);
-  std::vector<int64_t> load(waves, 0);
-  for (int32_t t : by_len) {
-    const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    mine[w].push_back(t);
-    load[w] += plans[t].steps;
+  std::vector<std::vector<int32_t>> mine;
+  {
+    std::vector<int64_t> cost(tiles);
+    for (int32_t t = 0; t < tiles; ++t) cost[t] = plans[t].steps;
+    assign_tiles(cost, waves, mine);
   }
   hp.wave_chunk_off.assign(waves + 1, 0);
   hp.wave_tile_off.assign(waves + 1, 0);
@@ -240,6 +279,168 @@ void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, cons
       hp.meta_w[k * 64 + l] = 1.0 / (1e-8 + size);   // R/plaid.R:75-76
       hp.meta_k[k * 64 + l] = size;
     }
+}
+
+// ---- pair plan: two sample columns per 16-byte LDS entry (ds_read_b128) -------------------
+// ds_read_b128 serves a wave in four groups of 16 lanes (MI355X LDS table); a group is conflict
+// free when its 16 lanes read 16 different 16-byte slots, slot = gene mod 16.
+static const uint8_t kB128Groups[4][16] = {
+    {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+
+// Schedule the genes of one tile that fall into [g0, g0+gs): edge-colour every 16-lane group
+// against the 16 slots.  Idle (lane, step) pairs read a zero entry gs + r (r < 16) on a free slot.
+void plan_tile_b128(int32_t g0, int32_t gs, const int32_t* Gp, const int32_t* Gi, const int32_t* lane_set,
+                    TilePlan& tp) {
+  std::vector<Edge> grp[4];
+  int D[4] = {0, 0, 0, 0};
+  for (int q = 0; q < 4; ++q) {
+    int degU[16] = {0}, degV[16] = {0};
+    for (int l = 0; l < 16; ++l) {
+      const int32_t j = lane_set[kB128Groups[q][l]];
+      if (j < 0) continue;
+      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
+        const int32_t gene = Gi[p] - g0;
+        if (gene < 0 || gene >= gs) continue;
+        Edge e{(uint8_t)l, (uint8_t)(gene & 15), (uint16_t)gene, -1};
+        grp[q].push_back(e);
+        ++degU[l];
+        ++degV[gene & 15];
+      }
+    }
+    for (int k = 0; k < 16; ++k) D[q] = std::max(D[q], std::max(degU[k], degV[k]));
+    color_bipartite(grp[q], D[q], 16);
+  }
+  const int dmax = std::max(std::max(D[0], D[1]), std::max(D[2], D[3]));
+  tp.steps = std::max(8, (dmax + 7) & ~7);
+  tp.idx.assign((size_t)tp.steps * 64, 0);
+  std::vector<uint8_t> used((size_t)tp.steps * 64, 0), filled((size_t)tp.steps * 64, 0);
+  for (int q = 0; q < 4; ++q)
+    for (const Edge& e : grp[q]) {
+      const size_t st = (size_t)e.color;
+      tp.idx[st * 64 + kB128Groups[q][e.u]] = e.gene;
+      filled[st * 64 + kB128Groups[q][e.u]] = 1;
+      used[st * 64 + q * 16 + e.v] = 1;
+    }
+  for (int32_t st = 0; st < tp.steps; ++st)
+    for (int q = 0; q < 4; ++q) {
+      int slot = 0;
+      for (int l = 0; l < 16; ++l) {
+        const int lane = kB128Groups[q][l];
+        if (filled[(size_t)st * 64 + lane]) continue;
+        while (used[(size_t)st * 64 + q * 16 + slot]) ++slot;
+        const int r = ((slot - gs) % 16 + 16) % 16;
+        tp.idx[(size_t)st * 64 + lane] = (uint16_t)(gs + r);
+        ++slot;
+      }
+    }
+}
+
+struct PairSliceHost {
+  int32_t g0 = 0, gs = 0;
+  std::vector<uint16_t> idx;             // [chunk][lane][8]
+  std::vector<int32_t> wave_chunk_off;   // waves + 1
+  std::vector<int32_t> wtile_end;        // per wave-stream tile k (+ sentinel)
+};
+struct PairPlanHost {
+  std::vector<PairSliceHost> slices;
+  std::vector<int32_t> wave_tile_off;    // waves + 1, shared by all slices
+  std::vector<int32_t> meta_j;           // [k][lane], shared
+  std::vector<double> meta_w, meta_k;
+  int64_t chunks = 0;
+};
+
+// Tiles (lane <-> set) and the tile -> wavefront assignment are the SAME in every gene slice, so a
+// lane meets the same set again in the next slice and its partial sum can round-trip through S
+// privately (no cross-wave hand-off).
+void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, int waves, PairPlanHost& pp) {
+  std::vector<int32_t> order(m);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return (Gp[a + 1] - Gp[a]) > (Gp[b + 1] - Gp[b]); });
+  const int32_t tiles = (m + 63) / 64;
+  std::vector<int32_t> lane_set((size_t)tiles * 64, -1);
+  for (int32_t s = 0; s < m; ++s) lane_set[s] = order[s];
+  const int32_t nsl = (g + kMaxLdsGenesPair - 1) / kMaxLdsGenesPair;
+  int32_t width = (g + nsl - 1) / nsl;
+  width = (width + 1) & ~1;
+  std::vector<int32_t> starts;
+  for (int32_t g0 = 0; g0 < g; g0 += width) starts.push_back(g0);
+  const int S = (int)starts.size();
+  std::vector<std::vector<TilePlan>> plans(S, std::vector<TilePlan>(tiles));
+  {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 16u));
+    if ((int64_t)tiles * S < 8) nt = 1;
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nt; ++w)
+      pool.emplace_back([&, w]() {
+        for (int64_t u = (int64_t)w; u < (int64_t)tiles * S; u += nt) {
+          const int si = (int)(u / tiles);
+          const int32_t t = (int32_t)(u % tiles);
+          plan_tile_b128(starts[si], std::min(width, g - starts[si]), Gp, Gi, &lane_set[(size_t)t * 64], plans[si][t]);
+        }
+      });
+    for (auto& th : pool) th.join();
+  }
+  // longest-processing-time on the steps summed over slices
+  std::vector<int64_t> tot(tiles, 0);
+  for (int si = 0; si < S; ++si)
+    for (int32_t t = 0; t < tiles; ++t) tot[t] += plans[si][t].steps;
+  std::vector<std::vector<int32_t>> mine;
+  assign_tiles(tot, waves, mine);
+  pp.wave_tile_off.assign(waves + 1, 0);
+  std::vector<int32_t> ktile;   // wave-stream order -> tile
+  for (int w = 0; w < waves; ++w) {
+    pp.wave_tile_off[w] = (int32_t)ktile.size();
+    for (int32_t t : mine[w]) ktile.push_back(t);
+  }
+  pp.wave_tile_off[waves] = (int32_t)ktile.size();
+  const size_t nk = ktile.size() + 1;   // + sentinel
+  pp.meta_j.assign(nk * 64, -1);
+  pp.meta_w.assign(nk * 64, 0.0);
+  pp.meta_k.assign(nk * 64, 0.0);
+  for (size_t k = 0; k + 1 < nk; ++k)
+    for (int l = 0; l < 64; ++l) {
+      const int32_t j = lane_set[(size_t)ktile[k] * 64 + l];
+      if (j < 0) continue;
+      const double size = (double)(Gp[j + 1] - Gp[j]);
+      pp.meta_j[k * 64 + l] = j;
+      pp.meta_w[k * 64 + l] = 1.0 / (1e-8 + size);   // R/plaid.R:75-76
+      pp.meta_k[k * 64 + l] = size;
+    }
+  pp.slices.resize(S);
+  pp.chunks = 0;
+  for (int si = 0; si < S; ++si) {
+    PairSliceHost& ps = pp.slices[si];
+    ps.g0 = starts[si];
+    ps.gs = std::min(width, g - starts[si]);
+    ps.wave_chunk_off.assign(waves + 1, 0);
+    int32_t chunk = 0;
+    for (int w = 0; w < waves; ++w) {
+      ps.wave_chunk_off[w] = chunk;
+      for (int32_t t : mine[w]) {
+        chunk += plans[si][t].steps / 8;
+        ps.wtile_end.push_back(chunk);
+      }
+    }
+    ps.wave_chunk_off[waves] = chunk;
+    ps.wtile_end.push_back(-1);
+    pp.chunks += chunk;
+    ps.idx.assign(((size_t)chunk + 12) * 64 * 8, (uint16_t)ps.gs);
+    int32_t c = 0;
+    for (int w = 0; w < waves; ++w)
+      for (int32_t t : mine[w]) {
+        const TilePlan& tp = plans[si][t];
+        for (int32_t st = 0; st < tp.steps; ++st) {
+          const int32_t ch = c + st / 8, e = st & 7;
+          for (int l = 0; l < 64; ++l) ps.idx[(((size_t)ch * 64) + l) * 8 + e] = tp.idx[(size_t)st * 64 + l];
+        }
+        c += tp.steps / 8;
+      }
+  }
 }
 
 template <typename T>
@@ -327,6 +528,42 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
       if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
     }
   }
+  if (m > 0) {
+    // pair plan (two sample columns per LDS entry) for the dense-X kernel
+    PairPlanHost pp;
+    std::vector<plaidhip_pair_slice_dev> hd;
+    gs->pair.waves = 16;
+    build_pair_plan(g, m, Gp, Gi, gs->pair.waves, pp);
+    gs->pair.chunks = pp.chunks;
+    if ((rc = upload(ctx, pp.wave_tile_off, &gs->pair.d_wave_tile_off)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, pp.meta_j, &gs->pair.d_meta_j)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, pp.meta_w, &gs->pair.d_meta_w)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, pp.meta_k, &gs->pair.d_meta_k)) != PLAIDHIP_OK) goto fail;
+    for (PairSliceHost& ps : pp.slices) {
+      plaidhip_pair_slice d;
+      d.g0 = ps.g0;
+      d.gs = ps.gs;
+      gs->pair.slices.push_back(d);
+      plaidhip_pair_slice& dd = gs->pair.slices.back();
+      if ((rc = upload(ctx, ps.idx, &dd.d_tile_idx)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, ps.wave_chunk_off, &dd.d_wave_chunk_off)) != PLAIDHIP_OK) goto fail;
+      if ((rc = upload(ctx, ps.wtile_end, &dd.d_wtile_end)) != PLAIDHIP_OK) goto fail;
+    }
+    for (const plaidhip_pair_slice& d : gs->pair.slices)
+      hd.push_back(plaidhip_pair_slice_dev{d.d_tile_idx, d.d_wave_chunk_off, d.d_wtile_end, d.g0, d.gs});
+    if ((rc = upload(ctx, hd, &gs->pair.d_slices)) != PLAIDHIP_OK) goto fail;
+    gs->pair.ktiles = pp.wave_tile_off[gs->pair.waves];
+    if (gs->pair.slices.size() > 1) {
+      gs->pair.partial_wgs = ctx->num_cu;
+      const size_t bytes = (size_t)gs->pair.partial_wgs * (gs->pair.ktiles + 1) * 64 * 2 * sizeof(double);
+      if (hipMalloc(reinterpret_cast<void**>(&gs->pair.d_partial), bytes) != hipSuccess) {
+        set_error("hipMalloc(%zu) for the slice partial sums failed", bytes);
+        rc = PLAIDHIP_ENOMEM;
+        goto fail;
+      }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
+  }
   *out = gs;
   return PLAIDHIP_OK;
 fail:
@@ -345,6 +582,17 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
     hipFree(d.d_meta_w);
     hipFree(d.d_meta_k);
   }
+  hipFree(gs->pair.d_wave_tile_off);
+  hipFree(gs->pair.d_meta_j);
+  hipFree(gs->pair.d_meta_w);
+  hipFree(gs->pair.d_meta_k);
+  hipFree(gs->pair.d_slices);
+  hipFree(gs->pair.d_partial);
+  for (plaidhip_pair_slice& d : gs->pair.slices) {
+    hipFree(d.d_tile_idx);
+    hipFree(d.d_wave_chunk_off);
+    hipFree(d.d_wtile_end);
+  }
   delete gs;
   return PLAIDHIP_OK;
 }
@@ -359,5 +607,52 @@ extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]
   info[4] = gs->tiles;
   info[5] = (int64_t)gs->slices.size();   // gene slices (1 when the whole column fits the LDS)
   info[6] = gs->slices.empty() ? 0 : gs->slices[0].waves;
+  info[7] = gs->pair.chunks * 64 * 8;     // padded index slots of the pair plan (dense-X kernel)
+  return PLAIDHIP_OK;
+}
+
+// Diagnostic / test hook (not part of include/plaidhip.h): builds the pair plan on the host only
+// and checks it.  out[0]=slices out[1]=chunks (all slices) out[2]=memberships found in the plan
+// out[3]=conflicts (two lanes of one ds_read_b128 lane group on the same 16-byte slot in one
+// step) out[4]=memberships scheduled for the wrong set / twice / out of slice.
+extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
+                                              int32_t waves, int64_t out[8]) {
+  PairPlanHost pp;
+  build_pair_plan(g, m, Gp, Gi, waves, pp);
+  int64_t found = 0, conflicts = 0, wrong = 0;
+  std::vector<uint8_t> seen((size_t)Gp[m], 0);
+  for (const PairSliceHost& ps : pp.slices) {
+    for (int w = 0; w < waves; ++w) {
+      int32_t k = pp.wave_tile_off[w];
+      for (int32_t ch = ps.wave_chunk_off[w]; ch < ps.wave_chunk_off[w + 1]; ++ch) {
+        for (int e = 0; e < 8; ++e) {
+          for (int q = 0; q < 4; ++q) {
+            uint32_t slots = 0;
+            for (int l = 0; l < 16; ++l) {
+              const int lane = kB128Groups[q][l];
+              const int32_t id = ps.idx[(((size_t)ch * 64) + lane) * 8 + e];
+              if (id >= ps.gs + kPadSlotsPair) { ++wrong; continue; }
+              if (slots & (1u << (id & 15))) ++conflicts;
+              slots |= 1u << (id & 15);
+              if (id >= ps.gs) continue;
+              const int32_t j = pp.meta_j[(size_t)k * 64 + lane];
+              if (j < 0) { ++wrong; continue; }
+              const int32_t* lo = std::lower_bound(Gi + Gp[j], Gi + Gp[j + 1], ps.g0 + id);
+              if (lo == Gi + Gp[j + 1] || *lo != ps.g0 + id || seen[lo - Gi]) { ++wrong; continue; }
+              seen[lo - Gi] = 1;
+              ++found;
+            }
+          }
+        }
+        if (ch + 1 == ps.wtile_end[k]) ++k;
+      }
+      if (k != pp.wave_tile_off[w + 1]) ++wrong;
+    }
+  }
+  out[0] = (int64_t)pp.slices.size();
+  out[1] = pp.chunks;
+  out[2] = found;
+  out[3] = conflicts;
+  out[4] = wrong;
   return PLAIDHIP_OK;
 }

@@ -23,6 +23,9 @@
 // slot) come from L2 once per column.
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace plaidhip {
 
 struct SpmmArgs {
@@ -337,8 +340,355 @@ spmm_colgather_f64(SpmmArgs a) {
 #undef PLAIDHIP_ST_ONE
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pair kernel (dense X): TWO sample columns per pass.  An LDS entry is 16 bytes {A_i, B_i}, so one
+// address op + one ds_read_b128 serve two scores and the index stream is read once per pair.  Only
+// half the genes fit (<= 10,224 per slice): a workgroup walks the gene slices of its pair inside
+// one launch; partial sums rest in a private [workgroup][tile][lane] scratch (L2-resident) between
+// slices, the epilogue runs in the last slice.  The host schedule (geneset.cpp, plan_tile_b128)
+// is conflict-free for the four 16-lane groups a ds_read_b128 is served in.
+struct SpmmPairArgs {
+  const double* X;
+  int64_t ldx;
+  int32_t n, npairs, nslices, ktiles;
+  const plaidhip_pair_slice_dev* slices;
+  const int32_t* wave_tile_off;
+  const int32_t* meta_j;
+  const double* meta_w;
+  const double* meta_k;
+  f64x2* partial;
+  int32_t stat;
+  double alpha, beta;
+  const double* alpha_div;
+  double* S;
+  int64_t lds;
+  uint32_t* flags;
+  unsigned long long* dbg;   // STAMP only
+};
+
+__device__ __forceinline__ uint32_t off16_lo(uint32_t q) {
+  uint32_t r;
+  asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+      : "=v"(r) : "v"(q));
+  return r;
+}
+__device__ __forceinline__ uint32_t off16_hi(uint32_t q) { return (q >> 16) << 4; }
+typedef __attribute__((address_space(3))) const f64x2 lds_cf64x2;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const int32_t* gptr_i32;
+typedef __attribute__((address_space(1))) const unsigned char* gptr_u8;
+typedef __attribute__((address_space(1))) const u32x4* gptr_u32x4;
+__device__ __forceinline__ f64x2 lds_pair_at(uint32_t byte_off) {
+  return *reinterpret_cast<lds_cf64x2*>(static_cast<uintptr_t>(byte_off));
+}
+
+template <bool STAMP, int ABL = 0>
+__global__ void __launch_bounds__(1024)
+spmm_colpair_f64(SpmmPairArgs a) {
+  constexpr int BLOCK = 1024;
+  unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
+  if constexpr (STAMP) t_all0 = __builtin_amdgcn_s_memtime();
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  f64x2* ent = reinterpret_cast<f64x2*>(smem_raw);
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t f = 0;
+  const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
+  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+  const int ns = a.nslices;
+  const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
+  f64x2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;   // next slice: p0..p4 column A, p5..p9 column B
+  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = f64x2{0.0, 0.0};
+
+#define PLAIDHIP_PF_ONE(k, reg, base)                                                              \
+  if ((k + 1) * BLOCK <= g2_) {                                                                     \
+    reg = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(base + (size_t)k * BLOCK * 16 + lane_off16)); \
+  } else { /* dead during the gather loop: never carries an old value across it */                  \
+    reg = f64x2{0.0, 0.0};                                                                          \
+    if (k * BLOCK < g2_ && tid + k * BLOCK < g2_)                                                   \
+      reg = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(base + (size_t)k * BLOCK * 16 + lane_off16)); \
+  }
+#define PLAIDHIP_PREFETCH(pp_, si_)                                                                 \
+  do {                                                                                              \
+    uint32_t lane_off16 = (uint32_t)tid * 16u;                                                      \
+    asm volatile("" : "+v"(lane_off16)); /* keep address math out of the enclosing loops */         \
+    const int g0_ = a.slices[si_].g0;                                                               \
+    const int g2_ = a.slices[si_].gs >> 1;                                                          \
+    const int ca_ = 2 * (pp_);                                                                      \
+    const int cb_ = (ca_ + 1 < a.n) ? ca_ + 1 : ca_;                                                \
+    const char* xa_ = reinterpret_cast<const char*>(a.X + (int64_t)ca_ * a.ldx + g0_);              \
+    const char* xb_ = reinterpret_cast<const char*>(a.X + (int64_t)cb_ * a.ldx + g0_);              \
+    PLAIDHIP_PF_ONE(0, p0, xa_) PLAIDHIP_PF_ONE(1, p1, xa_) PLAIDHIP_PF_ONE(2, p2, xa_)             \
+    PLAIDHIP_PF_ONE(3, p3, xa_) PLAIDHIP_PF_ONE(4, p4, xa_)                                         \
+    PLAIDHIP_PF_ONE(0, p5, xb_) PLAIDHIP_PF_ONE(1, p6, xb_) PLAIDHIP_PF_ONE(2, p7, xb_)             \
+    PLAIDHIP_PF_ONE(3, p8, xb_) PLAIDHIP_PF_ONE(4, p9, xb_)                                         \
+  } while (0)
+#define PLAIDHIP_ST_ONE(k, ra, rb)                      \
+  if (k * BLOCK < g2) {                                  \
+    const int i_ = tid_o + k * BLOCK;                    \
+    if (i_ < g2) {                                       \
+      ent[2 * i_] = f64x2{ra.x, rb.x};                   \
+      ent[2 * i_ + 1] = f64x2{ra.y, rb.y};               \
+    }                                                    \
+  }
+
+  int p = blockIdx.x;
+  if (p < a.npairs) PLAIDHIP_PREFETCH(p, 0);
+  const char* part = reinterpret_cast<const char*>(a.partial + (size_t)blockIdx.x * (size_t)(a.ktiles + 1) * 64);  // uniform
+
+  for (; p < a.npairs; p += gridDim.x) {
+    const int cA = 2 * p;
+    const bool hasB = cA + 1 < a.n;
+    const int cB = hasB ? cA + 1 : cA;
+    for (int si = 0; si < ns; ++si) {
+      const plaidhip_pair_slice_dev* sl = a.slices + si;
+      const int gs_ = __builtin_amdgcn_readfirstlane(sl->gs);
+      const int g2 = gs_ >> 1;
+      unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+      if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
+      int tid_o = tid;
+      asm volatile("" : "+v"(tid_o));
+      // ---- stage the slice of both columns, interleaved -----------------------------------
+      PLAIDHIP_ST_ONE(0, p0, p5) PLAIDHIP_ST_ONE(1, p1, p6) PLAIDHIP_ST_ONE(2, p2, p7)
+      PLAIDHIP_ST_ONE(3, p3, p8) PLAIDHIP_ST_ONE(4, p4, p9)
+      if ((gs_ & 1) && tid == 0) {
+        const int64_t gl = (int64_t)sl->g0 + gs_ - 1;
+        ent[gs_ - 1] = f64x2{a.X[(int64_t)cA * a.ldx + gl], a.X[(int64_t)cB * a.ldx + gl]};
+      }
+      if (tid < kPadSlotsPair) ent[gs_ + tid] = f64x2{0.0, 0.0};
+      __syncthreads();
+      if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
+      int nsi = si + 1, np = p;
+      if (nsi == ns) { nsi = 0; np = p + gridDim.x; }
+      const bool want_pf = np < a.npairs;
+      const bool first = si == 0, last = si == ns - 1;
+      const gptr_i32 wco = (gptr_i32)sl->wave_chunk_off;
+      const int ch_begin = __builtin_amdgcn_readfirstlane(wco[wave]);
+      const int ch_end = __builtin_amdgcn_readfirstlane(wco[wave + 1]);
+
+      if (ch_begin < ch_end) {
+        // pointers read from memory are generic to the compiler: say "global" or it emits flat loads
+        const gptr_i32 wtile_end = (gptr_i32)sl->wtile_end;
+        gptr_u8 ibase = (gptr_u8)sl->tile_idx + (int64_t)ch_begin * 1024;  // uniform
+        const gptr_u8 ibase0 = ibase;
+        uint32_t lane_o = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_o));
+        const uint32_t ioff = lane_o * 16u;
+#define PLAIDHIP_LOADQ(rel)                                                                          \
+  (ABL == 2 ? u32x4{lane_o | ((lane_o + 64u) << 16), (lane_o + 128u) | ((lane_o + 192u) << 16),       \
+                    (lane_o + 256u) | ((lane_o + 320u) << 16), (lane_o + 384u) | ((lane_o + 448u + (rel)) << 16)} \
+            : (ABL == 6 ? *(gptr_u32x4)(ibase0 + (int64_t)((rel) & 1) * 1024 + ioff)   /* L1-resident: same 2 KiB again */ \
+                        : *(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff)))
+#define PLAIDHIP_GATHER4A(q)                                                   \
+  va0 = lds_pair_at(off16_lo((q).x)); va1 = lds_pair_at(off16_hi((q).x));       \
+  va2 = lds_pair_at(off16_lo((q).y)); va3 = lds_pair_at(off16_hi((q).y));
+#define PLAIDHIP_GATHER4B(q)                                                   \
+  vb0 = lds_pair_at(off16_lo((q).z)); vb1 = lds_pair_at(off16_hi((q).z));       \
+  vb2 = lds_pair_at(off16_lo((q).w)); vb3 = lds_pair_at(off16_hi((q).w));
+#define PLAIDHIP_ADD4(V)                                                       \
+  a0 += (V##0).x; b0 += (V##0).y; a1 += (V##1).x; b1 += (V##1).y;                       \
+  a2 += (V##2).x; b2 += (V##2).y; a3 += (V##3).x; b3 += (V##3).y;
+#define PLAIDHIP_EPI(sum, cc)                                                  \
+  {                                                                            \
+    const double w_ = is_mean ? mw : 1.0;                                      \
+    const double v_ = alpha * ((sum) * w_) + a.beta * (mk * w_);               \
+    __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);         \
+    f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                              \
+    f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                            \
+    f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                              \
+  }
+#define PLAIDHIP_TILE_END(chv)                                                                 \
+  if ((chv) + 1 == next_end) { /* wave-uniform: tile finished */                               \
+    const double sumA = ((a0 + a1) + (a2 + a3)) + old.x;                                       \
+    const double sumB = ((b0 + b1) + (b2 + b3)) + old.y;                                       \
+    if (!last) {                                                                               \
+      if (ABL != 5) *reinterpret_cast<f64x2*>(const_cast<char*>(part) + (int64_t)k * 1024 + ioff) = f64x2{sumA, sumB};  \
+    } else if (mj >= 0) {                                                                      \
+      PLAIDHIP_EPI(sumA, cA)                                                                   \
+      if (hasB) PLAIDHIP_EPI(sumB, cB)                                                         \
+    }                                                                                          \
+    ++k;                                                                                       \
+    next_end = __builtin_amdgcn_readfirstlane(wtile_end[k]);                                   \
+    if (last) {                                                                                \
+      mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
+      mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
+      mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
+    }                                                                                          \
+    if (!first && ABL != 5) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);        \
+    a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = 0.0;                                               \
+  }
+        // 8 index chunks (8 KiB per wave) in flight: the lists come from L2 (~1 us away under load)
+        u32x4 qa = PLAIDHIP_LOADQ(0);
+        u32x4 qb = PLAIDHIP_LOADQ(1);
+        u32x4 qc = PLAIDHIP_LOADQ(2);
+        u32x4 qd = PLAIDHIP_LOADQ(3);
+        u32x4 qe = PLAIDHIP_LOADQ(4);
+        u32x4 qf = PLAIDHIP_LOADQ(5);
+        u32x4 qg = PLAIDHIP_LOADQ(6);
+        u32x4 qh = PLAIDHIP_LOADQ(7);
+        int k = tk_begin;
+        int next_end = __builtin_amdgcn_readfirstlane(wtile_end[k]);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        const uint32_t moff4 = lane_o * 4u, moff8 = lane_o * 8u;
+        int mj = -1;
+        double mw = 0.0, mk = 0.0;
+        if (last) {
+          mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
+          mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);
+          mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
+        }
+        f64x2 old = f64x2{0.0, 0.0};
+        if (!first && ABL != 5) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);
+        f64x2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+
+        // Half-chunk software pipeline: the four gathers of the next half are in the LDS queue
+        // while the eight adds of the current half issue, so the wave always has reads in flight.
+        int ch = ch_begin;
+        ibase += 8 * 1024;
+#define PLAIDHIP_STEP(qcur, qnext, rel, chv)                                             \
+  PLAIDHIP_GATHER4B(qcur)                                                                \
+  qcur = PLAIDHIP_LOADQ(rel);                                                            \
+  PLAIDHIP_ADD4(va)                                                                      \
+  PLAIDHIP_GATHER4A(qnext) /* first half of the next chunk (spare chunks exist behind the stream) */ \
+  PLAIDHIP_ADD4(vb)                                                                      \
+  PLAIDHIP_TILE_END(chv)
+#define PLAIDHIP_STEP_TAIL(qcur, qnext)                                                  \
+  if (ch < ch_end) {                                                                     \
+    PLAIDHIP_GATHER4B(qcur) PLAIDHIP_ADD4(va) PLAIDHIP_GATHER4A(qnext) PLAIDHIP_ADD4(vb) \
+    PLAIDHIP_TILE_END(ch)                                                                \
+    ++ch;                                                                                \
+  }
+        PLAIDHIP_GATHER4A(qa)
+        for (; ch + 7 < ch_end; ch += 8, ibase += 8 * 1024) {
+          PLAIDHIP_STEP(qa, qb, 0, ch)
+          PLAIDHIP_STEP(qb, qc, 1, ch + 1)
+          PLAIDHIP_STEP(qc, qd, 2, ch + 2)
+          PLAIDHIP_STEP(qd, qe, 3, ch + 3)
+          PLAIDHIP_STEP(qe, qf, 4, ch + 4)
+          PLAIDHIP_STEP(qf, qg, 5, ch + 5)
+          PLAIDHIP_STEP(qg, qh, 6, ch + 6)
+          PLAIDHIP_STEP(qh, qa, 7, ch + 7)
+        }
+        PLAIDHIP_STEP_TAIL(qa, qb)
+        PLAIDHIP_STEP_TAIL(qb, qc)
+        PLAIDHIP_STEP_TAIL(qc, qd)
+        PLAIDHIP_STEP_TAIL(qd, qe)
+        PLAIDHIP_STEP_TAIL(qe, qf)
+        PLAIDHIP_STEP_TAIL(qf, qg)
+        PLAIDHIP_STEP_TAIL(qg, qh)
+#undef PLAIDHIP_STEP
+#undef PLAIDHIP_STEP_TAIL
+#undef PLAIDHIP_GATHER4A
+#undef PLAIDHIP_GATHER4B
+#undef PLAIDHIP_ADD4
+#undef PLAIDHIP_TILE_END
+#undef PLAIDHIP_EPI
+#undef PLAIDHIP_LOADQ
+      }
+      if (want_pf) {
+        PLAIDHIP_PREFETCH(np, nsi);
+      } else {  // (tells the register allocator the old values are not needed across the gather loop)
+        p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = f64x2{0.0, 0.0};
+      }
+      if constexpr (STAMP) ts2 = __builtin_amdgcn_s_memtime();
+      __syncthreads();  // the slice is overwritten by the next iteration
+      if constexpr (STAMP) {
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        t_stage += ts1 - ts0;
+        t_gather += ts2 - ts1;
+        t_wait += ts3 - ts2;
+      }
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && a.dbg != nullptr) {
+      unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (BLOCK / 64) + wave) * 4;
+      d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
+    }
+  }
+  publish_flags(f, a.flags);
+#undef PLAIDHIP_PREFETCH
+#undef PLAIDHIP_PF_ONE
+#undef PLAIDHIP_ST_ONE
+}
+
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
+
+// which dense-X kernel: PLAIDHIP_SPMM_KERNEL = pair | single (default: pair where it applies)
+static int pair_kernel_mode() {   // read per launch (tests flip it): 0 single, 1 default, 2 pair wherever possible
+  const char* e = getenv("PLAIDHIP_SPMM_KERNEL");
+  if (e == nullptr) return 1;
+  return strcmp(e, "single") == 0 ? 0 : (strcmp(e, "pair") == 0 ? 2 : 1);
+}
+
+static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n,
+                          int stat, double alpha, const double* alpha_div, double beta, double* S, int64_t lds,
+                          uint32_t* flags) {
+  const plaidhip_pair_plan& pl = gs->pair;
+  int32_t gmax = 0;
+  for (const plaidhip_pair_slice& sl : pl.slices) gmax = sl.gs > gmax ? sl.gs : gmax;
+  const size_t smem = (size_t)(gmax + kPadSlotsPair) * 16;
+  PH_FULL_LDS(ctx, (&spmm_colpair_f64<false>));
+  SpmmPairArgs a{};
+  a.X = X;
+  a.ldx = ldx;
+  a.n = n;
+  a.npairs = (n + 1) / 2;
+  a.nslices = (int32_t)pl.slices.size();
+  a.ktiles = pl.ktiles;
+  a.slices = pl.d_slices;
+  a.wave_tile_off = pl.d_wave_tile_off;
+  a.meta_j = pl.d_meta_j;
+  a.meta_w = pl.d_meta_w;
+  a.meta_k = pl.d_meta_k;
+  a.partial = reinterpret_cast<f64x2*>(pl.d_partial);
+  a.stat = stat;
+  a.alpha = alpha;
+  a.beta = beta;
+  a.alpha_div = alpha_div;
+  a.S = S;
+  a.lds = lds;
+  a.flags = flags;
+  int per_cu = (int)(kLdsBytes / smem);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int grid = ctx->num_cu * per_cu;
+  if (a.nslices > 1 && grid > pl.partial_wgs) grid = pl.partial_wgs;
+  if (grid > a.npairs) grid = a.npairs;
+  if (g_ablate == 2) {   // no index loads (tools/ only, wrong scores)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL((spmm_colpair_f64<true, 2>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (g_ablate == 5) {   // no partial-sum round trip between slices (tools/ only, wrong scores)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 5>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL((spmm_colpair_f64<true, 5>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (g_ablate == 6) {   // index loads always hit L1 (tools/ only, wrong scores)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 6>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL((spmm_colpair_f64<true, 6>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL(spmm_colpair_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL(spmm_colpair_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  }
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_cast<unsigned long long*>(dbg); }
 
 template <bool CSC_X, int BLOCK>
@@ -417,6 +767,14 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
+  {
+    // two columns per pass when X allows 16-byte loads of both columns of a pair
+    const int mode = pair_kernel_mode();
+    const bool aligned = (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6;
+    if (diag && mode != 0 && aligned && !gs->pair.slices.empty())
+      return launch_colpair(ctx, gs, X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  }
   SpmmArgs a{};
   a.X = X;
   a.ldx = ldx;

@@ -162,6 +162,55 @@ def test_spmm_gene_sliced(hip_ctx, g):
     close(hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi), _oracle().plaid(Xs, rn, G, rn))
 
 
+@pytest.mark.parametrize("kernel", ["pair", "single"])
+@pytest.mark.parametrize("g,n,m", [(37, 1, 3), (1000, 5, 70), (10224, 9, 130), (10226, 8, 130), (20000, 33, 700),
+                                   (25001, 7, 150), (45000, 4, 90), (333, 3, 40)])
+def test_spmm_both_dense_kernels(hip_ctx, monkeypatch, kernel, g, n, m):
+    """the two-columns-per-pass kernel (1-5 gene slices, odd n) and the one-column kernel give the oracle's scores"""
+    from plaid_amd import synth as sy
+    monkeypatch.setenv("PLAIDHIP_SPMM_KERNEL", kernel)
+    Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(g, 400), sort_by_size=False)
+    X = sy.dense_columns(g, 0, n) - 8.0
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", False), _oracle().plaid(X, rn, G, rn, normalize=False))
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "sum", True), _oracle().plaid(X, rn, G, rn, stats="sum"))
+    close(hip_ctx.sing_dense(X, Gp, Gi), _oracle().replaid_sing(X, rn, G, rn))       # alpha/beta epilogue
+
+
+@pytest.mark.parametrize("g,n", [(10001, 5), (20001, 3), (333, 2)])
+def test_spmm_pair_kernel_odd_genes_strided(monkeypatch, g, n):
+    """device-level call with ldx = g + 1 (even) and odd g: the last gene of the last slice is staged separately"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    monkeypatch.setenv("PLAIDHIP_SPMM_KERNEL", "pair")
+    m = 90
+    rng = np.random.default_rng(g)
+    sets = [np.array([0, g // 2, g - 1])]                   # the odd last gene is a member
+    sets += [np.sort(rng.choice(g, size=int(k), replace=False)) for k in rng.integers(1, 300, size=m - 1)]
+    Gp = np.concatenate([[0], np.cumsum([len(x) for x in sets])]).astype(np.int32)
+    Gi = np.concatenate(sets).astype(np.int32)
+    X = sy.dense_columns(g, 0, n)
+    dev = torch.device("cuda", 0)
+    ctx = plaid_amd.Context(0)
+    gs = ctx.geneset(g, Gp, Gi)
+    Xd = torch.zeros((n, g + 1), dtype=torch.float64, device=dev)
+    Xd[:, :g] = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+    Sd = torch.full((n, m + 3), -7.0, dtype=torch.float64, device=dev)
+    fl = torch.zeros(4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.dev_spmm_dense(gs, Xd.data_ptr(), g + 1, n, Sd.data_ptr(), m + 3, "mean", 1.0, 0.0, fl.data_ptr())
+    ctx.synchronize()
+    S = Sd.cpu().numpy()
+    assert np.all(S[:, m:] == -7.0)                          # stride padding untouched
+    sizes = np.diff(Gp).astype(float)
+    exp = np.stack([np.add.reduceat(X[Gi, j], Gp[:-1]) for j in range(n)]) / (1e-8 + sizes)
+    close(S[:, :m], exp)
+    gs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("g", [1, 2, 63, 64, 65, 1000, 4097, 20000, 20448, 20449, 33000])
 def test_colranks_sizes_vs_oracle(hip_ctx, g):
     """column lengths around wave/workgroup/LDS boundaries, tied (rounded) data"""

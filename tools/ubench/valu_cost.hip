@@ -9,6 +9,11 @@
 
 #define SDWA_LO(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(q))
 #define SDWA_HI(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(q))
+#define SDWA4_LO(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(q))
+#define SDWA4_HI(r, q) asm volatile("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(q))
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f64x2 ld2;
+#define LD2(o) (*(ld2*)(uintptr_t)(o))
 
 template <int MODE>
 __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iters) {
@@ -20,6 +25,7 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
   const unsigned lane = threadIdx.x & 63;
   unsigned q0 = lane | ((lane + 64) << 16), q1 = (lane + 128) | ((lane + 192) << 16), q2 = (lane + 256) | ((lane + 320) << 16), q3 = (lane + 384) | ((lane + 448) << 16);
   unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+  f64x2 pv0 = {0, 0}, pv1 = {0, 0}, pv2 = {0, 0}, pv3 = {0, 0};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < iters; ++i) {
     if (MODE == 0) {
@@ -75,6 +81,30 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
                    "v_cmp_lt_u64 vcc, %0, %1\n v_cndmask_b32 %6, %6, %7, vcc\n"
                    : "+v"(k0), "+v"(k1), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "vcc");
       a0 = __longlong_as_double(k0); a1 = __longlong_as_double(k1);
+    } else if (MODE == 10) {  // ds_read_b128 only (16-byte entries, conflict-free per 16-lane group), 8 per iter
+      f64x2 v0, v1, v2, v3, v4, v5, v6, v7;
+      asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %9\n ds_read_b128 %2, %10\n ds_read_b128 %3, %11\n"
+                   "ds_read_b128 %4, %8 offset:4096\n ds_read_b128 %5, %9 offset:4096\n ds_read_b128 %6, %10 offset:4096\n ds_read_b128 %7, %11 offset:4096\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                   : "v"(lane * 16), "v"(lane * 16 + 1024), "v"(lane * 16 + 2048), "v"(lane * 16 + 3072));
+      asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    } else if (MODE == 11) {  // pair loop: 8 x (sdwa, ds_read_b128), then 16 adds
+      unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+      SDWA4_LO(o0, q0); SDWA4_HI(o1, q0); SDWA4_LO(o2, q1); SDWA4_HI(o3, q1); SDWA4_LO(o4, q2); SDWA4_HI(o5, q2); SDWA4_LO(o6, q3); SDWA4_HI(o7, q3);
+      const f64x2 v0 = LD2(o0), v1 = LD2(o1), v2 = LD2(o2), v3 = LD2(o3), v4 = LD2(o4), v5 = LD2(o5), v6 = LD2(o6), v7 = LD2(o7);
+      a0 += v0.x; a4 += v0.y; a1 += v1.x; a5 += v1.y; a2 += v2.x; a6 += v2.y; a3 += v3.x; a7 += v3.y;
+      a0 += v4.x; a4 += v4.y; a1 += v5.x; a5 += v5.y; a2 += v6.x; a6 += v6.y; a3 += v7.x; a7 += v7.y;
+      q0 += 0x00010001u * (i & 1);
+    } else if (MODE == 12) {  // pair loop, half-chunk pipelined: next 4 reads in flight during 8 adds
+      unsigned o0, o1, o2, o3;
+      SDWA4_LO(o0, q2); SDWA4_HI(o1, q2); SDWA4_LO(o2, q3); SDWA4_HI(o3, q3);
+      const f64x2 w0 = LD2(o0), w1 = LD2(o1), w2 = LD2(o2), w3 = LD2(o3);
+      a0 += pv0.x; a4 += pv0.y; a1 += pv1.x; a5 += pv1.y; a2 += pv2.x; a6 += pv2.y; a3 += pv3.x; a7 += pv3.y;
+      q0 += 0x00010001u * (i & 1);
+      SDWA4_LO(o0, q0); SDWA4_HI(o1, q0); SDWA4_LO(o2, q1); SDWA4_HI(o3, q1);
+      pv0 = LD2(o0); pv1 = LD2(o1); pv2 = LD2(o2); pv3 = LD2(o3);
+      a0 += w0.x; a4 += w0.y; a1 += w1.x; a5 += w1.y; a2 += w2.x; a6 += w2.y; a3 += w3.x; a7 += w3.y;
     } else if (MODE == 6) {  // ds_read only, no adds: LDS issue rate
       double v0, v1, v2, v3, v4, v5, v6, v7;
       asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
@@ -86,7 +116,7 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + pv0.x + pv1.y + pv2.x + pv3.y;
   outu[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
@@ -118,6 +148,9 @@ void run(const char* name, int threads) {
 int main() {
   // value check of the denormal trick is done by the kernel tests (addresses must match)
 
+  for (int t : {512, 1024}) {
+    run<10>("ds_read_b128", t); run<11>("pair loop", t); run<12>("pair loop pipelined", t);
+  }
   for (int t : {256, 512, 1024}) {
     run<0>("v_add_f64", t); run<1>("lshl_sdwa", t); run<2>("v_lshlrev", t); run<3>("v_add_f32", t);
     run<8>("min/max_f64", t); run<9>("cmp_u64+cnd", t); run<7>("mul_f32_sdwa", t); run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
