@@ -115,6 +115,7 @@ struct plaidhip_geneset {
   int64_t chunks = 0;          // total over slices
   std::vector<plaidhip_slice> slices;   // the column is consumed slice by slice when g > kMaxLdsGenes
   plaidhip_pair_plan pair;              // dense-X kernel: two columns per pass
+  bool rows_in_order = false;           // the sets came sorted by decreasing size: a tile's lanes are neighbouring rows of S
 };
 
 namespace plaidhip {

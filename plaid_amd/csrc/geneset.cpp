@@ -95,34 +95,66 @@ struct TilePlan {
   std::vector<uint16_t> idx;         // [step][lane 0..63]
 };
 
-// Schedule one tile (64 lanes; lane l handles set lane_set[l] or nothing).
+// Relative cost of one extra LDS pass (a 2-way conflict inside one lane group) against a whole
+// extra gather step; PLAIDHIP_CONFLICT_COST overrides (>= 1 disables conflicted steps).
+double conflict_cost() {
+  static const double c = [] {
+    const char* e = getenv("PLAIDHIP_CONFLICT_COST");
+    return e ? atof(e) : 0.2;
+  }();
+  return c;
+}
+
+// Number of steps T (a multiple of 8) for a tile whose longest lane has Lmax reads and whose slot
+// degrees are deg[0..n).  Koenig needs max(longest lane, busiest slot) steps for a conflict-free
+// schedule, and the busiest slot sits ~2 sigma above the mean.  A slot may instead serve TWO lanes
+// in a few steps (its reads beyond the first T go to a second vertex of that slot): such a step
+// costs one more LDS pass for that lane group but no instruction, no index bytes and no
+// VGPR-return cycles.  T minimises  T + conflict_cost * (reads beyond T over all slots).
+int choose_steps(int Lmax, const int* deg, int n) {
+  int Dmax = 0;
+  for (int k = 0; k < n; ++k) Dmax = std::max(Dmax, deg[k]);
+  const double cx = conflict_cost();
+  const int t_lo = std::max(8, (std::max(Lmax, (Dmax + 1) / 2) + 7) & ~7);
+  const int t_hi = std::max(t_lo, (Dmax + 7) & ~7);
+  if (cx >= 1.0) return t_hi;
+  int T = t_hi;
+  double best = 1e300;
+  for (int t = t_lo; t <= t_hi; t += 8) {
+    int64_t excess = 0;
+    for (int k = 0; k < n; ++k) excess += std::max(0, deg[k] - t);
+    const double cost = (double)t + cx * (double)excess;
+    if (cost < best) { best = cost; T = t; }
+  }
+  return T;
+}
+
+// Schedule one tile (64 lanes; lane l handles set lane_set[l] or nothing): edge-colour each
+// 32-lane half (the unit ds_read_b64 is served in) against the 32 bank pairs, slot = gene mod 32.
 void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* lane_set, TilePlan& tp) {
-  // PLAIDHIP_SLOT_PORTS=2 (tuning knob): let every bank pair serve TWO lanes per step (a 2-way
-  // bank conflict, +1 LDS cycle) -- fewer, fuller steps when instruction issue, not the LDS
-  // pipe, is the limit.  Each slot then has two vertices; its reads alternate between them.
-  static const int ports = (getenv("PLAIDHIP_SLOT_PORTS") && atoi(getenv("PLAIDHIP_SLOT_PORTS")) == 2) ? 2 : 1;
   std::vector<Edge> half[2];
-  int D[2] = {0, 0};
-  for (int h = 0; h < 2; ++h) {
-    int degU[32] = {0}, degV[64] = {0}, seen[32] = {0};
+  int degV[64] = {0};
+  int Lmax = 0;
+  for (int h = 0; h < 2; ++h)
     for (int l = 0; l < 32; ++l) {
       const int32_t j = lane_set[h * 32 + l];
       if (j < 0) continue;
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
         const int32_t gene = Gi[p];
-        const int slot = gene & 31;
-        const int vtx = slot + 32 * ((seen[slot]++) % ports);
-        Edge e{(uint8_t)l, (uint8_t)vtx, (uint16_t)gene, -1};
+        Edge e{(uint8_t)l, (uint8_t)(gene & 31), (uint16_t)gene, -1};
         half[h].push_back(e);
-        ++degU[l];
-        ++degV[vtx];
+        ++degV[h * 32 + (gene & 31)];
       }
+      Lmax = std::max(Lmax, Gp[j + 1] - Gp[j]);
     }
-    for (int k = 0; k < 32; ++k) D[h] = std::max(D[h], degU[k]);
-    for (int k = 0; k < 64; ++k) D[h] = std::max(D[h], degV[k]);
-    color_bipartite(half[h], D[h], 64);
+  const int T = choose_steps(Lmax, degV, 64);
+  for (int h = 0; h < 2; ++h) {
+    int seen[32] = {0};
+    for (Edge& e : half[h])
+      if (seen[e.v]++ >= T) e.v = (uint8_t)(e.v + 32);   // second vertex of an over-full slot
+    color_bipartite(half[h], T, 64);
   }
-  tp.steps = std::max(8, (std::max(D[0], D[1]) + 7) & ~7);   // >= 1 chunk: empty sets still get their 0 written
+  tp.steps = T;                                            // >= 1 chunk: empty sets still get their 0 written
   tp.idx.assign((size_t)tp.steps * 64, 0);
   std::vector<uint8_t> used((size_t)tp.steps * 64, 0);     // (step, half*32 + slot) taken by a real read
   std::vector<uint8_t> filled((size_t)tp.steps * 64, 0);   // (step, lane) has a real read
@@ -131,17 +163,16 @@ void plan_tile(int32_t g, const int32_t* Gp, const int32_t* Gi, const int32_t* l
       const size_t s = (size_t)e.color;
       tp.idx[s * 64 + h * 32 + e.u] = e.gene;
       filled[s * 64 + h * 32 + e.u] = 1;
-      used[s * 64 + h * 32 + (e.v & 31)] += 1;
+      used[s * 64 + h * 32 + (e.v & 31)] = 1;
     }
   // idle (lane, step) pairs read a zero entry behind the column (index g + r, r < 32) whose
-  // bank-slot ((g + r) mod 32) nobody else uses in this step: #free slots == #idle lanes.
+  // bank-slot ((g + r) mod 32) nobody else uses in this step: #free slots >= #idle lanes.
   for (int32_t s = 0; s < tp.steps; ++s)
     for (int h = 0; h < 2; ++h) {
       int slot = 0;
       for (int l = 0; l < 32; ++l) {
         if (filled[(size_t)s * 64 + h * 32 + l]) continue;
-        while (slot < 32 && used[(size_t)s * 64 + h * 32 + slot]) ++slot;
-        if (slot >= 32) slot = l;          // two-port schedules can fill every slot: share one (zero entries, harmless)
+        while (used[(size_t)s * 64 + h * 32 + slot]) ++slot;
         const int r = ((slot - g) % 32 + 32) % 32;
         tp.idx[(size_t)s * 64 + h * 32 + l] = (uint16_t)(g + r);
         ++slot;
@@ -291,30 +322,37 @@ static const uint8_t kB128Groups[4][16] = {
     {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
 
 // Schedule the genes of one tile that fall into [g0, g0+gs): edge-colour every 16-lane group
-// against the 16 slots.  Idle (lane, step) pairs read a zero entry gs + r (r < 16) on a free slot.
+// against the 16 slots (see choose_steps for the number of steps).  Idle (lane, step) pairs read a
+// zero entry gs + r (r < 16) on a free slot.
 void plan_tile_b128(int32_t g0, int32_t gs, const int32_t* Gp, const int32_t* Gi, const int32_t* lane_set,
                     TilePlan& tp) {
   std::vector<Edge> grp[4];
-  int D[4] = {0, 0, 0, 0};
+  int degV[4][16] = {{0}};
+  int Lmax = 0;
   for (int q = 0; q < 4; ++q) {
-    int degU[16] = {0}, degV[16] = {0};
     for (int l = 0; l < 16; ++l) {
       const int32_t j = lane_set[kB128Groups[q][l]];
       if (j < 0) continue;
+      int du = 0;
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
         const int32_t gene = Gi[p] - g0;
         if (gene < 0 || gene >= gs) continue;
         Edge e{(uint8_t)l, (uint8_t)(gene & 15), (uint16_t)gene, -1};
         grp[q].push_back(e);
-        ++degU[l];
-        ++degV[gene & 15];
+        ++du;
+        ++degV[q][gene & 15];
       }
+      Lmax = std::max(Lmax, du);
     }
-    for (int k = 0; k < 16; ++k) D[q] = std::max(D[q], std::max(degU[k], degV[k]));
-    color_bipartite(grp[q], D[q], 16);
   }
-  const int dmax = std::max(std::max(D[0], D[1]), std::max(D[2], D[3]));
-  tp.steps = std::max(8, (dmax + 7) & ~7);
+  const int T = choose_steps(Lmax, &degV[0][0], 64);
+  for (int q = 0; q < 4; ++q) {
+    int seen[16] = {0};
+    for (Edge& e : grp[q])
+      if (seen[e.v]++ >= T) e.v = (uint8_t)(e.v + 16);   // second vertex of an over-full slot
+    color_bipartite(grp[q], T, 32);
+  }
+  tp.steps = T;
   tp.idx.assign((size_t)tp.steps * 64, 0);
   std::vector<uint8_t> used((size_t)tp.steps * 64, 0), filled((size_t)tp.steps * 64, 0);
   for (int q = 0; q < 4; ++q)
@@ -322,7 +360,7 @@ void plan_tile_b128(int32_t g0, int32_t gs, const int32_t* Gp, const int32_t* Gi
       const size_t st = (size_t)e.color;
       tp.idx[st * 64 + kB128Groups[q][e.u]] = e.gene;
       filled[st * 64 + kB128Groups[q][e.u]] = 1;
-      used[st * 64 + q * 16 + e.v] = 1;
+      used[st * 64 + q * 16 + (e.v & 15)] = 1;
     }
   for (int32_t st = 0; st < tp.steps; ++st)
     for (int q = 0; q < 4; ++q) {
@@ -330,7 +368,7 @@ void plan_tile_b128(int32_t g0, int32_t gs, const int32_t* Gp, const int32_t* Gi
       for (int l = 0; l < 16; ++l) {
         const int lane = kB128Groups[q][l];
         if (filled[(size_t)st * 64 + lane]) continue;
-        while (used[(size_t)st * 64 + q * 16 + slot]) ++slot;
+        while (used[(size_t)st * 64 + q * 16 + slot]) ++slot;   // #free slots >= #idle lanes
         const int r = ((slot - gs) % 16 + 16) % 16;
         tp.idx[(size_t)st * 64 + lane] = (uint16_t)(gs + r);
         ++slot;
@@ -356,6 +394,15 @@ struct PairPlanHost {
 // lane meets the same set again in the next slice and its partial sum can round-trip through S
 // privately (no cross-wave hand-off).
 void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, int waves, PairPlanHost& pp) {
+  const int32_t nsl = (g + kMaxLdsGenesPair - 1) / kMaxLdsGenesPair;
+  int32_t width = (g + nsl - 1) / nsl;
+  width = (width + 1) & ~1;
+  std::vector<int32_t> starts;
+  for (int32_t g0 = 0; g0 < g; g0 += width) starts.push_back(g0);
+  const int S = (int)starts.size();
+  // Tiles: 64 sets of similar total size.  (Clustering on the per-slice sizes, k-d fashion, saves
+  // another 4 % of the steps but scatters the set ids of a tile, and the scattered 8-byte S stores
+  // cost far more than that: measured 1.25 vs 1.05 ms on C2.)
   std::vector<int32_t> order(m);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(),
@@ -363,12 +410,6 @@ void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
   const int32_t tiles = (m + 63) / 64;
   std::vector<int32_t> lane_set((size_t)tiles * 64, -1);
   for (int32_t s = 0; s < m; ++s) lane_set[s] = order[s];
-  const int32_t nsl = (g + kMaxLdsGenesPair - 1) / kMaxLdsGenesPair;
-  int32_t width = (g + nsl - 1) / nsl;
-  width = (width + 1) & ~1;
-  std::vector<int32_t> starts;
-  for (int32_t g0 = 0; g0 < g; g0 += width) starts.push_back(g0);
-  const int S = (int)starts.size();
   std::vector<std::vector<TilePlan>> plans(S, std::vector<TilePlan>(tiles));
   {
     unsigned nt = std::thread::hardware_concurrency();
@@ -528,6 +569,9 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
       if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
     }
   }
+  gs->rows_in_order = true;   // tiles take the sets in decreasing-size order: identity iff already sorted
+  for (int32_t j = 0; j + 1 < m; ++j)
+    if (Gp[j + 2] - Gp[j + 1] > Gp[j + 1] - Gp[j]) { gs->rows_in_order = false; break; }
   if (m > 0) {
     // pair plan (two sample columns per LDS entry) for the dense-X kernel
     PairPlanHost pp;

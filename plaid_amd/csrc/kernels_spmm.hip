@@ -36,6 +36,7 @@ struct SpmmArgs {
   const double* Xx;
   int32_t g, n, m;   // g: genes of THIS slice
   int32_t g0;        // first gene of the slice (CSC rows are filtered / re-based by it)
+  int32_t nt_store;  // 1: the lanes of a tile store neighbouring rows of S (streaming stores); 0: scattered rows, let L2 merge them
   int32_t acc_mode;  // 0 single slice; 1 first (store raw sum); 2 middle (S += sum); 3 last (S + sum, then epilogue)
   const uint4* tile_idx;
   const int32_t* wave_chunk_off;
@@ -210,7 +211,7 @@ spmm_colgather_f64(SpmmArgs a) {
       } else {                                                                                 \
         const double w = (a.stat == PLAIDHIP_STAT_MEAN) ? mw : 1.0;                            \
         const double v = alpha * (sum * w) + a.beta * (mk * w);                                \
-        __builtin_nontemporal_store(v, sp_);                                                   \
+        if (a.nt_store) __builtin_nontemporal_store(v, sp_); else *sp_ = v;                    \
         f |= (v < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                           \
         f |= (v == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                         \
         f |= (v != v) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                            \
@@ -352,6 +353,7 @@ struct SpmmPairArgs {
   const double* X;
   int64_t ldx;
   int32_t n, npairs, nslices, ktiles;
+  int32_t nt_store;  // see SpmmArgs
   const plaidhip_pair_slice_dev* slices;
   const int32_t* wave_tile_off;
   const int32_t* meta_j;
@@ -498,7 +500,8 @@ spmm_colpair_f64(SpmmPairArgs a) {
   {                                                                            \
     const double w_ = is_mean ? mw : 1.0;                                      \
     const double v_ = alpha * ((sum) * w_) + a.beta * (mk * w_);               \
-    __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);         \
+    if (a.nt_store) __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);  \
+    else a.S[(int64_t)(cc) * a.lds + mj] = v_;                                 \
     f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                              \
     f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                            \
     f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                              \
@@ -621,6 +624,11 @@ spmm_colpair_f64(SpmmPairArgs a) {
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 
+static int nt_store_mode(const plaidhip_geneset* gs) {
+  if (const char* e = getenv("PLAIDHIP_NT_STORE")) return atoi(e) != 0;
+  return gs->rows_in_order ? 1 : 0;
+}
+
 // which dense-X kernel: PLAIDHIP_SPMM_KERNEL = pair | single (default: pair where it applies)
 static int pair_kernel_mode() {   // read per launch (tests flip it): 0 single, 1 default, 2 pair wherever possible
   const char* e = getenv("PLAIDHIP_SPMM_KERNEL");
@@ -643,6 +651,7 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.npairs = (n + 1) / 2;
   a.nslices = (int32_t)pl.slices.size();
   a.ktiles = pl.ktiles;
+  a.nt_store = nt_store_mode(gs);
   a.slices = pl.d_slices;
   a.wave_tile_off = pl.d_wave_tile_off;
   a.meta_j = pl.d_meta_j;
@@ -752,6 +761,7 @@ static int launch_colgather(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmA
 
 static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int stat, double alpha,
                       const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
+  a.nt_store = nt_store_mode(gs);
   a.alpha_div = alpha_div;
   a.n = n;
   a.m = gs->m;

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--sets", type=int, default=5000)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ties", default="average")
+    ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..3 (wrong results by design)")
     a = ap.parse_args()
     import numpy as np
@@ -34,7 +35,7 @@ def main():
         ctx.lib.plaidhip_debug_set_ablation(a.ablate, dbg.data_ptr())
     g, n, m = a.genes, a.samples, a.sets
     t0 = time.perf_counter()
-    Gp, Gi = synth.geneset_csc(g, m)
+    Gp, Gi = synth.geneset_csc(g, m, sort_by_size=not a.unsorted)
     t1 = time.perf_counter()
     gs = ctx.geneset(g, Gp, Gi)
     t2 = time.perf_counter()
