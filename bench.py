@@ -135,17 +135,20 @@ def main():
     # ---- roofline of the dominant kernel (SpMM): algorithmic bytes per launch --------------
     # g*n*b_X + (4 z + 4 (m+1)) + m*n*b_S with b = 8 (fp64 in, fp64 out)
     alg_bytes = g * n * 8 + 4 * z + 4 * (m + 1) + m * n * 8
+    # dense X with 16-byte aligned columns takes the two-columns-per-pass kernel (kernels_spmm.hip)
+    spmm_kernel = "spmm_colpair_f64" if (g % 2 == 0 and os.environ.get("PLAIDHIP_SPMM_KERNEL") != "single") \
+        else "spmm_colgather_f64"
     achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = f"spmm_colgather_f64/{g}x{n}x{m}"
+            key = f"{spmm_kernel}/{g}x{n}x{m}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "spmm_colgather_f64", "bound": "hbm", "achieved": round(achieved, 1),
+    roofline = {"kernel": spmm_kernel, "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": round(spmm_ms, 4)}
 

@@ -610,6 +610,145 @@ int launch_minmax(plaidhip_ctx* ctx, const double* v, int64_t count, double* out
   return PLAIDHIP_OK;
 }
 
+
+// m <= BLOCK*ITEMS: register-resident RADIX selection, 8 bits per pass.  The column is read once
+// (coalesced); every thread keeps ITEMS 64-bit keys.  Keys are binned on (key - lo) >> shift over
+// the current range [lo, lo + range] (first the column's [min, max], then the bin that holds the
+// wanted rank): 256 bins, LDS-atomic histogram, one wavefront scans the bins; the search stops as
+// soon as the bin holds a single key or is one key wide.  Doubles of similar magnitude need two
+// to three passes where the bitwise search above needs one pass per differing bit.  (A variant on
+// 32-bit words -- high words first, then the low words of the keys sharing the selected high word --
+// needs more passes and measured slower: 0.235 vs 0.20 ms on C2; the passes are latency-, not
+// issue-bound.)
+template <int BLOCK, int ITEMS>
+__global__ void __launch_bounds__(BLOCK)
+col_medians_radix_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                         int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                         double* __restrict__ med) {
+  constexpr int NW = BLOCK / 64;
+  __shared__ __align__(16) uint32_t s_hist[256];
+  __shared__ unsigned long long s_mn[NW], s_mx[NW];
+  __shared__ uint32_t s_cnt[NW];
+  __shared__ uint32_t s_pick[3];        // digit, keys of the range below the bin, keys in the bin
+  __shared__ unsigned long long s_key;
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 256; i += BLOCK) s_hist[i] = 0;
+  __syncthreads();
+
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* sc = S + (int64_t)c * lds;
+    uint64_t key[ITEMS];
+    uint64_t tmn = ~0ull, tmx = 0ull;
+    uint32_t vc = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int i = tid + j * BLOCK;
+      const uint64_t k = (i < m) ? masked_key(sc[i < m ? i : m - 1], ignore_zero) : ~0ull;
+      key[j] = k;
+      const bool valid = k != ~0ull;
+      vc += (uint32_t)__popcll(__ballot(valid));
+      tmn = (valid && k < tmn) ? k : tmn;
+      tmx = (valid && k > tmx) ? k : tmx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint64_t a = (uint64_t)__shfl_xor((unsigned long long)tmn, off, 64);
+      const uint64_t b = (uint64_t)__shfl_xor((unsigned long long)tmx, off, 64);
+      tmn = a < tmn ? a : tmn;
+      tmx = b > tmx ? b : tmx;
+    }
+    if (lane == 0) { s_mn[wave] = tmn; s_mx[wave] = tmx; s_cnt[wave] = vc; }
+    __syncthreads();
+    uint64_t kmin = ~0ull, kmax = 0ull;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      kmin = s_mn[w] < kmin ? s_mn[w] : kmin;
+      kmax = s_mx[w] > kmax ? s_mx[w] : kmax;
+      cnt += s_cnt[w];
+    }
+    cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+    double r;
+    if (cnt == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+      const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
+      uint64_t lo = kmin, range = kmax - kmin;
+      uint32_t k = k_lo;         // rank wanted inside [lo, lo + range]
+      uint32_t count = cnt;      // keys inside [lo, lo + range]
+      while (range != 0ull && count > 1u) {
+        const int bits = 64 - __clzll((long long)range);
+        const int shift = bits > 8 ? bits - 8 : 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint64_t d = key[j] - lo;
+          if (key[j] >= lo && d <= range) atomicAdd(&s_hist[(uint32_t)(d >> shift)], 1u);   // masked keys lie above kmax
+        }
+        __syncthreads();
+        if (wave == 0) {
+          // 256-bin scan by one wavefront: lane l owns bins 4l .. 4l+3
+          const uint4 h4 = *reinterpret_cast<const uint4*>(&s_hist[lane * 4]);
+          *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+          const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
+          uint32_t incl = mine;
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+          }
+          uint32_t excl = incl - mine;
+          if (mine != 0 && excl <= k && k < incl) {
+            uint32_t d = 0, hh = h4.x;
+            if (k >= excl + h4.x) { excl += h4.x; d = 1; hh = h4.y;
+              if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
+                if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
+            s_pick[0] = (uint32_t)lane * 4u + d;
+            s_pick[1] = excl;
+            s_pick[2] = hh;
+          }
+        }
+        __syncthreads();
+        const uint32_t dsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pick[0]);
+        const uint32_t below = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pick[1]);
+        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pick[2]);
+        k -= below;
+        lo += (uint64_t)dsel << shift;
+        range = shift ? ((1ull << shift) - 1ull) : 0ull;
+      }
+      uint64_t V = lo;                       // range == 0: `count` copies of lo
+      if (range != 0ull) {                   // a single key inside a wider bin: fetch it
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint64_t d = key[j] - lo;
+          if (key[j] >= lo && d <= range) s_key = key[j];
+        }
+        __syncthreads();
+        V = s_key;
+      }
+      const uint32_t c_le = (k_lo - k) + count;   // keys <= V
+      uint64_t V2 = V;
+      if (k_hi != k_lo && k_hi >= c_le) {
+        // even count and the upper middle is the next distinct key: smallest key above V
+        uint64_t mn = ~0ull;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) mn = (key[j] > V && key[j] < mn) ? key[j] : mn;
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mn, off, 64);
+          mn = o < mn ? o : mn;
+        }
+        __syncthreads();            // every wave is done reading s_mn of the min/max step
+        if (lane == 0) s_mn[wave] = mn;
+        __syncthreads();
+        V2 = ~0ull;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) V2 = s_mn[w] < V2 ? s_mn[w] : V2;
+      }
+      r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
+    }
+    if (tid == 0) med[c] = r;
+    __syncthreads();   // s_mn / s_mx / s_cnt / s_key are rewritten by the next column
+  }
+}
+
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags) {
   if (count == 0) return PLAIDHIP_OK;
   int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
@@ -629,15 +768,29 @@ static void launch_bits(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t
                      m, n, ignore_zero, flags, med);
 }
 
+template <int BLOCK, int ITEMS>
+static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
+                         int ignore_zero, const uint32_t* flags, double* med) {
+  const int cap = ctx->num_cu * (2048 / BLOCK) * 4;
+  const int grid = n < cap ? n : cap;
+  hipLaunchKernelGGL((col_medians_radix_kernel<BLOCK, ITEMS>), dim3(grid), dim3(BLOCK), 0, ctx->stream, S, lds,
+                     m, n, ignore_zero, flags, med);
+}
+
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                        int ignore_zero, const uint32_t* flags, double* med) {
   if (n == 0) return PLAIDHIP_OK;
   static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");   // tools/: "sort" | "select" | unset
   const bool want_sort = force && force[0] == 's' && force[1] == 'o';
   const bool want_select = force && force[0] == 's' && force[1] == 'e';
-  const bool want_bits = (force && force[0] == 'b') || (!force && m <= 16384);
+  const bool want_bits = force && force[0] == 'b';
+  const bool want_radix = (force && force[0] == 'r') || (!force && m <= 16384);
   const bool want_sample = (force && force[0] == 's' && force[1] == 'a') || (!force && m > 16384);
-  if (want_sample) {
+  if (want_radix && m <= 16384) {
+    if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 6144) launch_radix<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else launch_radix<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
+  } else if (want_sample) {
     // measured on MI355X: the bitwise register kernel wins up to ~16k sets per column (0.57 vs
     // 0.78 ms at m = 5k), the sample-bracket kernel beyond (m = 50k: 2.5 vs 5.0 ms per 4,096 columns)
     // sample-bracket selection: BLOCK 512 up to 16k sets, 1024 beyond; the sample grows with m so
