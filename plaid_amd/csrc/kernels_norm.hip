@@ -749,6 +749,238 @@ col_medians_radix_kernel(const double* __restrict__ S, int64_t lds, int32_t m, i
   }
 }
 
+
+// Any m: ONE WAVEFRONT per column, no workgroup barriers.  The column is swept three or four
+// times (the first sweep from HBM, the others from L2): min/max of the keys; a 256-bin histogram
+// over the current key range (repeated on the bin that holds the wanted rank while that bin has
+// more than CAP keys); a collect sweep that compacts the keys of the bin into LDS, where the
+// wavefront sorts them (bitonic) and reads the middle key(s) off.  Every wavefront works on its
+// own column with its own 1 KiB histogram and CAP-key list, so a CU keeps 16+ columns in flight
+// and nothing waits for another wavefront; the register-resident kernels above spend most of
+// their time in workgroup barriers once m grows.
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wavefront are executed in order; only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+// key of one value as two dwords (same order as masked_key), masked entries -> {~0, ~0}
+struct Key32 { uint32_t hi, lo; };
+__device__ __forceinline__ Key32 masked_key32(double v, int ignore_zero) {
+  const double c = v + 0.0;                                    // -0 -> +0
+  const uint32_t h = (uint32_t)__double2hiint(c), l = (uint32_t)__double2loint(c);
+  const uint32_t sgn = (uint32_t)((int32_t)h >> 31);           // 0 / ~0
+  Key32 k{h ^ (sgn | 0x80000000u), l ^ sgn};
+  const bool masked = (v != v) | ((ignore_zero != 0) & (v == 0.0));
+  if (masked) { k.hi = 0xffffffffu; k.lo = 0xffffffffu; }
+  return k;
+}
+
+// One wavefront visits every key of a column: f(key) is called by ALL lanes together (masked or
+// out-of-range entries carry the all-ones key), 16-byte loads, 8 KiB per wavefront in flight.
+template <typename F>
+__device__ __forceinline__ void sweep_column(const double* __restrict__ sc, int32_t m, int ignore_zero, int lane, F&& f) {
+  constexpr int UN = 8;
+  const int head = (int)((reinterpret_cast<uintptr_t>(sc) >> 3) & 1u);   // first element not 16-byte aligned
+  const int npairs = (m - head) >> 1;
+  const int tail = (m - head) & 1;
+  {
+    Key32 k{0xffffffffu, 0xffffffffu};
+    if (lane == 0 && head) k = masked_key32(sc[0], ignore_zero);
+    if (lane == 1 && tail) k = masked_key32(sc[m - 1], ignore_zero);
+    f(k);
+  }
+  const f64x2_t* __restrict__ p = reinterpret_cast<const f64x2_t*>(sc + head);
+  for (int base = 0; base < npairs; base += 64 * UN) {
+    f64x2_t v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = base + u * 64 + lane;
+      v[u] = p[i < npairs ? i : npairs - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = base + u * 64 + lane < npairs;
+      Key32 a = masked_key32(v[u].x, ignore_zero), b = masked_key32(v[u].y, ignore_zero);
+      if (!ok) { a.hi = a.lo = b.hi = b.lo = 0xffffffffu; }
+      f(a);
+      f(b);
+    }
+  }
+}
+
+// The search interval is [lo, lo + 2^B - 1]; a key K lies inside iff K - lo does not borrow and
+// (K - lo) >> B == 0.  Its bin is (K - lo) >> shift, shift = max(B - 8, 0).  Everything per key is
+// 32-bit arithmetic (64-bit integer compares and shifts run at a quarter of that rate).
+struct RangeTest {
+  uint32_t lohi, lolo;
+  int shift;        // bin = d >> shift
+  uint32_t nbins;   // 1 << (B - shift) <= 256
+  // returns the bin, or 0xffffffff when the key is outside the interval
+  __device__ __forceinline__ uint32_t bin(const Key32& k) const {
+    const uint32_t dlo = k.lo - lolo;
+    const uint32_t borrow = k.lo < lolo ? 1u : 0u;
+    const uint32_t dhi = k.hi - lohi - borrow;
+    const bool under = (k.hi < lohi) | ((k.hi == lohi) & (borrow != 0u));
+    uint32_t b;
+    bool hi_ok = true;
+    if (shift >= 32) {
+      b = dhi >> (shift - 32);
+    } else {
+      b = shift ? __builtin_amdgcn_alignbit(dhi, dlo, (uint32_t)shift) : dlo;
+      hi_ok = (dhi >> shift) == 0u;   // shift == 0: dhi must be 0
+    }
+    const bool valid = k.hi != 0xffffffffu;   // masked entries (no valid key has an all-ones high word)
+    return (valid && !under && hi_ok && b < nbins) ? b : 0xffffffffu;
+  }
+};
+
+template <int CAP>
+__global__ void __launch_bounds__(256)
+col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                          int ignore_zero_mode, const uint32_t* __restrict__ flags,
+                          double* __restrict__ med) {
+  __shared__ __align__(16) uint32_t s_hist[4][256];
+  __shared__ unsigned long long s_list[4][CAP];
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* hist = s_hist[wave];
+  unsigned long long* list = s_list[wave];
+  *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+  wave_lds_sync();
+
+  const int nwaves = gridDim.x * 4;
+  for (int c = blockIdx.x * 4 + wave; c < n; c += nwaves) {
+    const double* sc = S + (int64_t)c * lds;
+    // ---- sweep 0: range of the keys' high words and the number of unmasked entries ---------
+    uint32_t hmin = 0xffffffffu, hmax = 0u, cnt = 0;
+    sweep_column(sc, m, ignore_zero, lane, [&](const Key32& k) {
+      const bool valid = k.hi != 0xffffffffu;      // no valid key has an all-ones high word
+      cnt += valid ? 1u : 0u;
+      hmin = k.hi < hmin ? k.hi : hmin;            // (a masked key never lowers the minimum)
+      hmax = (valid && k.hi > hmax) ? k.hi : hmax;
+    });
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t a = __shfl_xor(hmin, off, 64), b = __shfl_xor(hmax, off, 64);
+      hmin = a < hmin ? a : hmin;
+      hmax = b > hmax ? b : hmax;
+      cnt += __shfl_xor(cnt, off, 64);
+    }
+    cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+    hmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmin);
+    hmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmax);
+    double r;
+    if (cnt == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+      const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
+      uint64_t lo = (uint64_t)hmin << 32;
+      int B = 32 + (hmax == hmin ? 0 : 32 - __clz((int)(hmax - hmin)));   // interval [lo, lo + 2^B - 1] holds every key
+      uint32_t k = k_lo;       // rank wanted inside the interval
+      uint32_t count = cnt;    // keys inside the interval
+      // ---- histogram sweeps until the interval fits the list ------------------------------
+      while (B != 0 && count > (uint32_t)CAP) {
+        RangeTest rt;
+        rt.lohi = (uint32_t)(lo >> 32);
+        rt.lolo = (uint32_t)lo;
+        rt.shift = B > 8 ? B - 8 : 0;
+        rt.nbins = 1u << (B - rt.shift);
+        sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
+          const uint32_t b = rt.bin(key);
+          if (b != 0xffffffffu) atomicAdd(&hist[b], 1u);
+        });
+        wave_lds_sync();
+        const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
+        *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
+        const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
+        }
+        uint32_t excl = incl - mine;
+        const bool owner = mine != 0 && excl <= k && k < incl;
+        uint32_t d = 0, hh = h4.x;
+        if (k >= excl + h4.x) { excl += h4.x; d = 1; hh = h4.y;
+          if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
+            if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
+        const int src = (int)__builtin_ctzll(__ballot(owner));   // exactly one lane owns the wanted rank
+        const uint32_t dsel = (uint32_t)__shfl((int)((uint32_t)lane * 4u + d), src, 64);
+        const uint32_t below = (uint32_t)__shfl((int)excl, src, 64);
+        count = (uint32_t)__shfl((int)hh, src, 64);
+        k -= below;
+        lo += (uint64_t)dsel << rt.shift;
+        B = rt.shift;
+      }
+      uint64_t V = lo, V2 = lo;
+      bool need_above = false;
+      if (B != 0) {
+        // ---- collect sweep: keys of the interval -> LDS ------------------------------------
+        RangeTest rt;
+        rt.lohi = (uint32_t)(lo >> 32);
+        rt.lolo = (uint32_t)lo;
+        rt.shift = B > 8 ? B - 8 : 0;
+        rt.nbins = 1u << (B - rt.shift);
+        uint32_t base = 0;
+        sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
+          const bool in = rt.bin(key) != 0xffffffffu;
+          const unsigned long long bal = __ballot(in);
+          if (in) {
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (pos < (uint32_t)CAP) list[pos] = ((unsigned long long)key.hi << 32) | key.lo;
+          }
+          base += (uint32_t)__popcll(bal);
+        });
+        // ---- sort the list (count <= CAP keys, padded with all-ones to a power of two) ------
+        uint32_t N = 2;
+        while (N < count) N <<= 1;
+        for (uint32_t i = count + lane; i < N; i += 64) list[i] = ~0ull;
+        wave_lds_sync();
+        for (uint32_t kk = 2; kk <= N; kk <<= 1)
+          for (uint32_t j = kk >> 1; j >= 1; j >>= 1) {
+            for (uint32_t t = lane; t < (N >> 1); t += 64) {
+              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
+              const uint32_t p = i | j;
+              const bool up = (i & kk) == 0;
+              const unsigned long long x = list[i], y = list[p];
+              if ((x > y) == up) { list[i] = y; list[p] = x; }
+            }
+            wave_lds_sync();
+          }
+        V = list[k];
+        V2 = V;
+        if (k_hi != k_lo) {
+          if (k + 1 < count) V2 = list[k + 1];
+          else need_above = true;
+        }
+        wave_lds_sync();   // the list is refilled by the next column
+      } else {
+        // `count` copies of the key lo; the upper middle is another copy or the next larger key
+        const uint32_t c_le = (k_lo - k) + count;
+        need_above = k_hi != k_lo && k_hi >= c_le;
+      }
+      if (need_above) {   // rare: the upper middle key is the smallest key above V (one more sweep)
+        uint64_t above = ~0ull;
+        sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
+          const uint64_t kk = ((uint64_t)key.hi << 32) | key.lo;
+          above = (kk > V && key.hi != 0xffffffffu && kk < above) ? kk : above;
+        });
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)above, off, 64);
+          above = o < above ? o : above;
+        }
+        V2 = above;
+      }
+      r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
+    }
+    if (lane == 0) med[c] = r;
+  }
+}
+
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags) {
   if (count == 0) return PLAIDHIP_OK;
   int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
@@ -785,8 +1017,14 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   const bool want_select = force && force[0] == 's' && force[1] == 'e';
   const bool want_bits = force && force[0] == 'b';
   const bool want_radix = (force && force[0] == 'r') || (!force && m <= 16384);
-  const bool want_sample = (force && force[0] == 's' && force[1] == 'a') || (!force && m > 16384);
-  if (want_radix && m <= 16384) {
+  const bool want_sample = force && force[0] == 's' && force[1] == 'a';
+  const bool want_stream = (force && force[0] == 's' && force[1] == 't') || (!force && m > 16384);
+  if (want_stream) {
+    const int cap = ctx->num_cu * 8;                      // 8 workgroups x 4 wavefronts per CU
+    const int need = (n + 3) / 4;
+    hipLaunchKernelGGL((col_medians_stream_kernel<1024>), dim3(need < cap ? need : cap), dim3(256), 0, ctx->stream, S,
+                       lds, m, n, ignore_zero, flags, med);
+  } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 6144) launch_radix<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_radix<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
