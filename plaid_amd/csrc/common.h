@@ -23,6 +23,8 @@ constexpr int kMaxLdsKeys = kLdsBytes / 8;               // 20480
 constexpr int kPadSlotsPair = 16;
 constexpr int kMaxLdsGenesPair = kLdsBytes / 16 - kPadSlotsPair;   // 10224
 constexpr int kMaxPairSlices = 8;
+// scatter kernel (sparse X): fp64 accumulators of one chunk of gene sets in LDS
+constexpr int kScatterChunk = 20480;   // 160 KiB / 8
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -107,6 +109,20 @@ struct plaidhip_pair_plan {
   double* d_meta_k = nullptr;
 };
 
+// Scatter plan (sparse X): G transposed, gene-major.  The sets are cut into chunks of `ch` (the
+// LDS accumulators of one chunk); the sets of gene i inside chunk c are stored as whole segments
+// of 64 u16 ids relative to the chunk start (0xffff = padding): segments seg[c*g + i] ..
+// seg[c*g + i + 1] - 1 of d_ids.  (seg has nch*g + 1 entries, chunk-major, so the ranges of
+// consecutive (chunk, gene) pairs are contiguous.)
+struct plaidhip_scatter_plan {
+  int32_t ch = 0, nch = 0;
+  int64_t nseg = 0;
+  int32_t* d_seg = nullptr;
+  uint16_t* d_ids = nullptr;
+  double* d_w = nullptr;   // per set 1/(1e-8 + size)
+  double* d_k = nullptr;   // per set size
+};
+
 struct plaidhip_geneset {
   plaidhip_ctx* ctx = nullptr;
   int32_t g = 0, m = 0;
@@ -115,6 +131,7 @@ struct plaidhip_geneset {
   int64_t chunks = 0;          // total over slices
   std::vector<plaidhip_slice> slices;   // the column is consumed slice by slice when g > kMaxLdsGenes
   plaidhip_pair_plan pair;              // dense-X kernel: two columns per pass
+  plaidhip_scatter_plan scatter;        // sparse-X kernel: nonzeros are scattered into per-set LDS accumulators
   bool rows_in_order = false;           // the sets came sorted by decreasing size: a tile's lanes are neighbouring rows of S
 };
 
@@ -135,6 +152,10 @@ int spmm_block_for_genes(int32_t g);   // workgroup size of the column-resident 
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags);
+int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
+                                const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
+                                const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                                bool auto_select);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);

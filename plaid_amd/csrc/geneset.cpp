@@ -608,6 +608,35 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
+  if (m > 0) {
+    // scatter plan (sparse X): gene-major membership in 64-id segments per (chunk of sets, gene)
+    plaidhip_scatter_plan& sp = gs->scatter;
+    sp.ch = std::min<int32_t>(m, kScatterChunk);
+    sp.nch = (m + sp.ch - 1) / sp.ch;
+    std::vector<int32_t> cnt((size_t)sp.nch * g, 0);
+    for (int32_t j = 0; j < m; ++j)
+      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) ++cnt[(size_t)(j / sp.ch) * g + Gi[p]];
+    std::vector<int32_t> seg((size_t)sp.nch * g + 1, 0);
+    for (size_t i = 0; i < cnt.size(); ++i) seg[i + 1] = seg[i] + (cnt[i] + 63) / 64;
+    sp.nseg = seg.back();
+    std::vector<uint16_t> ids(((size_t)sp.nseg + 1) * 64, (uint16_t)0xffffu);   // + one all-padding segment (index nseg)
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int32_t j = 0; j < m; ++j)      // increasing j: ids inside a segment list are sorted
+      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
+        const size_t cell = (size_t)(j / sp.ch) * g + Gi[p];
+        ids[(size_t)seg[cell] * 64 + cnt[cell]++] = (uint16_t)(j % sp.ch);
+      }
+    std::vector<double> w(m), k(m);
+    for (int32_t j = 0; j < m; ++j) {
+      k[j] = (double)(Gp[j + 1] - Gp[j]);
+      w[j] = 1.0 / (1e-8 + k[j]);   // R/plaid.R:75-76
+    }
+    if ((rc = upload(ctx, seg, &sp.d_seg)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, ids, &sp.d_ids)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, w, &sp.d_w)) != PLAIDHIP_OK) goto fail;
+    if ((rc = upload(ctx, k, &sp.d_k)) != PLAIDHIP_OK) goto fail;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
+  }
   *out = gs;
   return PLAIDHIP_OK;
 fail:
@@ -630,6 +659,10 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   hipFree(gs->pair.d_meta_j);
   hipFree(gs->pair.d_meta_w);
   hipFree(gs->pair.d_meta_k);
+  hipFree(gs->scatter.d_seg);
+  hipFree(gs->scatter.d_ids);
+  hipFree(gs->scatter.d_w);
+  hipFree(gs->scatter.d_k);
   hipFree(gs->pair.d_slices);
   hipFree(gs->pair.d_partial);
   for (plaidhip_pair_slice& d : gs->pair.slices) {

@@ -352,6 +352,10 @@ spmm_colgather_f64(SpmmArgs a) {
 struct SpmmPairArgs {
   const double* X;
   int64_t ldx;
+  int64_t sparse_cells;   // CSC X, auto mode: return at once if 8 * nnz(X) < g * n (the scatter kernel takes it); 0 = always run
+  const int32_t* Xp;   // CSC X (dgCMatrix slots) instead of dense X
+  const int32_t* Xi;
+  const double* Xx;
   int32_t n, npairs, nslices, ktiles;
   int32_t nt_store;  // see SpmmArgs
   const plaidhip_pair_slice_dev* slices;
@@ -385,10 +389,13 @@ __device__ __forceinline__ f64x2 lds_pair_at(uint32_t byte_off) {
   return *reinterpret_cast<lds_cf64x2*>(static_cast<uintptr_t>(byte_off));
 }
 
-template <bool STAMP, int ABL = 0>
+template <bool STAMP, int ABL = 0, bool CSC_X = false>
 __global__ void __launch_bounds__(1024)
 spmm_colpair_f64(SpmmPairArgs a) {
   constexpr int BLOCK = 1024;
+  if constexpr (CSC_X) {
+    if (a.sparse_cells != 0 && (int64_t)a.Xp[a.n] * 8 < a.sparse_cells) return;
+  }
   unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
   if constexpr (STAMP) t_all0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -441,7 +448,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
   }
 
   int p = blockIdx.x;
-  if (p < a.npairs) PLAIDHIP_PREFETCH(p, 0);
+  if (!CSC_X && p < a.npairs) PLAIDHIP_PREFETCH(p, 0);
   const char* part = reinterpret_cast<const char*>(a.partial + (size_t)blockIdx.x * (size_t)(a.ktiles + 1) * 64);  // uniform
 
   for (; p < a.npairs; p += gridDim.x) {
@@ -456,19 +463,41 @@ spmm_colpair_f64(SpmmPairArgs a) {
       if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
       int tid_o = tid;
       asm volatile("" : "+v"(tid_o));
-      // ---- stage the slice of both columns, interleaved -----------------------------------
-      PLAIDHIP_ST_ONE(0, p0, p5) PLAIDHIP_ST_ONE(1, p1, p6) PLAIDHIP_ST_ONE(2, p2, p7)
-      PLAIDHIP_ST_ONE(3, p3, p8) PLAIDHIP_ST_ONE(4, p4, p9)
-      if ((gs_ & 1) && tid == 0) {
-        const int64_t gl = (int64_t)sl->g0 + gs_ - 1;
-        ent[gs_ - 1] = f64x2{a.X[(int64_t)cA * a.ldx + gl], a.X[(int64_t)cB * a.ldx + gl]};
+      if constexpr (!CSC_X) {
+        // ---- stage the slice of both columns, interleaved ---------------------------------
+        PLAIDHIP_ST_ONE(0, p0, p5) PLAIDHIP_ST_ONE(1, p1, p6) PLAIDHIP_ST_ONE(2, p2, p7)
+        PLAIDHIP_ST_ONE(3, p3, p8) PLAIDHIP_ST_ONE(4, p4, p9)
+        if ((gs_ & 1) && tid == 0) {
+          const int64_t gl = (int64_t)sl->g0 + gs_ - 1;
+          ent[gs_ - 1] = f64x2{a.X[(int64_t)cA * a.ldx + gl], a.X[(int64_t)cB * a.ldx + gl]};
+        }
+        if (tid < kPadSlotsPair) ent[gs_ + tid] = f64x2{0.0, 0.0};
+      } else {
+        // ---- sparse columns: zero the slice, then scatter the stored values of both columns ----
+        for (int i = tid_o; i < gs_ + kPadSlotsPair; i += BLOCK) ent[i] = f64x2{0.0, 0.0};
+        __syncthreads();
+        double* entd = reinterpret_cast<double*>(ent);
+        const int g0_ = sl->g0;
+        {
+          const int q0 = a.Xp[cA], q1 = a.Xp[cA + 1];
+          for (int q = q0 + tid_o; q < q1; q += BLOCK) {
+            const int r = a.Xi[q] - g0_;
+            if (r >= 0 && r < gs_) entd[2 * r] = a.Xx[q];
+          }
+        }
+        if (hasB) {
+          const int q0 = a.Xp[cB], q1 = a.Xp[cB + 1];
+          for (int q = q0 + tid_o; q < q1; q += BLOCK) {
+            const int r = a.Xi[q] - g0_;
+            if (r >= 0 && r < gs_) entd[2 * r + 1] = a.Xx[q];
+          }
+        }
       }
-      if (tid < kPadSlotsPair) ent[gs_ + tid] = f64x2{0.0, 0.0};
       __syncthreads();
       if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
       int nsi = si + 1, np = p;
       if (nsi == ns) { nsi = 0; np = p + gridDim.x; }
-      const bool want_pf = np < a.npairs;
+      const bool want_pf = !CSC_X && np < a.npairs;
       const bool first = si == 0, last = si == ns - 1;
       const gptr_i32 wco = (gptr_i32)sl->wave_chunk_off;
       const int ch_begin = __builtin_amdgcn_readfirstlane(wco[wave]);
@@ -621,6 +650,179 @@ spmm_colpair_f64(SpmmPairArgs a) {
 #undef PLAIDHIP_ST_ONE
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Scatter kernel (sparse X, dgCMatrix): work proportional to the stored values.  A workgroup owns
+// one sample column; the scores of a chunk of gene sets (<= 20,480) are fp64 accumulators in LDS.
+// Every stored value x[i, c] is added to the accumulators of the sets that contain gene i
+// (ds_add_f64; G is stored gene-major in 64-id segments, geneset.cpp), then the chunk is scaled
+// and written out coalesced.  A wavefront loads 64 stored values at once (row, value, segment
+// range per lane) and walks them four at a time with two 128-byte id segments per value in
+// flight.  At 5 % density this is ~20x fewer LDS operations than gathering every membership.
+// Sums are accumulated in arrival order, so the last bits differ from run to run (fp64, ~1e-16).
+struct ScatterArgs {
+  const int32_t* Xp;
+  const int32_t* Xi;
+  const double* Xx;
+  int32_t n, m, g, ch, nch;
+  int64_t dense_cells;      // auto mode: run only if 8 * nnz(X) < g * n (0 = always run)
+  const int32_t* seg;
+  const uint16_t* ids;
+  int32_t dummy_seg;
+  const double* w;
+  const double* k;
+  int32_t stat, nt_store;
+  double alpha, beta;
+  const double* alpha_div;
+  double* S;
+  int64_t lds;
+  uint32_t* flags;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(1024)
+spmm_scatter_csc_f64(ScatterArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* acc = reinterpret_cast<double*>(smem_raw);
+  if (a.dense_cells != 0 && (int64_t)a.Xp[a.n] * 8 >= a.dense_cells) return;   // the gather kernel takes this input
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t f = 0;
+  const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
+  const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
+  for (int i = tid; i < a.ch; i += 1024) acc[i] = 0.0;
+  __syncthreads();
+
+  for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
+    const int q0 = a.Xp[c], q1 = a.Xp[c + 1];
+    for (int chunk = 0; chunk < a.nch; ++chunk) {
+      const int j0 = chunk * a.ch;
+      const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
+      const int32_t* segc = a.seg + (int64_t)chunk * a.g;
+      for (int qb = q0 + wave * 64; qb < q1; qb += 16 * 64) {
+        const int my = qb + lane;
+        const bool have = my < q1;
+        const int gene = have ? a.Xi[my] : 0;
+        const double v = have ? a.Xx[my] : 0.0;
+        const int s0 = have ? segc[gene] : 0;
+        const int s1 = have ? segc[gene + 1] : 0;
+        const int nb = (q1 - qb) < 64 ? (q1 - qb) : 64;
+        constexpr int UN = 8;   // stored values per step: 16 id segments (2 KiB) in flight per wavefront
+        for (int k = 0; k < nb; k += UN) {
+          int b0[UN], b1[UN];
+          double vv[UN];
+          uint32_t ia[UN], ib[UN];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const int kk = (k + u < nb) ? k + u : k;          // (a repeated value gets an empty range below)
+            b0[u] = __builtin_amdgcn_readlane(s0, kk);
+            b1[u] = (k + u < nb) ? __builtin_amdgcn_readlane(s1, kk) : b0[u];
+            vv[u] = readlane_f64(v, kk);
+            const int sa = b0[u] < b1[u] ? b0[u] : a.dummy_seg;
+            const int sb = b0[u] + 1 < b1[u] ? b0[u] + 1 : a.dummy_seg;
+            ia[u] = a.ids[(int64_t)sa * 64 + lane];
+            ib[u] = a.ids[(int64_t)sb * 64 + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            if (ia[u] != 0xffffu) atomicAdd(&acc[ia[u]], vv[u]);
+            if (ib[u] != 0xffffu) atomicAdd(&acc[ib[u]], vv[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u)
+            for (int s = b0[u] + 2; s < b1[u]; ++s) {          // genes in more than 128 sets of the chunk
+              const uint32_t id = a.ids[(int64_t)s * 64 + lane];
+              if (id != 0xffffu) atomicAdd(&acc[id], vv[u]);
+            }
+        }
+      }
+      __syncthreads();
+      for (int i0 = tid; i0 < nj; i0 += 4 * 1024) {
+        // four sets per thread and step: the per-set scale factors are loaded before any is used
+        double kj[4], wj[4], sum[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 1024;
+          const int j = j0 + (i < nj ? i : nj - 1);
+          kj[u] = a.k[j];
+          wj[u] = is_mean ? a.w[j] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 1024;
+          if (i < nj) { sum[u] = acc[i]; acc[i] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 1024;
+          if (i < nj) {
+            const double val = alpha * (sum[u] * wj[u]) + a.beta * (kj[u] * wj[u]);
+            __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);
+            f |= (val < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;
+            f |= (val == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;
+            f |= (val != val) ? PLAIDHIP_FLAG_HAS_NAN : 0u;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  publish_flags(f, a.flags);
+}
+
+// how a sparse X is multiplied: PLAIDHIP_SPMM_SPARSE = scatter | gather | auto (default: decided on
+// the device from nnz(X): scatter below 12.5 % stored values)
+static int sparse_mode() {
+  const char* e = getenv("PLAIDHIP_SPMM_SPARSE");
+  if (e == nullptr) return 0;
+  return strcmp(e, "scatter") == 0 ? 1 : (strcmp(e, "gather") == 0 ? 2 : 0);
+}
+
+int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
+                                const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
+                                const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                                bool auto_select) {
+  const plaidhip_scatter_plan& sp = gs->scatter;
+  ScatterArgs a{};
+  a.Xp = Xp;
+  a.Xi = Xi;
+  a.Xx = Xx;
+  a.n = n;
+  a.m = gs->m;
+  a.g = gs->g;
+  a.ch = sp.ch;
+  a.nch = sp.nch;
+  a.dense_cells = auto_select ? (int64_t)gs->g * n : 0;
+  a.seg = sp.d_seg;
+  a.ids = sp.d_ids;
+  a.dummy_seg = (int32_t)sp.nseg;
+  a.w = sp.d_w;
+  a.k = sp.d_k;
+  a.stat = stat;
+  a.alpha = alpha;
+  a.beta = beta;
+  a.alpha_div = alpha_div;
+  a.S = S;
+  a.lds = lds;
+  a.flags = flags;
+  const size_t smem = (size_t)sp.ch * sizeof(double);
+  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64));
+  int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int grid = ctx->num_cu * per_cu;
+  if (grid > n) grid = n;
+  hipLaunchKernelGGL(spmm_scatter_csc_f64, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 
@@ -636,9 +838,10 @@ static int pair_kernel_mode() {   // read per launch (tests flip it): 0 single, 
   return strcmp(e, "single") == 0 ? 0 : (strcmp(e, "pair") == 0 ? 2 : 1);
 }
 
-static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n,
+static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx,
+                          const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t n,
                           int stat, double alpha, const double* alpha_div, double beta, double* S, int64_t lds,
-                          uint32_t* flags) {
+                          uint32_t* flags, bool auto_select = false) {
   const plaidhip_pair_plan& pl = gs->pair;
   int32_t gmax = 0;
   for (const plaidhip_pair_slice& sl : pl.slices) gmax = sl.gs > gmax ? sl.gs : gmax;
@@ -647,6 +850,10 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   SpmmPairArgs a{};
   a.X = X;
   a.ldx = ldx;
+  a.Xp = Xp;
+  a.Xi = Xi;
+  a.Xx = Xx;
+  a.sparse_cells = auto_select ? (int64_t)gs->g * n : 0;
   a.n = n;
   a.npairs = (n + 1) / 2;
   a.nslices = (int32_t)pl.slices.size();
@@ -671,7 +878,10 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   int grid = ctx->num_cu * per_cu;
   if (a.nslices > 1 && grid > pl.partial_wgs) grid = pl.partial_wgs;
   if (grid > a.npairs) grid = a.npairs;
-  if (g_ablate == 2) {   // no index loads (tools/ only, wrong scores)
+  if (Xp != nullptr) {   // sparse X
+    PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, true>));
+    hipLaunchKernelGGL((spmm_colpair_f64<false, 0, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (g_ablate == 2) {   // no index loads (tools/ only, wrong scores)
     a.dbg = g_dbg;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
@@ -783,7 +993,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     const bool aligned = (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6;
     if (diag && mode != 0 && aligned && !gs->pair.slices.empty())
-      return launch_colpair(ctx, gs, X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags);
+      return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags);
   }
   SpmmArgs a{};
   a.X = X;
@@ -796,6 +1006,16 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
+  if (g_ablate == 0 && pair_kernel_mode() != 0 && !gs->pair.slices.empty()) {
+    // sparse-aware scatter or dense-work gather: both are enqueued in auto mode and the one that does
+    // not apply returns at once (nnz(X) is only known on the device in a stream-ordered pipeline)
+    const int sm = sparse_mode();
+    if (sm != 2) {
+      const int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);
+      if (rc != PLAIDHIP_OK || sm == 1) return rc;
+    }
+    return launch_colpair(ctx, gs, nullptr, 0, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);
+  }
   SpmmArgs a{};
   a.Xp = Xp;
   a.Xi = Xi;

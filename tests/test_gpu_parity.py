@@ -176,6 +176,34 @@ def test_spmm_both_dense_kernels(hip_ctx, monkeypatch, kernel, g, n, m):
     close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", False), _oracle().plaid(X, rn, G, rn, normalize=False))
     close(hip_ctx.plaid_dense(X, Gp, Gi, "sum", True), _oracle().plaid(X, rn, G, rn, stats="sum"))
     close(hip_ctx.sing_dense(X, Gp, Gi), _oracle().replaid_sing(X, rn, G, rn))       # alpha/beta epilogue
+    Xz = X.copy()
+    Xz[np.random.default_rng(g).random(X.shape) < 0.9] = 0.0                           # sparse X, same kernels
+    Xs = sp.csc_matrix(Xz)
+    close(hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", False),
+          _oracle().plaid(Xs, rn, G, rn, normalize=False))
+
+
+@pytest.mark.parametrize("mode", ["scatter", "gather", "auto"])
+@pytest.mark.parametrize("g,n,m,dens", [(500, 3, 40, 0.05), (20000, 9, 700, 0.05), (20000, 5, 24000, 0.03),
+                                        (30001, 4, 300, 0.3), (64, 2, 5, 1.0)])
+def test_spmm_sparse_x_scatter_and_gather(hip_ctx, monkeypatch, mode, g, n, m, dens):
+    """dgCMatrix X: the scatter kernel (work ~ stored values; 1-2 chunks of LDS accumulators), the gather kernel
+    and the on-device choice between them all give the oracle's scores, incl. empty columns and the epilogues"""
+    from plaid_amd import synth as sy
+    monkeypatch.setenv("PLAIDHIP_SPMM_SPARSE", mode)
+    Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(g, 300), sort_by_size=False)
+    rng = np.random.default_rng(g + m)
+    X = np.where(rng.random((g, n)) < dens, np.round(rng.gamma(2.0, 1.0, size=(g, n)), 1), 0.0)
+    X[:, n - 1] = 0.0                                           # a sample without stored values
+    Xs = sp.csc_matrix(X)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", False),
+          _oracle().plaid(Xs, rn, G, rn, normalize=False))
+    close(hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "sum", True),
+          _oracle().plaid(Xs, rn, G, rn, stats="sum"))
+    close(hip_ctx.ssgsea_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, 0.25),
+          _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
 
 
 @pytest.mark.parametrize("g,n", [(10001, 5), (20001, 3), (333, 2)])
