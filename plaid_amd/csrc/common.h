@@ -111,7 +111,7 @@ struct plaidhip_pair_plan {
 
 // Scatter plan (sparse X): G transposed, gene-major.  The sets are cut into chunks of `ch` (the
 // LDS accumulators of one chunk); the sets of gene i inside chunk c are stored as whole segments
-// of 64 u16 ids relative to the chunk start (0xffff = padding): segments seg[c*g + i] ..
+// of 128 u16 ids (a dword = two ids per lane) relative to the chunk start (0xffff = padding): segments seg[c*g + i] ..
 // seg[c*g + i + 1] - 1 of d_ids.  (seg has nch*g + 1 entries, chunk-major, so the ranges of
 // consecutive (chunk, gene) pairs are contiguous.)
 struct plaidhip_scatter_plan {

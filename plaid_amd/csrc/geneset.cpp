@@ -609,7 +609,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
   if (m > 0) {
-    // scatter plan (sparse X): gene-major membership in 64-id segments per (chunk of sets, gene)
+    // scatter plan (sparse X): gene-major membership in 128-id segments (one dword = 2 ids per lane) per (chunk of sets, gene)
     plaidhip_scatter_plan& sp = gs->scatter;
     sp.ch = std::min<int32_t>(m, kScatterChunk);
     sp.nch = (m + sp.ch - 1) / sp.ch;
@@ -617,14 +617,14 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     for (int32_t j = 0; j < m; ++j)
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) ++cnt[(size_t)(j / sp.ch) * g + Gi[p]];
     std::vector<int32_t> seg((size_t)sp.nch * g + 1, 0);
-    for (size_t i = 0; i < cnt.size(); ++i) seg[i + 1] = seg[i] + (cnt[i] + 63) / 64;
+    for (size_t i = 0; i < cnt.size(); ++i) seg[i + 1] = seg[i] + (cnt[i] + 127) / 128;
     sp.nseg = seg.back();
-    std::vector<uint16_t> ids(((size_t)sp.nseg + 1) * 64, (uint16_t)0xffffu);   // + one all-padding segment (index nseg)
+    std::vector<uint16_t> ids(((size_t)sp.nseg + 1) * 128, (uint16_t)0xffffu);   // + one all-padding segment (index nseg)
     std::fill(cnt.begin(), cnt.end(), 0);
     for (int32_t j = 0; j < m; ++j)      // increasing j: ids inside a segment list are sorted
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
         const size_t cell = (size_t)(j / sp.ch) * g + Gi[p];
-        ids[(size_t)seg[cell] * 64 + cnt[cell]++] = (uint16_t)(j % sp.ch);
+        ids[(size_t)seg[cell] * 128 + cnt[cell]++] = (uint16_t)(j % sp.ch);
       }
     std::vector<double> w(m), k(m);
     for (int32_t j = 0; j < m; ++j) {

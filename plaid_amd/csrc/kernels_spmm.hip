@@ -655,9 +655,9 @@ spmm_colpair_f64(SpmmPairArgs a) {
 // Scatter kernel (sparse X, dgCMatrix): work proportional to the stored values.  A workgroup owns
 // one sample column; the scores of a chunk of gene sets (<= 20,480) are fp64 accumulators in LDS.
 // Every stored value x[i, c] is added to the accumulators of the sets that contain gene i
-// (ds_add_f64; G is stored gene-major in 64-id segments, geneset.cpp), then the chunk is scaled
+// (ds_add_f64; G is stored gene-major in 128-id segments, geneset.cpp), then the chunk is scaled
 // and written out coalesced.  A wavefront loads 64 stored values at once (row, value, segment
-// range per lane) and walks them four at a time with two 128-byte id segments per value in
+// range per lane) and walks them eight at a time with two 256-byte id segments per value in
 // flight.  At 5 % density this is ~20x fewer LDS operations than gathering every membership.
 // Sums are accumulated in arrival order, so the last bits differ from run to run (fp64, ~1e-16).
 struct ScatterArgs {
@@ -698,6 +698,13 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
   for (int i = tid; i < a.ch; i += 1024) acc[i] = 0.0;
   __syncthreads();
+  const uint32_t* __restrict__ idw = reinterpret_cast<const uint32_t*>(a.ids);   // two u16 ids per lane and load
+#define PLAIDHIP_SCATTER2(id2, val)                                              \
+  {                                                                              \
+    const uint32_t lo_ = (id2) & 0xffffu, hi_ = (id2) >> 16;                      \
+    if (lo_ != 0xffffu) atomicAdd(&acc[lo_], (val));                              \
+    if (hi_ != 0xffffu) atomicAdd(&acc[hi_], (val));                              \
+  }
 
   for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
     const int q0 = a.Xp[c], q1 = a.Xp[c + 1];
@@ -726,19 +733,19 @@ spmm_scatter_csc_f64(ScatterArgs a) {
             vv[u] = readlane_f64(v, kk);
             const int sa = b0[u] < b1[u] ? b0[u] : a.dummy_seg;
             const int sb = b0[u] + 1 < b1[u] ? b0[u] + 1 : a.dummy_seg;
-            ia[u] = a.ids[(int64_t)sa * 64 + lane];
-            ib[u] = a.ids[(int64_t)sb * 64 + lane];
+            ia[u] = idw[(int64_t)sa * 64 + lane];
+            ib[u] = idw[(int64_t)sb * 64 + lane];
           }
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
-            if (ia[u] != 0xffffu) atomicAdd(&acc[ia[u]], vv[u]);
-            if (ib[u] != 0xffffu) atomicAdd(&acc[ib[u]], vv[u]);
+            PLAIDHIP_SCATTER2(ia[u], vv[u])
+            PLAIDHIP_SCATTER2(ib[u], vv[u])
           }
 #pragma unroll
           for (int u = 0; u < UN; ++u)
-            for (int s = b0[u] + 2; s < b1[u]; ++s) {          // genes in more than 128 sets of the chunk
-              const uint32_t id = a.ids[(int64_t)s * 64 + lane];
-              if (id != 0xffffu) atomicAdd(&acc[id], vv[u]);
+            for (int s = b0[u] + 2; s < b1[u]; ++s) {          // genes in more than 256 sets of the chunk
+              const uint32_t id2 = idw[(int64_t)s * 64 + lane];
+              PLAIDHIP_SCATTER2(id2, vv[u])
             }
         }
       }
@@ -774,6 +781,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     }
   }
   publish_flags(f, a.flags);
+#undef PLAIDHIP_SCATTER2
 }
 
 // how a sparse X is multiplied: PLAIDHIP_SPMM_SPARSE = scatter | gather | auto (default: decided on
