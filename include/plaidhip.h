@@ -203,6 +203,40 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                   int remove_log2, int score_mean, double* S_out);
 
+/* ---- GMT text -> 0/1 membership matrix on the host (no device involved) --------------------------
+ * Replaces read.gmt() R/gmt-utils.R:99-125 and gmt2mat() R/gmt-utils.R:19-66 (50.9 s for a 50k-set
+ * collection in R, experiments/benchmark/benchmark-plaid.R:42).  Objects are owned by the library
+ * until *_destroy; returned pointers stay valid until the next call on the same object.            */
+typedef struct plaidhip_gmt plaidhip_gmt;         /* a named list of gene sets                        */
+typedef struct plaidhip_gmtmat plaidhip_gmtmat;   /* genes x sets 0/1 dgCMatrix pattern + dimnames    */
+
+/* read.gmt(gmt.file, add.source, nrows): '#' comments, tab fields name/source/genes, genes split on
+ * ' ' or tab, "" / "NA" / repeats dropped.  nrows <= 0: all lines.                                 */
+int plaidhip_gmt_read(const char* path, int add_source, int64_t nrows, plaidhip_gmt** out);
+/* the same from memory.  raw != 0: exchange format for an in-memory list (one set per line,
+ * name TAB source TAB gene TAB gene ...; nothing is filtered but empty tokens and repeats)         */
+int plaidhip_gmt_parse(const char* text, int64_t nbytes, int raw, int add_source, int64_t nrows,
+                       plaidhip_gmt** out);
+int64_t plaidhip_gmt_nsets(const plaidhip_gmt* gmt);
+const char* plaidhip_gmt_set_name(const plaidhip_gmt* gmt, int64_t j);
+int64_t plaidhip_gmt_set_size(const plaidhip_gmt* gmt, int64_t j);
+const char* plaidhip_gmt_set_gene(const plaidhip_gmt* gmt, int64_t j, int64_t k);
+/* all sets as text, one line per set: name TAB gene TAB gene ... (bulk transfer to a host language) */
+const char* plaidhip_gmt_text(plaidhip_gmt* gmt, int64_t* nbytes);
+int plaidhip_gmt_destroy(plaidhip_gmt* gmt);
+
+/* gmt2mat(gmt, max.genes, ntop, bg): sets by decreasing size, repeated names dropped, head(ntop);
+ * rows = bg (nbg names) or, nbg == 0, the genes by decreasing count (ties in name order);
+ * head(max.genes) (max_genes < 0: all); rows finally by decreasing number of sets (stable).        */
+int plaidhip_gmt2mat(const plaidhip_gmt* gmt, int64_t max_genes, int64_t ntop, const char* const* bg,
+                     int64_t nbg, plaidhip_gmtmat** out);
+int plaidhip_gmtmat_dims(const plaidhip_gmtmat* mat, int64_t dims[3]);   /* genes, sets, memberships */
+const int32_t* plaidhip_gmtmat_p(const plaidhip_gmtmat* mat);             /* @p, sets + 1              */
+const int32_t* plaidhip_gmtmat_i(const plaidhip_gmtmat* mat);             /* @i, sorted rows per set   */
+/* newline-joined dimnames: axis 0 = genes (rows), 1 = sets (columns)                                */
+const char* plaidhip_gmtmat_names(plaidhip_gmtmat* mat, int axis, int64_t* nbytes);
+int plaidhip_gmtmat_destroy(plaidhip_gmtmat* mat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,34 @@ SIGNATURES = {
     "plaidhip_ucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _f64, _vp],
     "plaidhip_aucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
+    # host-only GMT text path (gmt.cpp)
+    "plaidhip_gmt_read": [C.c_char_p, _int, _i64, C.POINTER(_vp)],
+    "plaidhip_gmt_parse": [C.c_char_p, _i64, _int, _int, _i64, C.POINTER(_vp)],
+    "plaidhip_gmt_nsets": [_vp],
+    "plaidhip_gmt_set_name": [_vp, _i64],
+    "plaidhip_gmt_set_size": [_vp, _i64],
+    "plaidhip_gmt_set_gene": [_vp, _i64, _i64],
+    "plaidhip_gmt_text": [_vp, C.POINTER(_i64)],
+    "plaidhip_gmt_destroy": [_vp],
+    "plaidhip_gmt2mat": [_vp, _i64, _i64, C.POINTER(C.c_char_p), _i64, C.POINTER(_vp)],
+    "plaidhip_gmtmat_dims": [_vp, C.POINTER(_i64)],
+    "plaidhip_gmtmat_p": [_vp],
+    "plaidhip_gmtmat_i": [_vp],
+    "plaidhip_gmtmat_names": [_vp, _int, C.POINTER(_i64)],
+    "plaidhip_gmtmat_destroy": [_vp],
+}
+
+# return types other than the int status code
+RESTYPES = {
+    "plaidhip_last_error_string": C.c_char_p,
+    "plaidhip_gmt_nsets": C.c_int64,
+    "plaidhip_gmt_set_name": C.c_char_p,
+    "plaidhip_gmt_set_size": C.c_int64,
+    "plaidhip_gmt_set_gene": C.c_char_p,
+    "plaidhip_gmt_text": C.c_void_p,
+    "plaidhip_gmtmat_p": C.c_void_p,
+    "plaidhip_gmtmat_i": C.c_void_p,
+    "plaidhip_gmtmat_names": C.c_void_p,
 }
 
 _lib = None
@@ -87,7 +115,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "plaidhip_last_error_string" else _int
+        fn.restype = RESTYPES.get(name, _int)
     _lib = lib
     return lib
 

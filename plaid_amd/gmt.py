@@ -1,13 +1,102 @@
 """GMT gene-set utilities with the reference's names and rules (R/gmt-utils.R).
 
-Host glue: produces the 0/1 genes x sets CSC matrix the device consumes.  (SURVEY.md 8f
-ranks a fast native builder as a later row; this is the plain host implementation.)"""
+Host glue: produces the 0/1 genes x sets CSC matrix the device consumes.  `read_gmt` and
+`gmt2mat` run in the native library (plaid_amd/csrc/gmt.cpp behind the C ABI; SURVEY.md 8f-2:
+the R versions take 50 s for a 50k-set collection); `gmt2mat_file` goes from the path to the
+matrix without materialising the gene lists in Python."""
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import scipy.sparse as sp
 
+from . import _lib
 from .matrix import NamedMatrix
+
+
+def _check(rc):
+    if rc != 0:
+        lib = _lib.load()
+        raise _lib.PlaidHipError(rc, (lib.plaidhip_last_error_string() or b"").decode())
+
+
+def _bytes_at(ptr, n):
+    return C.string_at(ptr, n) if ptr and n else b""
+
+
+class _NativeGmt:
+    """Owns a plaidhip_gmt handle."""
+
+    def __init__(self, handle):
+        self.lib = _lib.load()
+        self.handle = handle
+
+    @classmethod
+    def from_file(cls, path, add_source=False, nrows=-1):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _check(lib.plaidhip_gmt_read(str(path).encode(), int(bool(add_source)), int(nrows), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_list(cls, gmt):
+        """exchange format: one set per line, name TAB source TAB gene TAB gene ..."""
+        lib = _lib.load()
+        for nm, s in zip(gmt.names, gmt.sets):
+            if any(("\t" in x) or ("\n" in x) for x in s) or "\t" in nm or "\n" in nm:
+                raise ValueError("gene-set and gene names must not contain tabs or newlines")
+        text = "\n".join(nm + "\t\t" + "\t".join(s) for nm, s in zip(gmt.names, gmt.sets)).encode()
+        h = C.c_void_p()
+        _check(lib.plaidhip_gmt_parse(text, len(text), 1, 0, -1, C.byref(h)))
+        return cls(h)
+
+    def to_list(self) -> "GmtList":
+        nb = C.c_int64()
+        ptr = self.lib.plaidhip_gmt_text(self.handle, C.byref(nb))
+        text = _bytes_at(ptr, nb.value).decode()
+        names, sets = [], []
+        if self.lib.plaidhip_gmt_nsets(self.handle):
+            for line in text.split("\n"):
+                f = line.split("\t")
+                names.append(f[0])
+                sets.append(f[1:])
+        return GmtList(names, sets)
+
+    def to_matrix(self, max_genes=-1, ntop=-1, bg=None, sparse=True) -> NamedMatrix:
+        nbg = 0 if bg is None else len(bg)
+        arr = None
+        if nbg:
+            arr = (C.c_char_p * nbg)(*[str(x).encode() for x in bg])
+        m = C.c_void_p()
+        _check(self.lib.plaidhip_gmt2mat(self.handle, int(max_genes), int(ntop), arr, nbg, C.byref(m)))
+        try:
+            dims = (C.c_int64 * 3)()
+            _check(self.lib.plaidhip_gmtmat_dims(m, dims))
+            g, ns, z = dims[0], dims[1], dims[2]
+            p = np.ctypeslib.as_array(C.cast(self.lib.plaidhip_gmtmat_p(m), C.POINTER(C.c_int32)), shape=(ns + 1,)).copy()
+            i = (np.ctypeslib.as_array(C.cast(self.lib.plaidhip_gmtmat_i(m), C.POINTER(C.c_int32)), shape=(z,)).copy()
+                 if z else np.zeros(0, dtype=np.int32))
+            nb = C.c_int64()
+            rn = _bytes_at(self.lib.plaidhip_gmtmat_names(m, 0, C.byref(nb)), nb.value).decode()
+            rn = rn.split("\n") if g else []
+            cn = _bytes_at(self.lib.plaidhip_gmtmat_names(m, 1, C.byref(nb)), nb.value).decode()
+            cn = cn.split("\n") if ns else []
+        finally:
+            self.lib.plaidhip_gmtmat_destroy(m)
+        D = sp.csc_matrix((np.ones(z, dtype=np.float64), i, p), shape=(g, ns))
+        return NamedMatrix(D if sparse else D.toarray(), rn, cn)
+
+    def close(self):
+        if self.handle:
+            self.lib.plaidhip_gmt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GmtList:
@@ -44,27 +133,31 @@ def _unique(seq):
     return out
 
 
+def _gmt_path(gmt_file, dir):  # noqa: A002
+    path = gmt_file
+    if dir is not None and not str(gmt_file).startswith("/"):   # R/gmt-utils.R:104-105
+        path = str(dir).rstrip("/") + "/" + str(gmt_file)
+    return path
+
+
 def read_gmt(gmt_file, dir=None, add_source=False, nrows=-1) -> GmtList:  # noqa: A002
     """read.gmt(), R/gmt-utils.R:99-125: one set per line, '#' comments, tab separated,
     field 1 name, field 2 source, the rest genes; "" / "NA" / duplicates dropped (:117)."""
-    path = gmt_file
-    if dir is not None and not str(gmt_file).startswith("/"):
-        path = str(dir).rstrip("/") + "/" + str(gmt_file)
-    names, sets = [], []
-    with open(path, "r", encoding="utf-8") as fh:
-        for raw in fh:
-            line = raw.rstrip("\r\n").split("#", 1)[0]
-            if not line.strip():
-                continue
-            fields = line.split("\t")
-            source = fields[1] if len(fields) > 1 else "NA"
-            genes = " ".join(fields[2:]).replace("\t", " ").split(" ") if len(fields) >= 3 else []
-            name = f"{fields[0]} ({source})" if add_source else fields[0]
-            names.append(name)
-            sets.append(_unique(x for x in genes if x not in ("", "NA")))
-            if 0 < nrows <= len(names):
-                break
-    return GmtList(names, sets)
+    nat = _NativeGmt.from_file(_gmt_path(gmt_file, dir), add_source, nrows)
+    try:
+        return nat.to_list()
+    finally:
+        nat.close()
+
+
+def gmt2mat_file(gmt_file, dir=None, add_source=False, nrows=-1, max_genes=-1, ntop=-1, sparse=True,  # noqa: A002
+                 bg=None) -> NamedMatrix:
+    """gmt2mat(read.gmt(file)) without building the gene lists in the host language."""
+    nat = _NativeGmt.from_file(_gmt_path(gmt_file, dir), add_source, nrows)
+    try:
+        return nat.to_matrix(max_genes, ntop, bg, sparse)
+    finally:
+        nat.close()
 
 
 def write_gmt(gmt, file, source=None):
@@ -83,50 +176,11 @@ def gmt2mat(gmt, max_genes=-1, ntop=-1, sparse=True, bg=None, use_multicore=True
     (:62).  `use_multicore` is accepted for signature parity (in the reference both branches
     are single-threaded, :47-60)."""
     gmt = GmtList.coerce(gmt)
-    order = sorted(range(len(gmt)), key=lambda k: -len(gmt.sets[k]))       # stable
-    names = [gmt.names[k] for k in order]
-    sets = [gmt.sets[k] for k in order]
-    seen, keep = set(), []
-    for k, nm in enumerate(names):
-        if nm not in seen:
-            seen.add(nm)
-            keep.append(k)
-    names = [names[k] for k in keep]
-    sets = [sets[k] for k in keep]
-    if ntop > 0:
-        sets = [s[:ntop] for s in sets]
-    if not names:
-        names = []
-    if bg is None:
-        cnt: dict = {}
-        for s in sets:
-            for x in s:
-                cnt[x] = cnt.get(x, 0) + 1
-        bg = sorted(sorted(cnt), key=lambda x: -cnt[x])
-    bg = list(bg)
-    if max_genes < 0:
-        max_genes = len(bg)
-    gg = bg[:max_genes]
-    pos = {x: k for k, x in enumerate(gg)}
-    rows, cols = [], []
-    for j, s in enumerate(sets):
-        for x in _unique(s):
-            r = pos.get(x)
-            if r is not None:
-                rows.append(r)
-                cols.append(j)
-    D = sp.csc_matrix((np.ones(len(rows)), (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))),
-                      shape=(len(gg), len(names)), dtype=np.float64)
-    D.sum_duplicates()
-    D.data[:] = 1.0
-    rs = np.asarray((D != 0).sum(axis=1)).ravel()
-    ro = np.argsort(-rs, kind="stable")
-    D = D[ro, :].tocsc()
-    D.sort_indices()
-    rn = [gg[k] for k in ro]
-    if not sparse:
-        return NamedMatrix(D.toarray(), rn, names)
-    return NamedMatrix(D, rn, names)
+    nat = _NativeGmt.from_list(gmt)
+    try:
+        return nat.to_matrix(max_genes, ntop, bg, sparse)
+    finally:
+        nat.close()
 
 
 def mat2gmt(mat) -> GmtList:

@@ -10,6 +10,8 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 
+#include <string.h>
+
 #include "plaidhip.h"
 
 static plaidhip_ctx* g_ctx = NULL;
@@ -130,6 +132,56 @@ SEXP R_plaidhip_scse(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi
   return S;
 }
 
+
+/* gmt2mat(read.gmt(file)) in one native call: returns list(p, i, Dim, rownames, colnames); the R side
+ * wraps it with new("dgCMatrix", ...).  (R/gmt-utils.R:19-66, 99-125)                             */
+static SEXP split_lines(const char* txt, int64_t nbytes, int64_t count) {
+  SEXP out = PROTECT(Rf_allocVector(STRSXP, (R_xlen_t)count));
+  int64_t b = 0, k = 0;
+  for (int64_t e = 0; e <= nbytes && k < count; ++e)
+    if (e == nbytes || txt[e] == '\n') {
+      SET_STRING_ELT(out, (R_xlen_t)k++, Rf_mkCharLenCE(txt + b, (int)(e - b), CE_UTF8));
+      b = e + 1;
+    }
+  UNPROTECT(1);
+  return out;
+}
+
+SEXP R_plaidhip_gmt2mat_file(SEXP path, SEXP add_source, SEXP nrows, SEXP max_genes, SEXP ntop, SEXP bg) {
+  plaidhip_gmt* gmt = NULL;
+  plaidhip_gmtmat* mat = NULL;
+  if (plaidhip_gmt_read(CHAR(STRING_ELT(path, 0)), Rf_asLogical(add_source), (int64_t)Rf_asReal(nrows), &gmt) != PLAIDHIP_OK)
+    Rf_error("plaidhip: %s", plaidhip_last_error_string());
+  const int64_t nbg = Rf_isNull(bg) ? 0 : (int64_t)XLENGTH(bg);
+  const char** bgp = nbg ? (const char**)R_alloc((size_t)nbg, sizeof(char*)) : NULL;
+  for (int64_t k = 0; k < nbg; ++k) bgp[k] = Rf_translateCharUTF8(STRING_ELT(bg, (R_xlen_t)k));
+  const int rc = plaidhip_gmt2mat(gmt, (int64_t)Rf_asReal(max_genes), (int64_t)Rf_asReal(ntop), bgp, nbg, &mat);
+  plaidhip_gmt_destroy(gmt);
+  if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
+  int64_t dims[3], nb = 0;
+  plaidhip_gmtmat_dims(mat, dims);
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP p = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t)dims[1] + 1));
+  SEXP i = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t)dims[2]));
+  memcpy(INTEGER(p), plaidhip_gmtmat_p(mat), sizeof(int) * (size_t)(dims[1] + 1));
+  if (dims[2]) memcpy(INTEGER(i), plaidhip_gmtmat_i(mat), sizeof(int) * (size_t)dims[2]);
+  SEXP dim = PROTECT(Rf_allocVector(INTSXP, 2));
+  INTEGER(dim)[0] = (int)dims[0];
+  INTEGER(dim)[1] = (int)dims[1];
+  const char* rn = plaidhip_gmtmat_names(mat, 0, &nb);
+  SEXP rnames = PROTECT(split_lines(rn, nb, dims[0]));
+  const char* cn = plaidhip_gmtmat_names(mat, 1, &nb);
+  SEXP cnames = PROTECT(split_lines(cn, nb, dims[1]));
+  SET_VECTOR_ELT(out, 0, p);
+  SET_VECTOR_ELT(out, 1, i);
+  SET_VECTOR_ELT(out, 2, dim);
+  SET_VECTOR_ELT(out, 3, rnames);
+  SET_VECTOR_ELT(out, 4, cnames);
+  plaidhip_gmtmat_destroy(mat);
+  UNPROTECT(6);
+  return out;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
@@ -142,6 +194,7 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_ucell", (DL_FUNC)&R_plaidhip_ucell, 9},
     {"R_plaidhip_aucell", (DL_FUNC)&R_plaidhip_aucell, 8},
     {"R_plaidhip_scse", (DL_FUNC)&R_plaidhip_scse, 9},
+    {"R_plaidhip_gmt2mat_file", (DL_FUNC)&R_plaidhip_gmt2mat_file, 6},
     {NULL, NULL, 0}};
 
 void R_init_plaidhip(DllInfo* dll) {
