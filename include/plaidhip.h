@@ -203,6 +203,17 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                   int remove_log2, int score_mean, double* S_out);
 
+/* plaid.test(X, y, G, gsetX, tests, metap.method), R/plaid.R:392-474, for dense X and the aligned
+ * pattern G.  y: 0 / 1 per sample.  gsetX: sets x samples scores, or NULL: plaid(X, G) is computed
+ * and stays on the device (:424-427).  tests: bit mask 1 = "one" (one-sample t on logFC, :476-486),
+ * 2 = "two" (:488-520), 4 = "lm" (Welch per set over the scores, Rfast::ttests, :429).
+ * metap_method: 0 = fisher / sumlog, 1 = stouffer / sumz (:522-537).
+ * out: sets x 6, column-major: gsetFC, p.one, p.two, p.lm, p.meta, q.meta -- in the column order of
+ * G (the caller sorts, :469-471); columns of tests that were not asked for are NaN.               */
+int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* y,
+                        const int32_t* Gp, const int32_t* Gi, int32_t m, const double* gsetX, int tests,
+                        int metap_method, double* out);
+
 /* ---- GMT text -> 0/1 membership matrix on the host (no device involved) --------------------------
  * Replaces read.gmt() R/gmt-utils.R:99-125 and gmt2mat() R/gmt-utils.R:19-66 (50.9 s for a 50k-set
  * collection in R, experiments/benchmark/benchmark-plaid.R:42).  Objects are owned by the library

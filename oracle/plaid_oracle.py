@@ -369,6 +369,40 @@ def matrix_onesample_ttest(F, G):
     return meanx, t, p
 
 
+def matrix_twosample_ttest(F, G):
+    """R/plaid.R:488-520, F a vector (one column): genes of the set against all other genes."""
+    Gb = sp.csc_matrix((sp.csc_matrix(G) != 0).astype(np.float64))
+    sum1 = np.asarray(Gb.sum(axis=0)).ravel()
+    sum0 = Gb.shape[0] - sum1
+    F2 = F ** 2
+    ssq1 = Gb.T @ F2
+    ssq0 = F2.sum() - ssq1
+    mean1 = Gb.T @ F
+    mean0 = F.sum() - mean1
+    with np.errstate(all="ignore"):
+        mean1 = mean1 / (1e-8 + sum1)
+        mean0 = mean0 / (1e-8 + sum0)
+        var0 = (ssq0 - mean0 ** 2 * sum0) / (sum0 - 1)
+        var1 = (ssq1 - mean1 ** 2 * sum1) / (sum1 - 1)
+        varsum = var0 / sum0 + var1 / sum1
+        dof = varsum ** 2 / (var0 / sum0 * (sum0 - 1) + var1 / sum1 * (sum1 - 1))
+        f = mean1 - mean0
+        t = f / np.sqrt(varsum)
+    p = 2 * st.t.sf(np.abs(t), df=np.maximum(dof, 1))
+    return f, t, p
+
+
+def p_adjust_fdr(p):
+    """stats::p.adjust(p, method="fdr") (Benjamini-Hochberg)."""
+    p = np.asarray(p, dtype=np.float64)
+    n = len(p)
+    o = np.argsort(-p, kind="stable")
+    q = np.minimum.accumulate(p[o] * n / np.arange(n, 0, -1))
+    out = np.empty(n)
+    out[o] = np.minimum(1.0, q)
+    return out
+
+
 def welch_ttests(gsetX, y):
     """Rfast::ttests(t(gsetX), ina=y+1) (R/plaid.R:429): Welch per row."""
     a = gsetX[:, y == 0]
@@ -387,22 +421,35 @@ def matrix_combine_p(plist, method="fisher"):
     raise ValueError("Invalid method: " + method)
 
 
-def plaid_test(X, rownames_x, y, G, rownames_g, gsetX, metap_method="fisher"):
-    """R/plaid.R:392-474 with tests=c("one","lm").  Returns dict of arrays in
-    G-column order (no sorting)."""
+def plaid_test(X, rownames_x, y, G, rownames_g, gsetX, metap_method="fisher", tests=("one", "lm")):
+    """R/plaid.R:392-474.  Returns dict of arrays in G-column order (no sorting); gsetX=None
+    computes plaid(X, G) (:424-427)."""
     gg, ix, ig = align(rownames_g, rownames_x)            # :403 intersect(rownames(G), rownames(X))
     Xa = X[ig, :]
     Ga = sp.csc_matrix(G)[ix, :]
     m1 = np.asarray(Xa[:, y == 1].mean(axis=1)).ravel()   # :407
     m0 = np.asarray(Xa[:, y == 0].mean(axis=1)).ravel()   # :408
     fc = m1 - m0
-    mean1, _, p1 = matrix_onesample_ttest(fc, Ga)         # :413
-    p3 = welch_ttests(gsetX, y)                           # :429
-    df3 = gsetX[:, y == 1].mean(axis=1) - gsetX[:, y == 0].mean(axis=1)
-    P = []
-    for p in (p1, p3):                                    # :441-446
+    raw, eff = {}, []
+    if "one" in tests:
+        mean1, _, raw["p.one"] = matrix_onesample_ttest(fc, Ga)   # :413
+        eff.append(mean1)
+    if "two" in tests:
+        diff, _, raw["p.two"] = matrix_twosample_ttest(fc, Ga)    # :419
+        eff.append(diff)
+    if "lm" in tests:
+        if gsetX is None:
+            gsetX = plaid(Xa, gg, Ga, gg)                          # :424-427
+        gsetX = np.asarray(gsetX)
+        raw["p.lm"] = welch_ttests(gsetX, y)                       # :429
+        eff.append(gsetX[:, y == 1].mean(axis=1) - gsetX[:, y == 0].mean(axis=1))
+    out = {}
+    for k, p in raw.items():                                       # :441-446
         p = np.where(np.isnan(p), 1.0, p)
-        P.append(np.minimum(np.maximum(p, 1e-99), 1 - 1e-99))
-    pmeta = matrix_combine_p(P, metap_method)
-    return {"p.one": P[0], "p.lm": P[1], "p.meta": pmeta,
-            "gsetFC": (mean1 + df3) / 2}
+        out[k] = np.minimum(np.maximum(p, 1e-99), 1 - 1e-99)
+    P = list(out.values())
+    pmeta = matrix_combine_p(P, metap_method) if len(P) > 1 else P[0]
+    out["p.meta"] = pmeta
+    out["q.meta"] = p_adjust_fdr(pmeta)                            # :463
+    out["gsetFC"] = np.mean(np.stack(eff, axis=1), axis=1)         # :453
+    return out

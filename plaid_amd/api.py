@@ -14,6 +14,7 @@ import scipy.sparse as sp
 
 from ._lib import EUNSUPPORTED, PlaidHipError
 from .engine import Context, default_context
+from .gmt import GmtList, gmt2mat
 from .matrix import NamedMatrix, as_named
 
 INT_MAX = 2147483647  # .Machine$integer.max
@@ -263,3 +264,76 @@ def replaid_scse(X, matG, removeLog2=None, scoreMean=False, ctx: Context | None 
         _message("[replaid.scse] Converting data to linear scale (removing log2)...")
     S = ctx.scse(X.values, pat[0], pat[1], removeLog2, scoreMean)
     return NamedMatrix(S, matG.colnames, X.colnames)
+
+
+_TEST_BITS = {"one": 1, "two": 2, "lm": 4}
+
+
+def plaid_test(X, y, G, gsetX=None, tests=("one", "two", "lm"), metap_method="fisher", sort_by="p.meta",
+               ctx: Context | None = None):
+    """plaid.test(), R/plaid.R:392-474: one-/two-sample t-tests of the logFC inside each set plus a Welch test
+    of the single-sample scores between the two groups, combined by Fisher or Stouffer, BH-adjusted.
+    The statistics are reduced on the device; with gsetX=None the scores plaid(X, G) never leave it.
+    Returns a NamedMatrix (sets x [gsetFC, p.<test>..., p.meta, q.meta]) ordered by `sort_by` (:469-471)."""
+    y = np.asarray(y)
+    if not np.all(np.isin(np.unique(y), (0, 1))):
+        raise ValueError("elements of y must be 0 or 1")                      # :394
+    if isinstance(G, (GmtList, dict)) or (isinstance(G, tuple) and len(G) == 2):
+        _message("[plaid.test] converting gmt to sparse matrix...")           # :396-397
+        G = gmt2mat(G)
+    X, G = as_named(X), as_named(G)
+    tests = [tests] if isinstance(tests, str) else list(tests)
+    bits = 0
+    for t in tests:
+        if t not in _TEST_BITS:
+            raise ValueError(f"unknown test {t!r}")
+        bits |= _TEST_BITS[t]
+    if metap_method in ("fisher", "sumlog"):
+        mm = 0
+    elif metap_method in ("stouffer", "sumz"):
+        mm = 1
+    else:
+        raise ValueError("Invalid method: " + str(metap_method))              # :533
+    # gg <- intersect(rownames(G), rownames(X)); X <- X[gg,]; G <- G[gg,]    (:403-405)
+    posx = _first_pos(X.rownames)
+    seen, grow, xrow = set(), [], []
+    for k, nm in enumerate(G.rownames):
+        if nm in seen:
+            continue
+        seen.add(nm)
+        r = posx.get(nm)
+        if r is not None:
+            grow.append(k)
+            xrow.append(r)
+    Gs = sp.csc_matrix(G.values)[grow, :].tocsc()
+    Gs.sort_indices()
+    keep = Gs.data != 0
+    counts = np.bincount(np.repeat(np.arange(Gs.shape[1]), np.diff(Gs.indptr))[keep], minlength=Gs.shape[1])
+    Gp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    Gi = Gs.indices[keep].astype(np.int32)
+    Xv = X.values
+    Xs = np.asfortranarray(Xv[xrow, :].toarray() if sp.issparse(Xv) else np.asarray(Xv)[xrow, :], dtype=np.float64)
+    sx = None
+    if gsetX is not None:
+        gx = as_named(gsetX)
+        if gx.rownames is not None and list(gx.rownames) != list(G.colnames):
+            pos = _first_pos(gx.rownames)
+            sx = np.asarray(gx.values)[[pos[nm] for nm in G.colnames], :]
+        else:
+            sx = np.asarray(gx.values)
+    ctx = ctx or default_context()
+    out = ctx.plaid_test(Xs, y.astype(np.int32), Gp, Gi, sx, bits, mm)
+    cols, names = [0], ["gsetFC"]
+    for t, c in (("one", 1), ("two", 2), ("lm", 3)):
+        if t in tests:
+            cols.append(c)
+            names.append("p." + t)
+    cols += [4, 5]
+    names += ["p.meta", "q.meta"]
+    res = out[:, cols]
+    rn = list(G.colnames)
+    if sort_by in names:
+        o = np.argsort(res[:, names.index(sort_by)], kind="stable")       # order()
+        res = res[o, :]
+        rn = [rn[k] for k in o]
+    return NamedMatrix(res, rn, names)

@@ -5,6 +5,10 @@
 #include <cstdio>
 #include <cstring>
 
+#include <algorithm>
+#include <limits>
+#include <vector>
+
 #include "common.h"
 
 namespace plaidhip {
@@ -716,6 +720,98 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
                        score_mean ? 1.0 / (double)g : 1.0, nullptr, 0.0));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* y,
+                        const int32_t* Gp, const int32_t* Gi, int32_t m, const double* gsetX, int tests,
+                        int metap_method, double* out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(m == 0 || out, "plaid_test: null out");
+  PH_REQUIRE(n == 0 || (X && y), "plaid_test: null X / y");
+  PH_REQUIRE((tests & 7) != 0 && (tests & ~7) == 0, "plaid_test: tests is a bit mask of 1 (one), 2 (two), 4 (lm)");
+  PH_REQUIRE(metap_method == 0 || metap_method == 1, "Invalid method: %d", metap_method);      // R/plaid.R:533
+  int64_t n0 = 0, n1 = 0;
+  for (int32_t c = 0; c < n; ++c) {
+    PH_REQUIRE(y[c] == 0 || y[c] == 1, "elements of y must be 0 or 1");                        // R/plaid.R:394
+    if (y[c]) ++n1; else ++n0;
+  }
+  if (m == 0) return PLAIDHIP_OK;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  const int64_t ldg = even_ld(g);
+  DevBuf dX, dy, dmean, dF, dT, dws, dS, dsm, dsmall;
+  PH_TRY(dX.alloc((size_t)ldg * n * 8));
+  PH_TRY(dy.alloc((size_t)n * 4));
+  PH_TRY(dmean.alloc((size_t)g * 2 * 8));
+  PH_TRY(dF.alloc((size_t)ldg * 2 * 8));
+  PH_TRY(dT.alloc((size_t)m * 2 * 8));
+  const int64_t wsd = std::max(row_group_ws_doubles(g, n), row_group_ws_doubles(m, n));
+  PH_TRY(dws.alloc((size_t)wsd * 8));
+  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
+  PH_TRY(h2d(ctx, dy.p, y, (size_t)n * 4));
+  // fc = rowMeans(X[, y == 1]) - rowMeans(X[, y == 0])   (R/plaid.R:407-409); Gt fc and Gt fc^2 (:478-479)
+  PH_TRY(launch_row_group_moments(ctx, dX.as<double>(), ldg, g, n, dy.as<int32_t>(), n0, n1, dmean.as<double>(), nullptr,
+                                  dws.as<double>()));
+  PH_HIP(hipMemsetAsync(dF.p, 0, (size_t)ldg * 2 * 8, ctx->stream));
+  PH_TRY(launch_fold_change(ctx, dmean.as<double>(), g, ldg, dF.as<double>()));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dF.as<double>(), ldg, 2, PLAIDHIP_STAT_SUM, 1.0, nullptr, 0.0, dT.as<double>(),
+                               m, nullptr));
+  std::vector<double> T((size_t)m * 2), F((size_t)ldg * 2), SM;
+  PH_HIP(hipMemcpyAsync(T.data(), dT.p, (size_t)m * 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipMemcpyAsync(F.data(), dF.p, (size_t)ldg * 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (tests & 4) {
+    // scores stay on the device: given (uploaded) or plaid(X, G) computed here (R/plaid.R:424-427)
+    PH_TRY(dS.alloc((size_t)m * n * 8));
+    if (gsetX != nullptr) {
+      PH_TRY(h2d(ctx, dS.p, gsetX, (size_t)m * n * 8));
+    } else {
+      PH_TRY(plaid_on_device(ctx, gh.gs, dX.as<double>(), (int32_t)ldg, n, m, PLAIDHIP_STAT_MEAN, 1, dS.as<double>(), dsmall));
+    }
+    PH_TRY(dsm.alloc((size_t)m * 4 * 8));
+    PH_TRY(launch_row_group_moments(ctx, dS.as<double>(), m, m, n, dy.as<int32_t>(), n0, n1, dsm.as<double>(),
+                                    dsm.as<double>() + 2 * (size_t)m, dws.as<double>()));
+    SM.resize((size_t)m * 4);
+    PH_HIP(hipMemcpyAsync(SM.data(), dsm.p, (size_t)m * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  double tot1 = 0.0, tot2 = 0.0;
+  for (int32_t i = 0; i < g; ++i) { tot1 += F[i]; tot2 += F[(size_t)ldg + i]; }
+  double* o_fc = out;
+  double* o_p1 = out + (size_t)m;
+  double* o_p2 = out + 2 * (size_t)m;
+  double* o_p3 = out + 3 * (size_t)m;
+  double* o_pm = out + 4 * (size_t)m;
+  double* o_q = out + 5 * (size_t)m;
+  for (int32_t j = 0; j < m; ++j) {
+    const double k = (double)(Gp[j + 1] - Gp[j]);
+    double eff = 0.0, pv[3];
+    int np = 0;
+    o_p1[j] = o_p2[j] = o_p3[j] = nan;
+    if (tests & 1) {
+      double mean1;
+      o_p1[j] = clamp_p(onesample_p(k, T[j], T[(size_t)m + j], &mean1));
+      eff += mean1;
+      pv[np++] = o_p1[j];
+    }
+    if (tests & 2) {
+      double diff;
+      o_p2[j] = clamp_p(twosample_p((double)g, k, T[j], T[(size_t)m + j], tot1, tot2, &diff));
+      eff += diff;
+      pv[np++] = o_p2[j];
+    }
+    if (tests & 4) {
+      const double m0 = SM[j], m1 = SM[(size_t)m + j];
+      o_p3[j] = clamp_p(welch_p(m0, m1, SM[2 * (size_t)m + j], SM[3 * (size_t)m + j], (double)n0, (double)n1));
+      eff += m1 - m0;                                                                           // :431
+      pv[np++] = o_p3[j];
+    }
+    o_fc[j] = eff / np;                                                                         // rowMeans(F), :453
+    o_pm[j] = np > 1 ? combine_p(pv, np, metap_method) : pv[0];                                 // :455-460
+  }
+  p_adjust_fdr(o_pm, m, o_q);                                                                   // :463
   return PLAIDHIP_OK;
 }
 

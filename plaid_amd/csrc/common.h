@@ -148,6 +148,19 @@ int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask);
   } while (0)
 int spmm_block_for_genes(int32_t g);   // workgroup size of the column-resident SpMM kernel
 
+// kernels_stats.hip / stats.cpp  (plaid.test)
+int launch_row_group_moments(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n,
+                             const int32_t* d_y, int64_t n0, int64_t n1, double* d_mean, double* d_ssd,
+                             double* ws);
+int launch_fold_change(plaidhip_ctx* ctx, const double* d_mean, int32_t rows, int64_t ld2, double* d_F);
+int64_t row_group_ws_doubles(int32_t rows, int32_t n);
+double onesample_p(double k, double s1, double s2, double* mean_out);
+double twosample_p(double g, double k, double s1, double s2, double tot1, double tot2, double* diff_out);
+double welch_p(double m0, double m1, double ssd0, double ssd1, double n0, double n1);
+double clamp_p(double p);
+double combine_p(const double* p, int np, int method);
+void p_adjust_fdr(const double* p, int64_t m, double* q);
+
 // kernels_spmm.hip
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,

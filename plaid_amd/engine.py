@@ -257,6 +257,28 @@ def _scse(self, X, Gp, Gi, remove_log2=None, score_mean=False):
     return S
 
 
+def _plaid_test(self, X, y, Gp, Gi, gsetX=None, tests=7, metap_method=0):
+    """plaidhip_plaid_test: returns sets x 6 (gsetFC, p.one, p.two, p.lm, p.meta, q.meta), G's column order"""
+    X = _as_f64_fortran(X)
+    g, n = X.shape
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    if y.shape != (n,):
+        raise ValueError("y must have one entry per column of X")
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    sx = None
+    if gsetX is not None:
+        sx = _as_f64_fortran(gsetX)
+        if sx.shape != (m, n):
+            raise ValueError("gsetX must be sets x samples")
+    out = np.empty((m, 6), dtype=np.float64, order="F")
+    check(self.lib.plaidhip_plaid_test(self.handle, _np_ptr(X), g, n, _np_ptr(y), _np_ptr(Gp), _np_ptr(Gi), m,
+                                       _np_ptr(sx) if sx is not None else None, int(tests), int(metap_method),
+                                       _np_ptr(out)))
+    return out
+
+
+Context.plaid_test = _plaid_test
 Context.ucell = _ucell
 Context.aucell = _aucell
 Context.scse = _scse

@@ -146,3 +146,29 @@ gmt2mat.file <- function(gmt.file, dir = NULL, add.source = FALSE, nrows = -1,
   if (!sparse) D <- as.matrix(D)
   D
 }
+
+
+## plaid.test(), R/plaid.R:392-474: same arguments and result; the group means of X, Gt fc, Gt fc^2 and the
+## per-set Welch statistics are reduced on the device (with gsetX = NULL the score matrix never leaves it),
+## only O(sets) numbers come back.
+plaid.test <- function(X, y, G, gsetX = NULL, tests = c("one", "two", "lm"),
+                       metap.method = "fisher", sort.by = "p.meta") {
+  if (!all(unique(y) %in% c(0, 1))) stop("elements of y must be 0 or 1")
+  if (is.list(G)) {
+    message("[plaid.test] converting gmt to sparse matrix...")
+    G <- gmt2mat(G)
+  }
+  if (!metap.method %in% c("fisher", "sumlog", "stouffer", "sumz")) stop("Invalid method: ", metap.method)
+  gg <- intersect(rownames(G), rownames(X))
+  X <- as.matrix(X[gg, , drop = FALSE])
+  G <- methods::as(G[gg, , drop = FALSE] != 0, "dgCMatrix")
+  if (!is.null(gsetX)) gsetX <- as.matrix(gsetX[colnames(G), , drop = FALSE])
+  bits <- sum(c(one = 1L, two = 2L, lm = 4L)[intersect(tests, c("one", "two", "lm"))])
+  r <- .Call("R_plaidhip_plaid_test", X, as.integer(y), G@p, G@i, gsetX, bits,
+             as.integer(metap.method %in% c("stouffer", "sumz")), PACKAGE = "plaidhip")
+  keep <- c(TRUE, "one" %in% tests, "two" %in% tests, "lm" %in% tests, TRUE, TRUE)
+  res <- r[, keep, drop = FALSE]
+  dimnames(res) <- list(colnames(G), c("gsetFC", "p.one", "p.two", "p.lm", "p.meta", "q.meta")[keep])
+  if (sort.by %in% colnames(res)) res <- res[order(res[, sort.by]), ]
+  res
+}

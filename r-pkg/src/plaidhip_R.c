@@ -182,6 +182,18 @@ SEXP R_plaidhip_gmt2mat_file(SEXP path, SEXP add_source, SEXP nrows, SEXP max_ge
   return out;
 }
 
+
+/* plaid.test(): sets x 6 matrix (gsetFC, p.one, p.two, p.lm, p.meta, q.meta) in G's column order */
+SEXP R_plaidhip_plaid_test(SEXP X, SEXP y, SEXP Gp, SEXP Gi, SEXP gsetX, SEXP tests, SEXP metap) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, m, 6));
+  int rc = plaidhip_plaid_test(ctx(), REAL(X), g, n, INTEGER(y), INTEGER(Gp), INTEGER(Gi), m,
+                               Rf_isNull(gsetX) ? NULL : REAL(gsetX), Rf_asInteger(tests), Rf_asInteger(metap), REAL(out));
+  if (rc != PLAIDHIP_OK) Rf_error("%s", plaidhip_last_error_string());
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
@@ -195,6 +207,7 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_aucell", (DL_FUNC)&R_plaidhip_aucell, 8},
     {"R_plaidhip_scse", (DL_FUNC)&R_plaidhip_scse, 9},
     {"R_plaidhip_gmt2mat_file", (DL_FUNC)&R_plaidhip_gmt2mat_file, 6},
+    {"R_plaidhip_plaid_test", (DL_FUNC)&R_plaidhip_plaid_test, 7},
     {NULL, NULL, 0}};
 
 void R_init_plaidhip(DllInfo* dll) {

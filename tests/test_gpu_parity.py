@@ -430,3 +430,62 @@ def test_replaid_ucell_aucell_scse(hip_ctx, sparse):
         for sm in (False, True):
             close(plaid_amd.replaid_scse(Xn, Gn, removeLog2=rl, scoreMean=sm).values,
                   po.replaid_scse(X, rn, G, grn, remove_log2=rl, score_mean=sm))
+
+
+# ---------------------------------------------------------------- plaid.test on the device
+@pytest.mark.parametrize("metap", ["fisher", "stouffer"])
+def test_plaid_test_fixture_matches_oracle_and_vignette(pbmc, golden_dir, metap):
+    """plaid.test() (R/plaid.R:392-474) through the R-like API: all three tests and the combined p / q against
+    the oracle; with metap.method = "stouffer" the six vignette known answers (doc/plaid-vignette.html:857-869)"""
+    import os
+    import plaid_amd
+    Xn, e = _pbmc_named(pbmc)
+    d = pbmc[0]
+    matG = plaid_amd.gmt2mat(plaid_amd.read_gmt(os.path.join(golden_dir, "hallmarks.gmt")))
+    y = (d["celltype"] == "B").astype(int)
+    po = _oracle()
+    rn = list(d["rownames"])
+    exp = po.plaid_test(Xn.values, rn, y, sp.csc_matrix(matG.values), matG.rownames, None, metap_method=metap,
+                        tests=("one", "two", "lm"))
+    res = plaid_amd.plaid_test(Xn, y, matG, metap_method=metap, sort_by=None)          # gsetX = NULL: scores stay on the device
+    assert res.colnames == ["gsetFC", "p.one", "p.two", "p.lm", "p.meta", "q.meta"] and res.rownames == matG.colnames
+    for k, nm in enumerate(res.colnames):
+        np.testing.assert_allclose(res.values[:, k], exp[nm], rtol=1e-7, atol=1e-300, err_msg=nm)
+    S = plaid_amd.plaid(Xn, matG)
+    res2 = plaid_amd.plaid_test(Xn, y, matG, gsetX=S, tests=("one", "lm"), metap_method=metap)   # sorted by p.meta
+    assert res2.colnames == ["gsetFC", "p.one", "p.lm", "p.meta", "q.meta"]
+    assert np.all(np.diff(res2.values[:, 3]) >= 0)
+    if metap == "stouffer":
+        # doc/plaid-vignette.html:857-869: head(res) sorted by p.meta, printed with 7 significant digits
+        kat = {"HALLMARK_INTERFERON_GAMMA_RESPONSE": (0.003668116, 8.246828e-06, 3.868049e-07),
+               "HALLMARK_ALLOGRAFT_REJECTION": (0.102407488, 1.071307e-05, 4.781538e-05),
+               "HALLMARK_P53_PATHWAY": (0.038355508, 1.906952e-04, 8.369509e-05),
+               "HALLMARK_INTERFERON_ALPHA_RESPONSE": (0.032562973, 9.261621e-03, 1.491854e-03),
+               "HALLMARK_PEROXISOME": (0.016625538, 4.052692e-02, 3.080580e-03),
+               "HALLMARK_G2M_CHECKPOINT": (0.012385507, 6.049535e-02, 3.638628e-03)}
+        assert res2.rownames[:6] == list(kat)
+        for k, nm in enumerate(kat):
+            np.testing.assert_allclose(res2.values[k, 1:4], kat[nm], rtol=2e-6)
+
+
+def test_plaid_test_synthetic_and_errors(hip_ctx):
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, n, m = 3000, 301, 77
+    Gp, Gi = sy.geneset_csc(g, m, kmin=2, kmax=200, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n)
+    rng = np.random.default_rng(0)
+    y = (rng.random(n) < 0.4).astype(int)
+    X[:, y == 1] += rng.normal(0, 0.3, size=(g, 1))
+    rn = [f"g{k}" for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    cn = [f"s{k}" for k in range(m)]
+    exp = _oracle().plaid_test(X, rn, y, G, rn, None, tests=("one", "two", "lm"))
+    res = plaid_amd.plaid_test(plaid_amd.NamedMatrix(X, rn, [str(c) for c in range(n)]), y,
+                               plaid_amd.NamedMatrix(G, rn, cn), sort_by=None)
+    for k, nm in enumerate(res.colnames):
+        np.testing.assert_allclose(res.values[:, k], exp[nm], rtol=1e-7, atol=1e-300, err_msg=nm)
+    with pytest.raises(ValueError):
+        plaid_amd.plaid_test(plaid_amd.NamedMatrix(X, rn, None), y + 1, plaid_amd.NamedMatrix(G, rn, cn))
+    with pytest.raises(plaid_amd.PlaidHipError):
+        hip_ctx.plaid_test(X, y * 2, Gp, Gi)                     # the C ABI checks y itself (R/plaid.R:394)

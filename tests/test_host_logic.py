@@ -183,3 +183,46 @@ def test_shard_bounds_cover_all_columns():
         spans = [shard_bounds(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[r][1] == spans[r + 1][0] for r in range(w - 1))
+
+
+def test_distribution_functions_of_the_plaid_test_tail_match_scipy():
+    """stats.cpp: 2*pt(|t|, df, lower=FALSE), pchisq(x, 2k, lower=FALSE), qnorm, pnorm upper -- reached through
+    a test hook of the library (host code; no device involved)"""
+    import ctypes as C
+    import scipy.stats as st
+    lib = _lib.load()
+    f = lib.plaidhip_debug_pvalue
+    f.argtypes = [C.c_int, C.c_double, C.c_double]
+    f.restype = C.c_double
+    rng = np.random.default_rng(5)
+    for t, df in zip(np.concatenate([rng.normal(0, 3, 200), [0.0, 1e-9, 40.0, 300.0, -7.5]]),
+                     np.concatenate([rng.uniform(1.0, 300.0, 200), [1.0, 2.5, 4.0, 17.3, 1e6]])):
+        np.testing.assert_allclose(f(0, abs(t), df), 2 * st.t.sf(abs(t), df), rtol=2e-10, atol=1e-300)
+    for x in [0.0, 1e-3, 1.0, 9.2, 55.0, 460.0, 900.0]:
+        for k in (1, 2, 3):
+            np.testing.assert_allclose(f(1, x, k), st.chi2.sf(x, 2 * k), rtol=1e-12, atol=1e-300)
+    for p_ in [1e-99, 1e-20, 1e-6, 0.01, 0.3, 0.5, 0.77, 0.999, 1 - 1e-12]:
+        np.testing.assert_allclose(f(2, p_, 0), st.norm.ppf(p_), rtol=1e-13, atol=1e-15)
+    for z in [-38.0, -5.0, -0.3, 0.0, 1.7, 8.0, 21.0]:
+        np.testing.assert_allclose(f(3, z, 0), st.norm.sf(z), rtol=1e-13, atol=1e-300)
+    assert np.isnan(f(0, 1.0, 0.0)) and f(0, np.inf, 3.0) == 0.0
+
+
+def test_oracle_twosample_t_is_welch_t_of_set_vs_rest():
+    """R/plaid.R:488-520: the statistic is the Welch t of the set's logFC against all other genes (up to the
+    1e-8 guards); its degrees of freedom are the reference's own formula, kept as written (":510 NEED CHECKING")"""
+    import scipy.stats as st
+    rng = np.random.default_rng(1)
+    g, m = 400, 12
+    F = rng.normal(0, 1, g)
+    G = sp.random(g, m, density=0.1, random_state=3, format="csc")
+    f, t, p = po.matrix_twosample_ttest(F, G)
+    Gd = (G.toarray() != 0)
+    for j in range(m):
+        a, b = F[Gd[:, j]], F[~Gd[:, j]]
+        ref = st.ttest_ind(a, b, equal_var=False)
+        np.testing.assert_allclose(t[j], ref.statistic, rtol=1e-6)
+        np.testing.assert_allclose(f[j], a.mean() - b.mean(), rtol=1e-6)
+    q = po.p_adjust_fdr(p)
+    o = np.argsort(p)
+    assert np.all(np.diff(q[o]) >= -1e-15) and np.all(q >= p - 1e-15) and np.all(q <= 1)
