@@ -203,6 +203,13 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                   int remove_log2, int score_mean, double* S_out);
 
+/* replaid.gsva(X, matG, tau, rowtf), R/plaid.R:338-363, dense X: row z-transform (rowtf = 0, "z";
+ * the "ecdf" variant is not implemented on the device: PLAIDHIP_EINVAL), signed average ranks per
+ * sample, / max|rank|, sign * |.|^(1 + tau) for tau > 0, then plaid(mean, normalised).  The row
+ * statistics need every sample, so this call does not shard by sample.                           */
+int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* Gp,
+                  const int32_t* Gi, int32_t m, double tau, int rowtf, double* S_out);
+
 /* plaid.test(X, y, G, gsetX, tests, metap.method), R/plaid.R:392-474, for dense X and the aligned
  * pattern G.  y: 0 / 1 per sample.  gsetX: sets x samples scores, or NULL: plaid(X, G) is computed
  * and stays on the device (:424-427).  tests: bit mask 1 = "one" (one-sample t on logFC, :476-486),

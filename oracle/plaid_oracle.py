@@ -352,6 +352,23 @@ def replaid_scse(X, rownames_x, matG, rownames_g, remove_log2=None, score_mean=F
     return sX / sumx[None, :] * 100                       # :182
 
 
+def replaid_gsva(X, rownames_x, matG, rownames_g, tau=0, rowtf="z"):
+    """R/plaid.R:338-363."""
+    Xd = _dense(X)
+    if rowtf == "z":
+        with np.errstate(all="ignore"):
+            zX = (Xd - Xd.mean(axis=1, keepdims=True)) / (1e-8 + Xd.std(axis=1, ddof=1, keepdims=True))   # :343
+    elif rowtf == "ecdf":
+        zX = np.stack([(np.sum(r[None, :] <= r[:, None], axis=1)) / len(r) for r in Xd])                   # :346
+    else:
+        raise ValueError("Error: unknown row transform" + str(rowtf))
+    rX = colranks(zX, signed=True, ties_method="average")       # :352
+    rX = rX / np.max(np.abs(rX))                                  # :353
+    if tau > 0:
+        rX = np.sign(rX) * np.abs(rX) ** (1 + tau)                # :357
+    return plaid(rX, rownames_x, matG, rownames_g)                # :360
+
+
 # ---------------------------------------------------------------------------
 # plaid.test pieces -- only what the vignette known answers need
 # (R/plaid.R:392-537)

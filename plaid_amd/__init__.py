@@ -5,7 +5,7 @@ Host side of the drop-in: the reference's R function names (`plaid`, `colranks`,
 gfx950 kernels through the C ABI of include/plaidhip.h.  See DESIGN.md / INTEGRATION.md.
 """
 from ._lib import PlaidHipError, device_count
-from .api import (aligned_pattern, chunked_crossprod, colranks, normalize_medians, plaid, plaid_test,
+from .api import (aligned_pattern, chunked_crossprod, colranks, normalize_medians, plaid, plaid_test, replaid_gsva,
                   replaid_aucell, replaid_scse, replaid_sing, replaid_ssgsea, replaid_ucell,
                   sparse_colranks)
 from .engine import Context, Geneset, default_context
@@ -16,6 +16,6 @@ __all__ = [
     "PlaidHipError", "device_count", "Context", "Geneset", "default_context", "NamedMatrix",
     "as_named", "GmtList", "read_gmt", "write_gmt", "gmt2mat", "mat2gmt", "plaid",
     "chunked_crossprod", "normalize_medians", "colranks", "sparse_colranks", "replaid_sing",
-    "replaid_ssgsea", "replaid_ucell", "replaid_aucell", "replaid_scse", "aligned_pattern", "plaid_test",
+    "replaid_ssgsea", "replaid_ucell", "replaid_aucell", "replaid_scse", "aligned_pattern", "plaid_test", "replaid_gsva",
 ]
 __version__ = "0.1.0"

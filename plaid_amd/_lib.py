@@ -62,6 +62,7 @@ SIGNATURES = {
     "plaidhip_ucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _f64, _vp],
     "plaidhip_aucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
+    "plaidhip_gsva": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _int, _vp],
     "plaidhip_plaid_test": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _int, _int, _vp],
     # host-only GMT text path (gmt.cpp)
     "plaidhip_gmt_read": [C.c_char_p, _int, _i64, C.POINTER(_vp)],

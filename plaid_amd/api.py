@@ -266,6 +266,21 @@ def replaid_scse(X, matG, removeLog2=None, scoreMean=False, ctx: Context | None 
     return NamedMatrix(S, matG.colnames, X.colnames)
 
 
+def replaid_gsva(X, matG, tau=0, rowtf="z", ctx: Context | None = None):
+    """replaid.gsva(), R/plaid.R:338-363 (row z-transform variant; the result of plaid() on the rank matrix
+    carries the dimnames of matG / X)."""
+    rowtf = rowtf if isinstance(rowtf, str) else rowtf[0]
+    X, matG = as_named(X), as_named(matG)
+    pat = aligned_pattern(X, matG)
+    if pat is None:
+        _message("[plaid] ERROR. No overlapping features.")
+        return None
+    ctx = ctx or default_context()
+    Xv = X.values.toarray() if sp.issparse(X.values) else X.values
+    S = ctx.gsva(Xv, pat[0], pat[1], float(tau), rowtf)
+    return NamedMatrix(S, matG.colnames, X.colnames)
+
+
 _TEST_BITS = {"one": 1, "two": 2, "lm": 4}
 
 

@@ -815,4 +815,48 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   return PLAIDHIP_OK;
 }
 
+int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi,
+                  int32_t m, double tau, int rowtf, double* S_out) {
+  PH_CTX(ctx);
+  PH_TRY(check_host_common(Gp, g, n, m));
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(X && S_out, "gsva: null X/S_out");
+  PH_REQUIRE(rowtf == 0, "Error: unknown row transform (only \"z\" runs on the device)");   // R/plaid.R:348
+  GenesetHolder gh;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  const int64_t ldg = even_ld(g);
+  DevBuf dX, dR, dS, dy, dmom, dws, dsmall;
+  PH_TRY(dX.alloc((size_t)ldg * n * 8));
+  PH_TRY(dR.alloc((size_t)ldg * n * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(dy.alloc((size_t)n * 4));
+  PH_TRY(dmom.alloc((size_t)g * 4 * 8));
+  PH_TRY(dws.alloc((size_t)row_group_ws_doubles(g, n) * 8));
+  PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
+  uint32_t* d_flags = dsmall.as<uint32_t>();
+  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
+  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
+  double* d_colmax = d_med + n;
+  double* d_gmax = d_red + 2;
+  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
+  PH_HIP(hipMemsetAsync(dy.p, 0, (size_t)n * 4, ctx->stream));                         // one group: every sample
+  // zX = (X - rowMeans(X)) / (1e-8 + rowSds(X))                                       (R/plaid.R:341-343)
+  PH_TRY(launch_row_group_moments(ctx, dX.as<double>(), ldg, g, n, dy.as<int32_t>(), n, 0, dmom.as<double>(),
+                                  dmom.as<double>() + 2 * (size_t)g, dws.as<double>()));
+  PH_TRY(launch_row_ztransform(ctx, dX.as<double>(), ldg, g, n, dmom.as<double>(), dmom.as<double>() + 2 * (size_t)g));
+  // rX = colranks(zX, signed = TRUE, "average"); rX / max|rX|; sign * |rX|^(1 + tau)   (:352-358)
+  //    = sign * rank^(1+tau) / max(rank^(1+tau)): the power is fused into the rank kernel, the division into the
+  //    SpMM epilogue (alpha_div), by linearity of the mean statistic
+  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_AVERAGE, 1, tau > 0.0 ? 1.0 + tau : 1.0,
+                                   dR.as<double>(), ldg, d_colmax));
+  PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
+  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
+  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, 0.0, dS.as<double>(),
+                               m, d_flags));
+  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));   // :360 plaid()
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
 }  // extern "C"

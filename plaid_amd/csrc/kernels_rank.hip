@@ -106,8 +106,8 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
         const uint32_t ub = upper_bound_f64(keys, nvalid, x);
         r = rank_from_bounds(lb, ub, ties);
         if (power != 1.0) r = pow(r, power);
+        vmax = (r > vmax) ? r : vmax;            // max |value| of the column (before the sign goes on)
         if (is_signed) r *= sign_of(x0);
-        vmax = (r > vmax) ? r : vmax;
       }
       rc[i] = r;
     }
@@ -236,8 +236,8 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
         } else {
           r = rank_from_bounds(la, upper_from(la, xa), ties);
           if (power != 1.0) r = pow(r, power);
+          vmax = (r > vmax) ? r : vmax;          // max |value| of the column
           if (is_signed) r *= sign_of(xa0);
-          vmax = (r > vmax) ? r : vmax;
         }
         rc[i0] = r;
       }
@@ -248,8 +248,8 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
         } else {
           r = rank_from_bounds(lb_, upper_from(lb_, xb), ties);
           if (power != 1.0) r = pow(r, power);
-          if (is_signed) r *= sign_of(xb0);
           vmax = (r > vmax) ? r : vmax;
+          if (is_signed) r *= sign_of(xb0);
         }
         rc[i1] = r;
       }

@@ -82,6 +82,33 @@ fold_change_kernel(const double* __restrict__ mean, int32_t rows, int64_t ld2, d
   F[ld2 + r] = fc * fc;
 }
 
+// replaid.gsva row transform, R/plaid.R:343: z = (x - rowMeans(X)) / (1e-8 + rowSds(X)), in place.
+// mom: [2][rows] group-0 means, ssd: [2][rows] group-0 sums of squared deviations (all samples in group 0)
+__global__ void __launch_bounds__(256)
+row_ztransform_kernel(double* __restrict__ A, int64_t ld, int32_t rows, int32_t n,
+                      const double* __restrict__ mean, const double* __restrict__ ssd) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * kColBlock;
+  const int c1 = c0 + kColBlock < n ? c0 + kColBlock : n;
+  if (r >= rows) return;
+  const double mu = mean[r];
+  const double den = 1e-8 + sqrt(ssd[r] / (double)(n - 1));   // sd with n - 1 (NaN for a single sample, as in R)
+  for (int c = c0; c < c1; ++c) {
+    double* p = &A[(int64_t)c * ld + r];
+    *p = (*p - mu) / den;   // a true division, as the reference does: ties between genes stay ties
+  }
+}
+
+int launch_row_ztransform(plaidhip_ctx* ctx, double* A, int64_t ld, int32_t rows, int32_t n, const double* d_mean,
+                          const double* d_ssd) {
+  if (rows == 0 || n == 0) return PLAIDHIP_OK;
+  const int nblk = (n + kColBlock - 1) / kColBlock;
+  hipLaunchKernelGGL(row_ztransform_kernel, dim3((rows + 255) / 256, nblk), dim3(256), 0, ctx->stream, A, ld, rows, n,
+                     d_mean, d_ssd);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 // Group means (and optionally sums of squared deviations) of every row of A.
 // d_mean: [2][rows] (group 0, group 1); d_ssd: [2][rows] or null.  n0 / n1: group sizes.
 // ws: scratch of at least 2 * rows * ceil(n / kColBlock) doubles.

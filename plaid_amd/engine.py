@@ -278,6 +278,20 @@ def _plaid_test(self, X, y, Gp, Gi, gsetX=None, tests=7, metap_method=0):
     return out
 
 
+def _gsva(self, X, Gp, Gi, tau=0.0, rowtf="z"):
+    if rowtf != "z":
+        raise ValueError("Error: unknown row transform" if rowtf != "ecdf" else
+                         "rowtf='ecdf' is not implemented on the device")
+    X = _as_f64_fortran(X)
+    g, n = X.shape
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    check(self.lib.plaidhip_gsva(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m, float(tau), 0, _np_ptr(S)))
+    return S
+
+
+Context.gsva = _gsva
 Context.plaid_test = _plaid_test
 Context.ucell = _ucell
 Context.aucell = _aucell

@@ -172,3 +172,16 @@ plaid.test <- function(X, y, G, gsetX = NULL, tests = c("one", "two", "lm"),
   if (sort.by %in% colnames(res)) res <- res[order(res[, sort.by]), ]
   res
 }
+
+
+## replaid.gsva(), R/plaid.R:338-363: the row z-transform, the signed ranks, the power and plaid() run on the
+## device in one call; rowtf = "ecdf" keeps the reference's R code path (not on the device).
+replaid.gsva <- function(X, matG, tau = 0, rowtf = c("z", "ecdf")[1]) {
+  rowtf <- rowtf[1]
+  if (rowtf != "z") stop("Error: unknown row transform", rowtf)
+  pat <- .aligned_pattern(X, matG)
+  if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  S <- .Call("R_plaidhip_gsva", as.matrix(X), pat$Gp, pat$Gi, as.numeric(tau), PACKAGE = "plaidhip")
+  dimnames(S) <- list(colnames(matG), colnames(X))
+  S
+}

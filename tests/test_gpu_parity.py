@@ -489,3 +489,24 @@ def test_plaid_test_synthetic_and_errors(hip_ctx):
         plaid_amd.plaid_test(plaid_amd.NamedMatrix(X, rn, None), y + 1, plaid_amd.NamedMatrix(G, rn, cn))
     with pytest.raises(plaid_amd.PlaidHipError):
         hip_ctx.plaid_test(X, y * 2, Gp, Gi)                     # the C ABI checks y itself (R/plaid.R:394)
+
+
+@pytest.mark.parametrize("tau", [0, 0.5])
+def test_replaid_gsva_matches_oracle(hip_ctx, tau):
+    """replaid.gsva (R/plaid.R:338-363): row z-transform, signed ranks, / max|rank|, power, plaid(mean, normalised)"""
+    import plaid_amd
+    Xn, Gn = _small_named(False)[:2]
+    # continuous values: with few distinct values per gene many z-scores of DIFFERENT genes are equal in exact
+    # arithmetic (z only depends on the pattern), and which of them ranks first is decided by the last bit of the
+    # row mean -- in R as much as here
+    X = np.random.default_rng(4).gamma(2.0, 1.5, size=Xn.shape)
+    X[:, 3] = X[:, 2]                                               # identical samples are fine
+    X[5, :] = 1.25                                                  # a constant gene: sd 0 -> z = 0 (1e-8 guard)
+    X[7, :] = X[6, :]                                               # identical genes: exact ties in every sample
+    Xn = plaid_amd.NamedMatrix(X, Xn.rownames, Xn.colnames)
+    exp = _oracle().replaid_gsva(X, Xn.rownames, sp.csc_matrix(Gn.values), Gn.rownames, tau=tau)
+    got = plaid_amd.replaid_gsva(Xn, Gn, tau=tau)
+    assert got.rownames == Gn.colnames and got.colnames == Xn.colnames
+    close(got.values, exp)
+    with pytest.raises(ValueError):
+        plaid_amd.replaid_gsva(Xn, Gn, rowtf="ecdf")
