@@ -547,7 +547,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
     }                                                                                          \
     ++k;                                                                                       \
     next_end = __builtin_amdgcn_readfirstlane(wtile_end[k]);                                   \
-    if (last) {                                                                                \
+    if (last && ABL != 7) {                                                                    \
       mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
       mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
       mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
@@ -899,6 +899,11 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 5>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     hipLaunchKernelGGL((spmm_colpair_f64<true, 5>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (g_ablate == 7) {   // no per-tile metadata loads (tools/ only, wrong scores)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 7>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL((spmm_colpair_f64<true, 7>), dim3(grid), dim3(1024), smem, ctx->stream, a);
   } else if (g_ablate == 6) {   // index loads always hit L1 (tools/ only, wrong scores)
     a.dbg = g_dbg;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 6>),
@@ -999,7 +1004,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     // two columns per pass when X allows 16-byte loads of both columns of a pair
     const int mode = pair_kernel_mode();
     const bool aligned = (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-    const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6;
+    const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6 || g_ablate == 7;
     if (diag && mode != 0 && aligned && !gs->pair.slices.empty())
       return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags);
   }

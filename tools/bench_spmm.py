@@ -128,7 +128,7 @@ def main():
     print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
     if a.kernel == "medians":
         print("  flags words (3 = bracket misses over all launches):", flags.cpu().tolist())
-    if a.ablate == 4 or (a.ablate in (2, 5, 6) and os.environ.get('PLAIDHIP_SPMM_KERNEL') == 'pair'):
+    if a.ablate == 4 or (a.ablate in (2, 5, 6, 7) and os.environ.get('PLAIDHIP_SPMM_KERNEL') == 'pair'):
         waves = info["waves"]
         nwg = min(n, 256)
         d = dbg.cpu().numpy()[: nwg * waves * 4].reshape(nwg, waves, 4).astype(float)

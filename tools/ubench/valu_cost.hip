@@ -15,6 +15,8 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f64x2 ld2;
 #define LD2(o) (*(ld2*)(uintptr_t)(o))
 
+__device__ const uint4* g_idx;   // index chunks for MODE 13 / 14: [chunk][lane] uint4 of valid 16-byte-entry ids
+
 template <int MODE>
 __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iters) {
   extern __shared__ double lds[];
@@ -26,6 +28,19 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
   unsigned q0 = lane | ((lane + 64) << 16), q1 = (lane + 128) | ((lane + 192) << 16), q2 = (lane + 256) | ((lane + 320) << 16), q3 = (lane + 384) | ((lane + 448) << 16);
   unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
   f64x2 pv0 = {0, 0}, pv1 = {0, 0}, pv2 = {0, 0}, pv3 = {0, 0};
+  uint4 ring0 = make_uint4(0, 0, 0, 0), ring1 = ring0, ring2 = ring0, ring3 = ring0;
+  if (MODE == 13) {
+    const uint4* ib0 = g_idx + ((size_t)(threadIdx.x >> 6) * 128) * 64 + lane;
+    ring0 = ib0[0]; ring1 = ib0[64]; ring2 = ib0[128]; ring3 = ib0[192];
+  }
+  if (MODE == 14) {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(1))) const void* gptr;
+    const uint4* ib0 = g_idx + ((size_t)(threadIdx.x >> 6) * 128) * 64 + lane;
+    lds_u8* ring = (lds_u8*)(uintptr_t)(65536u + (threadIdx.x >> 6) * 4096u);
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr)(ib0 + j * 64), (__attribute__((address_space(3))) void*)(ring + j * 1024), 16, 0, 0);
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < iters; ++i) {
     if (MODE == 0) {
@@ -105,6 +120,41 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
       SDWA4_LO(o0, q0); SDWA4_HI(o1, q0); SDWA4_LO(o2, q1); SDWA4_HI(o3, q1);
       pv0 = LD2(o0); pv1 = LD2(o1); pv2 = LD2(o2); pv3 = LD2(o3);
       a0 += w0.x; a4 += w0.y; a1 += w1.x; a5 += w1.y; a2 += w2.x; a6 += w2.y; a3 += w3.x; a7 += w3.y;
+    } else if (MODE == 13) {  // pair loop + the index chunk through VGPRs (global_load_dwordx4, 4 in flight), 4 chunks per trip
+      const uint4* ib = g_idx + ((size_t)(threadIdx.x >> 6) * 128) * 64 + lane;
+#define PAIR_CHUNK(q)                                                                                     \
+      {                                                                                                    \
+        unsigned o0, o1, o2, o3, o4, o5, o6, o7;                                                           \
+        SDWA4_LO(o0, (q).x); SDWA4_HI(o1, (q).x); SDWA4_LO(o2, (q).y); SDWA4_HI(o3, (q).y);                 \
+        SDWA4_LO(o4, (q).z); SDWA4_HI(o5, (q).z); SDWA4_LO(o6, (q).w); SDWA4_HI(o7, (q).w);                 \
+        const f64x2 v0 = LD2(o0), v1 = LD2(o1), v2 = LD2(o2), v3 = LD2(o3), v4 = LD2(o4), v5 = LD2(o5), v6 = LD2(o6), v7 = LD2(o7); \
+        a0 += v0.x; a4 += v0.y; a1 += v1.x; a5 += v1.y; a2 += v2.x; a6 += v2.y; a3 += v3.x; a7 += v3.y;   \
+        a0 += v4.x; a4 += v4.y; a1 += v5.x; a5 += v5.y; a2 += v6.x; a6 += v6.y; a3 += v7.x; a7 += v7.y;   \
+      }
+      const int c0 = (i + 4) & 127;
+      PAIR_CHUNK(ring0) ring0 = ib[((c0 + 0) & 127) * 64];
+      PAIR_CHUNK(ring1) ring1 = ib[((c0 + 1) & 127) * 64];
+      PAIR_CHUNK(ring2) ring2 = ib[((c0 + 2) & 127) * 64];
+      PAIR_CHUNK(ring3) ring3 = ib[((c0 + 3) & 127) * 64];
+      i += 3;
+    } else if (MODE == 14) {  // the index chunk through LDS-DMA (global_load_lds_dwordx4) and one ds_read_b128, 4 chunks per trip
+      typedef __attribute__((address_space(3))) unsigned char lds_u8;
+      typedef __attribute__((address_space(1))) const void* gptr;
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) const u32x4_t lds_u4;
+      const uint4* ib = g_idx + ((size_t)(threadIdx.x >> 6) * 128) * 64 + lane;
+      const unsigned rb = 65536u + (threadIdx.x >> 6) * 4096u;
+      const int c0 = (i + 4) & 127;
+#define GLDS_CHUNK(slot)                                                                                  \
+      {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   /* the oldest DMA has landed */                  \
+        const u32x4_t q = *(lds_u4*)(uintptr_t)(rb + (slot) * 1024u + lane * 16u);                          \
+        PAIR_CHUNK(q)                                                                                      \
+        __builtin_amdgcn_global_load_lds((gptr)(ib + ((c0 + (slot)) & 127) * 64),                           \
+                                         (__attribute__((address_space(3))) void*)(lds_u8*)(uintptr_t)(rb + (slot) * 1024u), 16, 0, 0); \
+      }
+      GLDS_CHUNK(0) GLDS_CHUNK(1) GLDS_CHUNK(2) GLDS_CHUNK(3)
+      i += 3;
     } else if (MODE == 6) {  // ds_read only, no adds: LDS issue rate
       double v0, v1, v2, v3, v4, v5, v6, v7;
       asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
@@ -116,7 +166,7 @@ __global__ void k(double* out, unsigned* outu, unsigned long long* cyc, int iter
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + pv0.x + pv1.y + pv2.x + pv3.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + pv0.x + pv1.y + pv2.x + pv3.y + ring0.x + ring1.y + ring2.z + ring3.w;
   outu[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
@@ -127,11 +177,27 @@ void run(const char* name, int threads) {
   (void)hipMalloc(&d, 256 * 1024 * 8 * 2); (void)hipMalloc(&u, 256 * 1024 * 4 * 2); (void)hipMalloc(&c, 256 * 16 * 8);
   (void)hipMemset(d, 0, 256 * 1024 * 8);
   const int iters = 20000;
+  static uint4* d_idx = nullptr;
+  if (d_idx == nullptr) {   // 16 wavefront streams x 128 chunks x 1 KiB (2 MiB, L2-resident like the kernel's lists), ids < 4096 (64 KiB of 16-byte entries), conflict-free per 16-lane group
+    const size_t nq = (size_t)16 * 132 * 64;
+    std::vector<uint4> h(nq);
+    for (size_t c = 0; c < nq / 64; ++c)
+      for (unsigned l = 0; l < 64; ++l) {
+        unsigned id[8];
+        for (int e = 0; e < 8; ++e) id[e] = ((unsigned)((c * 8 + e) * 37u) & 0xff0u) | (l & 15u);   // slot = lane mod 16
+        h[c * 64 + l] = make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16), id[6] | (id[7] << 16));
+      }
+    (void)hipMalloc(&d_idx, nq * 16);
+    (void)hipMemcpy(d_idx, h.data(), nq * 16, hipMemcpyHostToDevice);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_idx), &d_idx, sizeof(d_idx));
+  }
+  const size_t smem = (MODE == 14) ? 65536 + 16 * 4096 : 65536;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) k<MODE><<<256, threads, 65536>>>(d, u, c, iters);   // warm the clocks
+  for (int w = 0; w < 3; ++w) k<MODE><<<256, threads, smem>>>(d, u, c, iters);   // warm the clocks
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  k<MODE><<<256, threads, 65536>>>(d, u, c, iters);
+  k<MODE><<<256, threads, smem>>>(d, u, c, iters);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(256 * threads / 64);
@@ -148,9 +214,11 @@ void run(const char* name, int threads) {
 int main() {
   // value check of the denormal trick is done by the kernel tests (addresses must match)
 
-  for (int t : {512, 1024}) {
+  for (int t : {1024}) {
     run<10>("ds_read_b128", t); run<11>("pair loop", t); run<12>("pair loop pipelined", t);
+    run<13>("pair + idx VGPR", t); run<14>("pair + idx LDS-DMA", t);
   }
+  if (getenv("UBENCH_ONLY_PAIR")) return 0;
   for (int t : {256, 512, 1024}) {
     run<0>("v_add_f64", t); run<1>("lshl_sdwa", t); run<2>("v_lshlrev", t); run<3>("v_add_f32", t);
     run<8>("min/max_f64", t); run<9>("cmp_u64+cnd", t); run<7>("mul_f32_sdwa", t); run<6>("ds_read_b64", t); run<4>("ds_read+adds", t); run<5>("fused loop", t);
