@@ -72,6 +72,12 @@ int plaidhip_device_count(int* count);
 int plaidhip_init(int device, void* stream, plaidhip_ctx** out);
 int plaidhip_finalize(plaidhip_ctx* ctx);
 int plaidhip_synchronize(plaidhip_ctx* ctx);
+/* Precision of the dense crossprod.  PLAIDHIP_PRECISION_F64 (default): fp64 storage and accumulation,
+ * scores agree with the reference to ~1e-15.  PLAIDHIP_PRECISION_MIXED (opt-in): the sample columns are
+ * staged as fp32 (2^-24 relative rounding of the inputs, ~6e-8 on the scores, inside the 1e-5 bar),
+ * sums stay fp64; applies to dense X with 8,192 < genes <= 20,448, everything else keeps fp64.        */
+enum { PLAIDHIP_PRECISION_F64 = 0, PLAIDHIP_PRECISION_MIXED = 1 };
+int plaidhip_set_precision(plaidhip_ctx* ctx, int mode);
 /* device memory helpers for hosts without a tensor library (R) */
 int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr);
 int plaidhip_free(plaidhip_ctx* ctx, void* dptr);

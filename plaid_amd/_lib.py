@@ -33,6 +33,7 @@ SIGNATURES = {
     "plaidhip_init": [_int, _vp, C.POINTER(_vp)],
     "plaidhip_finalize": [_vp],
     "plaidhip_synchronize": [_vp],
+    "plaidhip_set_precision": [_vp, _int],
     "plaidhip_malloc": [_vp, C.c_size_t, C.POINTER(_vp)],
     "plaidhip_free": [_vp, _vp],
     "plaidhip_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],

@@ -125,6 +125,13 @@ extern "C" {
 int plaidhip_version(void) { return PLAIDHIP_VERSION; }
 
 // not part of include/plaidhip.h: selects a diagnostic SpMM variant for tools/bench_spmm.py
+int plaidhip_set_precision(plaidhip_ctx* ctx, int mode) {
+  PH_CTX(ctx);
+  PH_REQUIRE(mode == PLAIDHIP_PRECISION_F64 || mode == PLAIDHIP_PRECISION_MIXED, "set_precision: unknown mode %d", mode);
+  ctx->precision = mode;
+  return PLAIDHIP_OK;
+}
+
 int plaidhip_debug_set_ablation(int mode, void* dbg) { debug_set_ablation(mode, dbg); return PLAIDHIP_OK; }
 
 const char* plaidhip_last_error_string(void) { return g_err; }

@@ -53,6 +53,7 @@ struct plaidhip_ctx {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   int num_cu = 256;
+  int precision = 0;   // PLAIDHIP_PRECISION_*: 0 fp64 throughout (default), 1 fp32 operand staging in the dense SpMM
 };
 
 // Prepared membership (built by geneset.cpp, see the header comment there).

@@ -26,7 +26,8 @@
 using namespace plaidhip;
 
 // measured on MI355X (tools/bench_spmm.py --ablate 4), see wave_weights()
-static const double kAgeShare16[4] = {1.3, 1.1, 0.9, 0.7};
+static const double kAgeShare16[4] = {1.3, 1.1, 0.9, 0.7};          // two-column fp64 kernel (pair plan)
+static const double kAgeShare16Single[4] = {1.6, 1.2, 0.8, 0.4};    // one-column plan: tuned on its main user, the mixed-precision pair kernel
 
 namespace {
 
@@ -199,9 +200,9 @@ struct HostPlan {
 // equal shares the older waves finish early and the youngest one ends up alone on the SIMD, which a
 // single wave cannot keep busy.  Shares proportional to the speed each age actually gets let all
 // waves reach the end-of-column barrier together.  PLAIDHIP_WAVE_WEIGHTS="a,b,c,d" overrides.
-void wave_weights(int waves, std::vector<double>& wt) {
+void wave_weights(int waves, std::vector<double>& wt, const double* share16) {
   double age[4] = {1.0, 1.0, 1.0, 1.0};
-  if (waves == 16) { age[0] = kAgeShare16[0]; age[1] = kAgeShare16[1]; age[2] = kAgeShare16[2]; age[3] = kAgeShare16[3]; }
+  if (waves == 16) { age[0] = share16[0]; age[1] = share16[1]; age[2] = share16[2]; age[3] = share16[3]; }
   if (const char* e = getenv("PLAIDHIP_WAVE_WEIGHTS")) {
     double a, b, c, d;
     if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4 && a > 0 && b > 0 && c > 0 && d > 0) {
@@ -213,10 +214,11 @@ void wave_weights(int waves, std::vector<double>& wt) {
 }
 
 // longest-processing-time assignment of tiles (cost[t]) to wavefronts with capacity weights
-void assign_tiles(const std::vector<int64_t>& cost, int waves, std::vector<std::vector<int32_t>>& mine) {
+void assign_tiles(const std::vector<int64_t>& cost, int waves, std::vector<std::vector<int32_t>>& mine,
+                  const double* share16) {
   const int32_t tiles = (int32_t)cost.size();
   std::vector<double> wt;
-  wave_weights(waves, wt);
+  wave_weights(waves, wt, share16);
   std::vector<int32_t> by_len(tiles);
   std::iota(by_len.begin(), by_len.end(), 0);
   std::stable_sort(by_len.begin(), by_len.end(), [&](int32_t a, int32_t b) { return cost[a] > cost[b]; });
@@ -264,7 +266,7 @@ void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, cons
   {
     std::vector<int64_t> cost(tiles);
     for (int32_t t = 0; t < tiles; ++t) cost[t] = plans[t].steps;
-    assign_tiles(cost, waves, mine);
+    assign_tiles(cost, waves, mine, kAgeShare16Single);
   }
   hp.wave_chunk_off.assign(waves + 1, 0);
   hp.wave_tile_off.assign(waves + 1, 0);
@@ -431,7 +433,7 @@ void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
   for (int si = 0; si < S; ++si)
     for (int32_t t = 0; t < tiles; ++t) tot[t] += plans[si][t].steps;
   std::vector<std::vector<int32_t>> mine;
-  assign_tiles(tot, waves, mine);
+  assign_tiles(tot, waves, mine, kAgeShare16);
   pp.wave_tile_off.assign(waves + 1, 0);
   std::vector<int32_t> ktile;   // wave-stream order -> tile
   for (int w = 0; w < waves; ++w) {

@@ -831,6 +831,216 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   return PLAIDHIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Mixed-precision pair kernel (opt-in, plaidhip_set_precision(ctx, PLAIDHIP_PRECISION_MIXED)):
+// the two sample columns of a pair are staged in LDS as FLOATS, 8 bytes {A_i, B_i} per gene, so the
+// whole 20k-gene pair fits the LDS (no gene slices, no partial sums) and one ds_read_b64 serves two
+// scores -- a quarter of the LDS bytes per score of the fp64 one-column kernel.  The eight values a
+// lane gathers per chunk are summed with packed fp32 adds (four terms per partial sum) and the
+// chunk's partials are added to fp64 accumulators, so the only precision given up is the rounding of
+// the inputs to fp32 (2^-24 relative per value, ~6e-8 on the scores; the fp64 kernels stay the
+// default and the parity reference).  Same host schedule as the one-column kernel (32-lane halves
+// of ds_read_b64 against 32 bank pairs), same per-wave tile streams and epilogue.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x2 lds_cf32x2;
+__device__ __forceinline__ f32x2 lds_f32x2_at(uint32_t byte_off) {
+  return *reinterpret_cast<lds_cf32x2*>(static_cast<uintptr_t>(byte_off));
+}
+
+__global__ void __launch_bounds__(1024)
+spmm_colpair_mixed(SpmmArgs a) {
+  constexpr int BLOCK = 1024;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  f32x2* ent = reinterpret_cast<f32x2*>(smem_raw);
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t f = 0;
+  const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
+  const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
+  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
+  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
+  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+  const int g2 = a.g >> 1;
+  const int npairs = (a.n + 1) >> 1;
+  // next pair, as loaded: 10 x 16 bytes of column A and of column B per thread
+  f64x2 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pa8, pa9, pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7, pb8, pb9;
+  pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pa6 = pa7 = pa8 = pa9 = f64x2{0.0, 0.0};
+  pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = pb8 = pb9 = f64x2{0.0, 0.0};
+#define PLAIDHIP_ITEMS10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+#define PLAIDHIP_PF_ONE(k)                                                                          \
+  if ((k + 1) * BLOCK <= g2) {                                                                      \
+    pa##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xa_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+    pb##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xb_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+  } else {                                                                                          \
+    pa##k = pb##k = f64x2{0.0, 0.0};                                                                \
+    if (k * BLOCK < g2 && tid + k * BLOCK < g2) {                                                   \
+      pa##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xa_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+      pb##k = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xb_ + (size_t)k * BLOCK * 16 + lane_off16)); \
+    }                                                                                               \
+  }
+#define PLAIDHIP_PREFETCH(pp_)                                                                      \
+  do {                                                                                              \
+    uint32_t lane_off16 = (uint32_t)tid * 16u;                                                      \
+    asm volatile("" : "+v"(lane_off16));                                                            \
+    const int ca_ = 2 * (pp_);                                                                      \
+    const int cb_ = (ca_ + 1 < a.n) ? ca_ + 1 : ca_;                                                \
+    const char* xa_ = reinterpret_cast<const char*>(a.X + (int64_t)ca_ * a.ldx);                    \
+    const char* xb_ = reinterpret_cast<const char*>(a.X + (int64_t)cb_ * a.ldx);                    \
+    PLAIDHIP_ITEMS10(PLAIDHIP_PF_ONE)                                                               \
+  } while (0)
+#define PLAIDHIP_ST_ONE(k)                                                                          \
+  if (k * BLOCK < g2) {                                                                             \
+    const int i_ = tid_o + k * BLOCK;                                                               \
+    if (i_ < g2)                                                                                    \
+      ent4[i_] = f32x4{(float)pa##k.x, (float)pb##k.x, (float)pa##k.y, (float)pb##k.y};             \
+  }
+
+  int p = blockIdx.x;
+  if (p < npairs) PLAIDHIP_PREFETCH(p);
+  for (; p < npairs; p += gridDim.x) {
+    const int cA = 2 * p;
+    const bool hasB = cA + 1 < a.n;
+    const int cB = hasB ? cA + 1 : cA;
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    {
+      f32x4* ent4 = reinterpret_cast<f32x4*>(smem_raw);
+      PLAIDHIP_ITEMS10(PLAIDHIP_ST_ONE)
+      if ((a.g & 1) && tid == 0)
+        ent[a.g - 1] = f32x2{(float)a.X[(int64_t)cA * a.ldx + a.g - 1], (float)a.X[(int64_t)cB * a.ldx + a.g - 1]};
+      if (tid < kPadSlots) ent[a.g + tid] = f32x2{0.0f, 0.0f};
+    }
+    __syncthreads();
+    const int np = p + gridDim.x;
+    const bool want_pf = np < npairs;
+
+    if (ch_begin < ch_end) {
+      const char* ibase = reinterpret_cast<const char*>(a.tile_idx) + (int64_t)ch_begin * 1024;  // uniform
+      uint32_t lane_o = (uint32_t)lane;
+      asm volatile("" : "+v"(lane_o));
+      const uint32_t ioff = lane_o * 16u;
+      const uint32_t moff4 = lane_o * 4u, moff8 = lane_o * 8u;
+#define PLAIDHIP_LOADQ(rel) (*reinterpret_cast<const uint4*>(ibase + (int64_t)(rel) * 1024 + ioff))
+#define PLAIDHIP_GATHER8(q)                                                  \
+  v0 = lds_f32x2_at(off_lo((q).x)); v1 = lds_f32x2_at(off_hi((q).x));         \
+  v2 = lds_f32x2_at(off_lo((q).y)); v3 = lds_f32x2_at(off_hi((q).y));         \
+  v4 = lds_f32x2_at(off_lo((q).z)); v5 = lds_f32x2_at(off_hi((q).z));         \
+  v6 = lds_f32x2_at(off_lo((q).w)); v7 = lds_f32x2_at(off_hi((q).w));
+      // packed fp32 partial sums of four values each, folded into the fp64 accumulators per chunk
+#define PLAIDHIP_ADD8                                                        \
+  {                                                                          \
+    const f32x2 s0_ = (v0 + v1) + (v2 + v3);                                 \
+    const f32x2 s1_ = (v4 + v5) + (v6 + v7);                                 \
+    dA0 += (double)s0_.x; dB0 += (double)s0_.y;                              \
+    dA1 += (double)s1_.x; dB1 += (double)s1_.y;                              \
+  }
+#define PLAIDHIP_EPI(sum, cc)                                                  \
+  {                                                                            \
+    const double w_ = is_mean ? mw : 1.0;                                      \
+    const double v_ = alpha * ((sum) * w_) + a.beta * (mk * w_);               \
+    if (a.nt_store) __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);  \
+    else a.S[(int64_t)(cc) * a.lds + mj] = v_;                                 \
+    f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                              \
+    f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                            \
+    f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                              \
+  }
+#define PLAIDHIP_TILE_END(chv)                                                                 \
+  if ((chv) + 1 == next_end) { /* wave-uniform: tile finished -> epilogue */                   \
+    if (mj >= 0) {                                                                             \
+      PLAIDHIP_EPI(dA0 + dA1, cA)                                                              \
+      if (hasB) PLAIDHIP_EPI(dB0 + dB1, cB)                                                    \
+    }                                                                                          \
+    ++k;                                                                                       \
+    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
+    mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
+    mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
+    mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
+    dA0 = dA1 = dB0 = dB1 = 0.0;                                                               \
+  }
+      uint4 qa = PLAIDHIP_LOADQ(0);
+      uint4 qb = PLAIDHIP_LOADQ(1);
+      uint4 qc = PLAIDHIP_LOADQ(2);
+      uint4 qd = PLAIDHIP_LOADQ(3);
+      int k = tk_begin;
+      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
+      double dA0 = 0.0, dA1 = 0.0, dB0 = 0.0, dB1 = 0.0;
+      int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
+      double mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);
+      double mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
+      f32x2 v0, v1, v2, v3, v4, v5, v6, v7;
+      int ch = ch_begin;
+      ibase += 4 * 1024;
+      for (; ch + 3 < ch_end; ch += 4, ibase += 4 * 1024) {
+        PLAIDHIP_GATHER8(qa)
+        qa = PLAIDHIP_LOADQ(0);
+        PLAIDHIP_ADD8
+        PLAIDHIP_TILE_END(ch)
+        PLAIDHIP_GATHER8(qb)
+        qb = PLAIDHIP_LOADQ(1);
+        PLAIDHIP_ADD8
+        PLAIDHIP_TILE_END(ch + 1)
+        PLAIDHIP_GATHER8(qc)
+        qc = PLAIDHIP_LOADQ(2);
+        PLAIDHIP_ADD8
+        PLAIDHIP_TILE_END(ch + 2)
+        PLAIDHIP_GATHER8(qd)
+        qd = PLAIDHIP_LOADQ(3);
+        PLAIDHIP_ADD8
+        PLAIDHIP_TILE_END(ch + 3)
+      }
+      if (ch < ch_end) { PLAIDHIP_GATHER8(qa) PLAIDHIP_ADD8 PLAIDHIP_TILE_END(ch) ++ch; }
+      if (ch < ch_end) { PLAIDHIP_GATHER8(qb) PLAIDHIP_ADD8 PLAIDHIP_TILE_END(ch) ++ch; }
+      if (ch < ch_end) { PLAIDHIP_GATHER8(qc) PLAIDHIP_ADD8 PLAIDHIP_TILE_END(ch) ++ch; }
+#undef PLAIDHIP_GATHER8
+#undef PLAIDHIP_ADD8
+#undef PLAIDHIP_TILE_END
+#undef PLAIDHIP_EPI
+#undef PLAIDHIP_LOADQ
+    }
+    if (want_pf) {
+      PLAIDHIP_PREFETCH(np);
+    } else {
+      pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pa6 = pa7 = pa8 = pa9 = f64x2{0.0, 0.0};
+      pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = pb8 = pb9 = f64x2{0.0, 0.0};
+    }
+    __syncthreads();  // the pair is overwritten by the next iteration
+  }
+  publish_flags(f, a.flags);
+#undef PLAIDHIP_PREFETCH
+#undef PLAIDHIP_PF_ONE
+#undef PLAIDHIP_ST_ONE
+#undef PLAIDHIP_ITEMS10
+}
+
+static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs a) {
+  const plaidhip_slice& sl = gs->slices[0];
+  a.g = sl.gs;
+  a.g0 = 0;
+  a.acc_mode = 0;
+  a.tile_idx = reinterpret_cast<const uint4*>(sl.d_tile_idx);
+  a.wave_chunk_off = sl.d_wave_chunk_off;
+  a.wave_tile_off = sl.d_wave_tile_off;
+  a.wtile_end = sl.d_wtile_end;
+  a.meta_j = sl.d_meta_j;
+  a.meta_w = sl.d_meta_w;
+  a.meta_k = sl.d_meta_k;
+  const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
+  PH_FULL_LDS(ctx, (&spmm_colpair_mixed));
+  int grid = ctx->num_cu;
+  const int npairs = (a.n + 1) / 2;
+  if (grid > npairs) grid = npairs;
+  hipLaunchKernelGGL(spmm_colpair_mixed, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 
@@ -1000,6 +1210,15 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
+  if (ctx->precision == PLAIDHIP_PRECISION_MIXED && g_ablate == 0 && (ldx & 1) == 0 &&
+      (reinterpret_cast<uintptr_t>(X) & 15) == 0 && gs->slices.size() == 1 && gs->slices[0].waves == 16) {
+    // opt-in: fp32 operand staging (plaidhip_set_precision); one gene slice and the 1024-thread schedule only
+    SpmmArgs a{};
+    a.X = X;
+    a.ldx = ldx;
+    fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+    return launch_colpair_mixed(ctx, gs, a);
+  }
   {
     // two columns per pass when X allows 16-byte loads of both columns of a pair
     const int mode = pair_kernel_mode();

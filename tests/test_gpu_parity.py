@@ -510,3 +510,34 @@ def test_replaid_gsva_matches_oracle(hip_ctx, tau):
     close(got.values, exp)
     with pytest.raises(ValueError):
         plaid_amd.replaid_gsva(Xn, Gn, rowtf="ecdf")
+
+
+def test_spmm_mixed_precision_mode_is_opt_in_and_within_the_bar():
+    """plaidhip_set_precision(MIXED): the dense crossprod stages the sample columns as fp32 (sums stay fp64).
+    Scores must stay within the 1e-5 relative bar of BASELINE.json (here: elementwise rtol 1e-5 with
+    atol 1e-7 for centred scores that cancel towards 0; matrix-relative error ~1e-7), it must really be a
+    different path (not bit-identical to fp64), and the default must stay exact fp64."""
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, n, m = 20000, 33, 700
+    Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    po = _oracle()
+    ctx = plaid_amd.Context(0)
+    exact = ctx.plaid_dense(X, Gp, Gi, "mean", False)
+    ctx.set_precision("mixed")
+    mixed = ctx.plaid_dense(X, Gp, Gi, "mean", False)
+    ref = po.plaid(X, rn, G, rn, normalize=False)
+    np.testing.assert_allclose(exact, ref, rtol=1e-12)
+    np.testing.assert_allclose(mixed, ref, rtol=1e-5, atol=0)
+    rel = np.abs(mixed - ref) / np.abs(ref)
+    assert 0 < rel.max() < 2e-7                                   # fp32 input rounding: 2^-24 = 6e-8 per value
+    assert np.linalg.norm(mixed - ref) / np.linalg.norm(ref) < 1e-7
+    np.testing.assert_allclose(ctx.plaid_dense(X, Gp, Gi, "sum", True), po.plaid(X, rn, G, rn, stats="sum"), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(ctx.sing_dense(X, Gp, Gi), po.replaid_sing(X, rn, G, rn), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ctx.ssgsea_dense(X, Gp, Gi, 0.25), po.replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-5, atol=1e-7)
+    ctx.set_precision("f64")
+    assert np.array_equal(ctx.plaid_dense(X, Gp, Gi, "mean", False), exact)
+    ctx.close()

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--sets", type=int, default=5000)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ties", default="average")
+    ap.add_argument("--precision", default="f64", choices=["f64", "mixed"])
     ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..3 (wrong results by design)")
     a = ap.parse_args()
@@ -27,6 +28,7 @@ def main():
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     ctx = plaid_amd.Context(0, stream.cuda_stream)
+    ctx.set_precision(a.precision)
     dbg = None
     if a.ablate:
         import ctypes
