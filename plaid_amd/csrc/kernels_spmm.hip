@@ -28,6 +28,10 @@
 
 namespace plaidhip {
 
+// diagnostic kernel variants (tools/ only, plaidhip_debug_set_ablation)
+static int g_ablate = 0;
+static unsigned long long* g_dbg = nullptr;
+
 struct SpmmArgs {
   const double* X;
   int64_t ldx;
@@ -849,9 +853,12 @@ __device__ __forceinline__ f32x2 lds_f32x2_at(uint32_t byte_off) {
   return *reinterpret_cast<lds_cf32x2*>(static_cast<uintptr_t>(byte_off));
 }
 
+template <bool STAMP>
 __global__ void __launch_bounds__(1024)
 spmm_colpair_mixed(SpmmArgs a) {
   constexpr int BLOCK = 1024;
+  unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
+  if constexpr (STAMP) t_all0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) unsigned char smem_raw[];
   f32x2* ent = reinterpret_cast<f32x2*>(smem_raw);
   {
@@ -910,6 +917,8 @@ spmm_colpair_mixed(SpmmArgs a) {
     const int cB = hasB ? cA + 1 : cA;
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o));
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
     {
       f32x4* ent4 = reinterpret_cast<f32x4*>(smem_raw);
       PLAIDHIP_ITEMS10(PLAIDHIP_ST_ONE)
@@ -918,6 +927,7 @@ spmm_colpair_mixed(SpmmArgs a) {
       if (tid < kPadSlots) ent[a.g + tid] = f32x2{0.0f, 0.0f};
     }
     __syncthreads();
+    if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
     const int np = p + gridDim.x;
     const bool want_pf = np < npairs;
 
@@ -1010,7 +1020,20 @@ spmm_colpair_mixed(SpmmArgs a) {
       pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pa6 = pa7 = pa8 = pa9 = f64x2{0.0, 0.0};
       pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = pb8 = pb9 = f64x2{0.0, 0.0};
     }
+    if constexpr (STAMP) ts2 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the pair is overwritten by the next iteration
+    if constexpr (STAMP) {
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      t_stage += ts1 - ts0;
+      t_gather += ts2 - ts1;
+      t_wait += ts3 - ts2;
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && a.dbg != nullptr) {
+      unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (BLOCK / 64) + wave) * 4;
+      d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
+    }
   }
   publish_flags(f, a.flags);
 #undef PLAIDHIP_PREFETCH
@@ -1032,17 +1055,22 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
   a.meta_w = sl.d_meta_w;
   a.meta_k = sl.d_meta_k;
   const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
-  PH_FULL_LDS(ctx, (&spmm_colpair_mixed));
+  PH_FULL_LDS(ctx, (&spmm_colpair_mixed<false>));
   int grid = ctx->num_cu;
   const int npairs = (a.n + 1) / 2;
   if (grid > npairs) grid = npairs;
-  hipLaunchKernelGGL(spmm_colpair_mixed, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
+    a.dbg = g_dbg;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_mixed<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL(spmm_colpair_mixed<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL(spmm_colpair_mixed<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }
 
-static int g_ablate = 0;
-static unsigned long long* g_dbg = nullptr;
 
 static int nt_store_mode(const plaidhip_geneset* gs) {
   if (const char* e = getenv("PLAIDHIP_NT_STORE")) return atoi(e) != 0;
@@ -1210,7 +1238,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (ctx->precision == PLAIDHIP_PRECISION_MIXED && g_ablate == 0 && (ldx & 1) == 0 &&
+  if (ctx->precision == PLAIDHIP_PRECISION_MIXED && (g_ablate == 0 || g_ablate == 4) && (ldx & 1) == 0 &&
       (reinterpret_cast<uintptr_t>(X) & 15) == 0 && gs->slices.size() == 1 && gs->slices[0].waves == 16) {
     // opt-in: fp32 operand staging (plaidhip_set_precision); one gene slice and the 1024-thread schedule only
     SpmmArgs a{};
