@@ -855,32 +855,136 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
   const int nwaves = gridDim.x * 4;
   for (int c = blockIdx.x * 4 + wave; c < n; c += nwaves) {
     const double* sc = S + (int64_t)c * lds;
-    // ---- sweep 0: range of the keys' high words and the number of unmasked entries ---------
-    uint32_t hmin = 0xffffffffu, hmax = 0u, cnt = 0;
-    sweep_column(sc, m, ignore_zero, lane, [&](const Key32& k) {
-      const bool valid = k.hi != 0xffffffffu;      // no valid key has an all-ones high word
+    uint32_t cnt = 0, k_lo = 0, k_hi = 0, k = 0, count = 0;
+    uint64_t lo = 0;
+    int B = 0;
+    bool seeded = false;
+    // ---- sampled start (large columns): a 512-entry sample (8 chunks spread over the column) gives a key
+    //      interval around the middle rank, 4 sigma of a sample quantile either side; ONE sweep then counts the
+    //      valid keys, the keys below the interval and a 256-bin histogram inside it, which replaces the min/max
+    //      sweep and the first two histogram sweeps of the generic path.  If the interval misses the middle
+    //      rank (probability ~1e-4 per column for exchangeable data) the generic path starts from scratch.
+    if (m > 4 * CAP) {
+      uint32_t ns = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int64_t i = (int64_t)u * m / 8 + lane;
+        i = i < m ? i : m - 1;
+        const Key32 kk = masked_key32(sc[i], ignore_zero);
+        const bool valid = kk.hi != 0xffffffffu;
+        const unsigned long long bal = __ballot(valid);
+        if (valid)
+          list[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+              ((unsigned long long)kk.hi << 32) | kk.lo;
+        ns += (uint32_t)__popcll(bal);
+      }
+      const uint32_t mid = ns > 0 ? (ns - 1u) >> 1 : 0u;
+      const uint32_t w = 2u * (uint32_t)sqrtf((float)ns) + 2u;      // 4 sigma of a sample quantile's rank
+      if (ns >= 256u && mid > w && mid + 1u + w < ns - 1u) {
+        uint32_t N = 2;
+        while (N < ns) N <<= 1;
+        for (uint32_t i = ns + lane; i < N; i += 64) list[i] = ~0ull;
+        wave_lds_sync();
+        for (uint32_t kk2 = 2; kk2 <= N; kk2 <<= 1)
+          for (uint32_t j = kk2 >> 1; j >= 1; j >>= 1) {
+            for (uint32_t t = lane; t < (N >> 1); t += 64) {
+              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const uint32_t p2 = i | j;
+              const bool up = (i & kk2) == 0;
+              const unsigned long long x = list[i], y = list[p2];
+              if ((x > y) == up) { list[i] = y; list[p2] = x; }
+            }
+            wave_lds_sync();
+          }
+        const uint64_t qa = list[mid - w], qb = list[mid + 1u + w];
+        wave_lds_sync();
+        const int Bw = qb == qa ? 1 : 64 - __clzll((long long)(qb - qa));   // [qa, qa + 2^Bw - 1] covers [qa, qb]
+        RangeTest rt;
+        rt.lohi = (uint32_t)(qa >> 32);
+        rt.lolo = (uint32_t)qa;
+        rt.shift = Bw > 8 ? Bw - 8 : 0;
+        rt.nbins = 1u << (Bw - rt.shift);
+        uint32_t below = 0;
+        sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
+          const bool valid = key.hi != 0xffffffffu;
+          cnt += valid ? 1u : 0u;
+          below += (valid && ((key.hi < rt.lohi) | ((key.hi == rt.lohi) & (key.lo < rt.lolo)))) ? 1u : 0u;
+          const uint32_t b = rt.bin(key);
+          if (b != 0xffffffffu) atomicAdd(&hist[b], 1u);
+        });
+        for (int off = 32; off >= 1; off >>= 1) {
+          cnt += __shfl_xor(cnt, off, 64);
+          below += __shfl_xor(below, off, 64);
+        }
+        cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+        below = (uint32_t)__builtin_amdgcn_readfirstlane((int)below);
+        wave_lds_sync();
+        const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
+        *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
+        const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
+        }
+        const uint32_t inside = (uint32_t)__shfl((int)incl, 63, 64);
+        if (cnt > 0u) {
+          k_lo = (cnt - 1u) >> 1;
+          k_hi = cnt >> 1;
+          if (below <= k_lo && k_lo - below < inside) {
+            k = k_lo - below;
+            uint32_t excl = incl - mine;
+            const bool owner = mine != 0 && excl <= k && k < incl;
+            uint32_t d = 0, hh = h4.x;
+            if (k >= excl + h4.x) { excl += h4.x; d = 1; hh = h4.y;
+              if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
+                if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
+            const int src = (int)__builtin_ctzll(__ballot(owner));
+            const uint32_t dsel = (uint32_t)__shfl((int)((uint32_t)lane * 4u + d), src, 64);
+            k -= (uint32_t)__shfl((int)excl, src, 64);
+            count = (uint32_t)__shfl((int)hh, src, 64);
+            lo = qa + ((uint64_t)dsel << rt.shift);
+            B = rt.shift;
+            seeded = true;
+          }
+        }
+      } else {
+        wave_lds_sync();
+      }
+    }
+    if (!seeded) {
+    // ---- generic start, sweep 0: range of the keys' high words and the number of unmasked entries ---------
+    uint32_t hmin = 0xffffffffu, hmax = 0u;
+    cnt = 0;
+    sweep_column(sc, m, ignore_zero, lane, [&](const Key32& k_) {
+      const bool valid = k_.hi != 0xffffffffu;      // no valid key has an all-ones high word
       cnt += valid ? 1u : 0u;
-      hmin = k.hi < hmin ? k.hi : hmin;            // (a masked key never lowers the minimum)
-      hmax = (valid && k.hi > hmax) ? k.hi : hmax;
+      hmin = k_.hi < hmin ? k_.hi : hmin;            // (a masked key never lowers the minimum)
+      hmax = (valid && k_.hi > hmax) ? k_.hi : hmax;
     });
     for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t a = __shfl_xor(hmin, off, 64), b = __shfl_xor(hmax, off, 64);
-      hmin = a < hmin ? a : hmin;
-      hmax = b > hmax ? b : hmax;
+      const uint32_t a_ = __shfl_xor(hmin, off, 64), b_ = __shfl_xor(hmax, off, 64);
+      hmin = a_ < hmin ? a_ : hmin;
+      hmax = b_ > hmax ? b_ : hmax;
       cnt += __shfl_xor(cnt, off, 64);
     }
     cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
     hmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmin);
     hmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmax);
+    if (cnt != 0u) {
+      k_lo = (cnt - 1) >> 1;
+      k_hi = cnt >> 1;
+      lo = (uint64_t)hmin << 32;
+      B = 32 + (hmax == hmin ? 0 : 32 - __clz((int)(hmax - hmin)));   // interval [lo, lo + 2^B - 1] holds every key
+      k = k_lo;       // rank wanted inside the interval
+      count = cnt;    // keys inside the interval
+    }
+    }
     double r;
     if (cnt == 0) {
       r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
     } else {
-      const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
-      uint64_t lo = (uint64_t)hmin << 32;
-      int B = 32 + (hmax == hmin ? 0 : 32 - __clz((int)(hmax - hmin)));   // interval [lo, lo + 2^B - 1] holds every key
-      uint32_t k = k_lo;       // rank wanted inside the interval
-      uint32_t count = cnt;    // keys inside the interval
       // ---- histogram sweeps until the interval fits the list ------------------------------
       while (B != 0 && count > (uint32_t)CAP) {
         RangeTest rt;
@@ -1016,9 +1120,9 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   const bool want_sort = force && force[0] == 's' && force[1] == 'o';
   const bool want_select = force && force[0] == 's' && force[1] == 'e';
   const bool want_bits = force && force[0] == 'b';
-  const bool want_radix = (force && force[0] == 'r') || (!force && m <= 16384);
+  const bool want_radix = (force && force[0] == 'r') || (!force && m <= 6144);
   const bool want_sample = force && force[0] == 's' && force[1] == 'a';
-  const bool want_stream = (force && force[0] == 's' && force[1] == 't') || (!force && m > 16384);
+  const bool want_stream = (force && force[0] == 's' && force[1] == 't') || (!force && m > 6144);
   if (want_stream) {
     const int cap = ctx->num_cu * 8;                      // 8 workgroups x 4 wavefronts per CU
     const int need = (n + 3) / 4;
