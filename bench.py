@@ -136,7 +136,7 @@ def main():
     # ---- secondary, reported beside the headline, never in `value`: the opt-in mixed-precision crossprod
     #      (sample columns staged as fp32 in LDS, sums fp64), same workload, same step ---------------------
     mixed = None
-    if not a.no_mixed:
+    if not a.no_mixed and world == 1:   # N = 1 only, like cpu_baseline: no collective may depend on an optional block
         try:
             ctx.set_precision("mixed")
             msteps = max(3, min(a.steps, 10))
