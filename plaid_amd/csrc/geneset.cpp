@@ -26,7 +26,7 @@
 using namespace plaidhip;
 
 // measured on MI355X (tools/bench_spmm.py --ablate 4), see wave_weights()
-static const double kAgeShare16[4] = {1.3, 1.1, 0.9, 0.7};          // two-column fp64 kernel (pair plan)
+static const double kAgeShare16[4] = {1.6, 1.2, 0.8, 0.4};          // two-column fp64 kernel (pair plan): 0.988 -> 0.970 ms vs 1.3/1.1/0.9/0.7
 static const double kAgeShare16Single[4] = {1.6, 1.2, 0.8, 0.4};    // one-column plan: tuned on its main user, the mixed-precision pair kernel
 
 namespace {
