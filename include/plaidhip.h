@@ -209,10 +209,10 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                   int remove_log2, int score_mean, double* S_out);
 
-/* replaid.gsva(X, matG, tau, rowtf), R/plaid.R:338-363, dense X: row z-transform (rowtf = 0, "z";
- * the "ecdf" variant is not implemented on the device: PLAIDHIP_EINVAL), signed average ranks per
- * sample, / max|rank|, sign * |.|^(1 + tau) for tau > 0, then plaid(mean, normalised).  The row
- * statistics need every sample, so this call does not shard by sample.                           */
+/* replaid.gsva(X, matG, tau, rowtf), R/plaid.R:338-363, dense X: row transform (rowtf = 0: "z",
+ * center + scale per gene; 1: "ecdf", the per-gene empirical CDF), signed average ranks per sample,
+ * / max|rank|, sign * |.|^(1 + tau) for tau > 0, then plaid(mean, normalised).  The row transform
+ * needs every sample of a gene, so this call does not shard by sample.                           */
 int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* Gp,
                   const int32_t* Gi, int32_t m, double tau, int rowtf, double* S_out);
 

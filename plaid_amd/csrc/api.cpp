@@ -828,7 +828,7 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   PH_TRY(check_host_common(Gp, g, n, m));
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X && S_out, "gsva: null X/S_out");
-  PH_REQUIRE(rowtf == 0, "Error: unknown row transform (only \"z\" runs on the device)");   // R/plaid.R:348
+  PH_REQUIRE(rowtf == 0 || rowtf == 1, "Error: unknown row transform %d", rowtf);                   // R/plaid.R:348
   GenesetHolder gh;
   PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
   const int64_t ldg = even_ld(g);
@@ -847,10 +847,20 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   double* d_gmax = d_red + 2;
   PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   PH_HIP(hipMemsetAsync(dy.p, 0, (size_t)n * 4, ctx->stream));                         // one group: every sample
-  // zX = (X - rowMeans(X)) / (1e-8 + rowSds(X))                                       (R/plaid.R:341-343)
-  PH_TRY(launch_row_group_moments(ctx, dX.as<double>(), ldg, g, n, dy.as<int32_t>(), n, 0, dmom.as<double>(),
-                                  dmom.as<double>() + 2 * (size_t)g, dws.as<double>()));
-  PH_TRY(launch_row_ztransform(ctx, dX.as<double>(), ldg, g, n, dmom.as<double>(), dmom.as<double>() + 2 * (size_t)g));
+  if (rowtf == 0) {
+    // zX = (X - rowMeans(X)) / (1e-8 + rowSds(X))                                     (R/plaid.R:341-343)
+    PH_TRY(launch_row_group_moments(ctx, dX.as<double>(), ldg, g, n, dy.as<int32_t>(), n, 0, dmom.as<double>(),
+                                    dmom.as<double>() + 2 * (size_t)g, dws.as<double>()));
+    PH_TRY(launch_row_ztransform(ctx, dX.as<double>(), ldg, g, n, dmom.as<double>(), dmom.as<double>() + 2 * (size_t)g));
+  } else {
+    // zX = t(apply(X, 1, function(x) ecdf(x)(x)))  (:346): ecdf(x)(x_i) = #{x <= x_i} / n = rank(x, "max") / n per
+    // gene.  Genes become columns (transpose), the column rank kernel ranks them, and the result goes back; the
+    // factor 1/n is dropped because only the per-sample ORDER of zX is used afterwards (:352).
+    PH_TRY(launch_transpose_f64(ctx, dX.as<double>(), ldg, g, n, dR.as<double>(), n));              // dR: n x g
+    PH_TRY(launch_colranks_dense_f64(ctx, dR.as<double>(), n, n, g, PLAIDHIP_TIES_MAX, 0, 1.0, dX.as<double>(), n, nullptr));
+    PH_TRY(launch_transpose_f64(ctx, dX.as<double>(), n, n, g, dR.as<double>(), ldg));              // dR: g x n
+    PH_HIP(hipMemcpyAsync(dX.p, dR.p, (size_t)ldg * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   // rX = colranks(zX, signed = TRUE, "average"); rX / max|rX|; sign * |rX|^(1 + tau)   (:352-358)
   //    = sign * rank^(1+tau) / max(rank^(1+tau)): the power is fused into the rank kernel, the division into the
   //    SpMM epilogue (alpha_div), by linearity of the mean statistic

@@ -155,6 +155,8 @@ int launch_row_group_moments(plaidhip_ctx* ctx, const double* A, int64_t ld, int
                              double* ws);
 int launch_row_ztransform(plaidhip_ctx* ctx, double* A, int64_t ld, int32_t rows, int32_t n, const double* d_mean,
                           const double* d_ssd);
+int launch_transpose_f64(plaidhip_ctx* ctx, const double* A, int64_t lda, int32_t rows, int32_t cols, double* B,
+                         int64_t ldb);
 int launch_fold_change(plaidhip_ctx* ctx, const double* d_mean, int32_t rows, int64_t ld2, double* d_F);
 int64_t row_group_ws_doubles(int32_t rows, int32_t n);
 double onesample_p(double k, double s1, double s2, double* mean_out);

@@ -109,6 +109,35 @@ int launch_row_ztransform(plaidhip_ctx* ctx, double* A, int64_t ld, int32_t rows
   return PLAIDHIP_OK;
 }
 
+// B (cols x rows, ldb) = transpose of A (rows x cols, lda), both column-major; 32 x 32 tiles through LDS
+// (+1 padding), coalesced on both sides.  Used by the ECDF row transform of replaid.gsva, which needs
+// per-GENE ranks across samples (R/plaid.R:346): genes become columns, the column rank kernel does the rest.
+__global__ void __launch_bounds__(256)
+transpose_f64_kernel(const double* __restrict__ A, int64_t lda, int32_t rows, int32_t cols,
+                     double* __restrict__ B, int64_t ldb) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + tx, c = c0 + j;
+    if (r < rows && c < cols) tile[j][tx] = A[(int64_t)c * lda + r];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + tx, r = r0 + j;
+    if (r < rows && c < cols) B[(int64_t)r * ldb + c] = tile[tx][j];
+  }
+}
+
+int launch_transpose_f64(plaidhip_ctx* ctx, const double* A, int64_t lda, int32_t rows, int32_t cols, double* B,
+                         int64_t ldb) {
+  if (rows == 0 || cols == 0) return PLAIDHIP_OK;
+  hipLaunchKernelGGL(transpose_f64_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, ctx->stream, A, lda,
+                     rows, cols, B, ldb);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 // Group means (and optionally sums of squared deviations) of every row of A.
 // d_mean: [2][rows] (group 0, group 1); d_ssd: [2][rows] or null.  n0 / n1: group sizes.
 // ws: scratch of at least 2 * rows * ceil(n / kColBlock) doubles.

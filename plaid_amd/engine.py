@@ -284,15 +284,15 @@ def _plaid_test(self, X, y, Gp, Gi, gsetX=None, tests=7, metap_method=0):
 
 
 def _gsva(self, X, Gp, Gi, tau=0.0, rowtf="z"):
-    if rowtf != "z":
-        raise ValueError("Error: unknown row transform" if rowtf != "ecdf" else
-                         "rowtf='ecdf' is not implemented on the device")
+    if rowtf not in ("z", "ecdf"):
+        raise ValueError("Error: unknown row transform" + str(rowtf))          # R/plaid.R:348
     X = _as_f64_fortran(X)
     g, n = X.shape
     Gp, Gi = _as_i32(Gp), _as_i32(Gi)
     m = len(Gp) - 1
     S = np.empty((m, n), dtype=np.float64, order="F")
-    check(self.lib.plaidhip_gsva(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m, float(tau), 0, _np_ptr(S)))
+    check(self.lib.plaidhip_gsva(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m, float(tau),
+                                 0 if rowtf == "z" else 1, _np_ptr(S)))
     return S
 
 

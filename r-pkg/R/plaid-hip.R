@@ -174,14 +174,14 @@ plaid.test <- function(X, y, G, gsetX = NULL, tests = c("one", "two", "lm"),
 }
 
 
-## replaid.gsva(), R/plaid.R:338-363: the row z-transform, the signed ranks, the power and plaid() run on the
-## device in one call; rowtf = "ecdf" keeps the reference's R code path (not on the device).
+## replaid.gsva(), R/plaid.R:338-363: the row transform ("z" or "ecdf"), the signed ranks, the power and
+## plaid() run on the device in one call.
 replaid.gsva <- function(X, matG, tau = 0, rowtf = c("z", "ecdf")[1]) {
   rowtf <- rowtf[1]
-  if (rowtf != "z") stop("Error: unknown row transform", rowtf)
+  if (!rowtf %in% c("z", "ecdf")) stop("Error: unknown row transform", rowtf)
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
-  S <- .Call("R_plaidhip_gsva", as.matrix(X), pat$Gp, pat$Gi, as.numeric(tau), PACKAGE = "plaidhip")
+  S <- .Call("R_plaidhip_gsva", as.matrix(X), pat$Gp, pat$Gi, as.numeric(tau), as.integer(rowtf == "ecdf"), PACKAGE = "plaidhip")
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }

@@ -195,10 +195,10 @@ SEXP R_plaidhip_plaid_test(SEXP X, SEXP y, SEXP Gp, SEXP Gi, SEXP gsetX, SEXP te
 }
 
 
-SEXP R_plaidhip_gsva(SEXP X, SEXP Gp, SEXP Gi, SEXP tau) {
+SEXP R_plaidhip_gsva(SEXP X, SEXP Gp, SEXP Gi, SEXP tau, SEXP rowtf) {
   const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
   SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
-  int rc = plaidhip_gsva(ctx(), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, Rf_asReal(tau), 0, REAL(S));
+  int rc = plaidhip_gsva(ctx(), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, Rf_asReal(tau), Rf_asInteger(rowtf), REAL(S));
   if (rc != PLAIDHIP_OK) Rf_error("%s", plaidhip_last_error_string());
   UNPROTECT(1);
   return S;
@@ -218,7 +218,7 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_scse", (DL_FUNC)&R_plaidhip_scse, 9},
     {"R_plaidhip_gmt2mat_file", (DL_FUNC)&R_plaidhip_gmt2mat_file, 6},
     {"R_plaidhip_plaid_test", (DL_FUNC)&R_plaidhip_plaid_test, 7},
-    {"R_plaidhip_gsva", (DL_FUNC)&R_plaidhip_gsva, 4},
+    {"R_plaidhip_gsva", (DL_FUNC)&R_plaidhip_gsva, 5},
     {NULL, NULL, 0}};
 
 void R_init_plaidhip(DllInfo* dll) {

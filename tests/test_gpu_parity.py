@@ -508,8 +508,14 @@ def test_replaid_gsva_matches_oracle(hip_ctx, tau):
     got = plaid_amd.replaid_gsva(Xn, Gn, tau=tau)
     assert got.rownames == Gn.colnames and got.colnames == Xn.colnames
     close(got.values, exp)
+    Xe = np.round(X, 1)                                             # the ECDF variant: ties inside a gene (ties -> max rank)
+    Xe[5, :] = 1.25
+    Xen = plaid_amd.NamedMatrix(Xe, Xn.rownames, Xn.colnames)
+    # (many genes share ECDF values in a sample -> exact ties between genes, which both sides average)
+    close(plaid_amd.replaid_gsva(Xen, Gn, tau=tau, rowtf="ecdf").values,
+          _oracle().replaid_gsva(Xe, Xn.rownames, sp.csc_matrix(Gn.values), Gn.rownames, tau=tau, rowtf="ecdf"))
     with pytest.raises(ValueError):
-        plaid_amd.replaid_gsva(Xn, Gn, rowtf="ecdf")
+        plaid_amd.replaid_gsva(Xn, Gn, rowtf="nope")
 
 
 def test_spmm_mixed_precision_mode_is_opt_in_and_within_the_bar():
