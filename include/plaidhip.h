@@ -89,7 +89,9 @@ int plaidhip_memcpy_d2h(plaidhip_ctx* ctx, void* dst, const void* src, size_t by
  *      binarised membership: column j lists the rows OF X (0-based, < g) that belong to
  *      set j, i.e. `matG[gg,] != 0` re-indexed into X's row space (R/plaid.R:65-73) --
  *      X itself is never row-gathered.  Explicit zeros must already be dropped.
- *      Set sizes (colSums(G), R/plaid.R:75) are the column lengths. ------------------- */
+ *      Set sizes (colSums(G), R/plaid.R:75) are the column lengths.
+ *      A prepared gene-set collection is reused for every sample, chunk and call, but it owns
+ *      per-launch device scratch: use it from ONE stream at a time (one per context is free). */
 int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp,
                             const int32_t* Gi, plaidhip_geneset** out);
 int plaidhip_geneset_destroy(plaidhip_geneset* gs);
