@@ -77,10 +77,51 @@ struct DevBuf {
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
 
+// The host-level entry points prepare the gene-set collection themselves.  An R session calls them again and
+// again with the same matG, so the last few prepared collections stay in the context (keyed by sizes and a hash
+// of the pattern) instead of being rebuilt: preparing C2's 5,000 sets costs ~20 ms of a 76 ms call.
 struct GenesetHolder {
-  plaidhip_geneset* gs = nullptr;
-  ~GenesetHolder() { plaidhip_geneset_destroy(gs); }
+  plaidhip_geneset* gs = nullptr;   // owned by the context's cache
 };
+
+// two independent 64-bit hashes over the int32 words of the pattern (a 128-bit key)
+void hash_words(const int32_t* w, size_t count, uint64_t& h1, uint64_t& h2) {
+  for (size_t i = 0; i < count; ++i) {
+    const uint64_t v = (uint32_t)w[i];
+    h1 = (h1 ^ v) * 1099511628211ull;                       // FNV-1a on words
+    h2 = (h2 + v + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+    h2 ^= h2 >> 31;
+  }
+}
+
+int acquire_geneset(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, plaidhip_geneset** out) {
+  *out = nullptr;
+  uint64_t h = 1469598103934665603ull, h2 = 0x243f6a8885a308d3ull;
+  if (Gp != nullptr && m >= 0) {
+    hash_words(Gp, (size_t)m + 1, h, h2);
+    const int64_t z = m > 0 ? Gp[m] : 0;
+    if (Gi != nullptr && z > 0) hash_words(Gi, (size_t)z, h, h2);
+  }
+  for (size_t k = 0; k < ctx->gs_cache.size(); ++k) {
+    plaidhip_ctx::cached_geneset& e = ctx->gs_cache[k];
+    if (e.hash == h && e.hash2 == h2 && e.g == g && e.m == m) {
+      plaidhip_ctx::cached_geneset hit = e;
+      ctx->gs_cache.erase(ctx->gs_cache.begin() + (long)k);
+      ctx->gs_cache.push_back(hit);   // most recently used last
+      *out = hit.gs;
+      return PLAIDHIP_OK;
+    }
+  }
+  plaidhip_geneset* gs = nullptr;
+  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gs));
+  if (ctx->gs_cache.size() >= 4) {
+    plaidhip_geneset_destroy(ctx->gs_cache.front().gs);
+    ctx->gs_cache.erase(ctx->gs_cache.begin());
+  }
+  ctx->gs_cache.push_back(plaidhip_ctx::cached_geneset{h, h2, g, m, gs});
+  *out = gs;
+  return PLAIDHIP_OK;
+}
 
 int h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -184,6 +225,8 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   if (!ctx) return PLAIDHIP_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  for (plaidhip_ctx::cached_geneset& e : ctx->gs_cache) plaidhip_geneset_destroy(e.gs);
+  ctx->gs_cache.clear();
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -344,7 +387,7 @@ int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t 
   PH_REQUIRE(n == 0 || (X && S_out), "plaid_dense: null X/S_out");
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dS, dsmall;
   const int64_t ldg = even_ld(g);
   PH_TRY(dX.alloc((size_t)ldg * n * 8));
@@ -372,7 +415,7 @@ int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, 
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   const int64_t zx = Xp[n];
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dXp, dXi, dXx, dS, dsmall;
   PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
   PH_TRY(dXi.alloc((size_t)zx * 4));
@@ -484,7 +527,7 @@ int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X && S_out, "sing_dense: null X/S_out");
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dR, dS;
   const int64_t ldg = even_ld(g);
   PH_TRY(dX.alloc((size_t)ldg * n * 8));
@@ -508,7 +551,7 @@ int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X && S_out, "ssgsea_dense: null X/S_out");
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dX, dR, dS, dsmall;
   const int64_t ldg = even_ld(g);
   PH_TRY(dX.alloc((size_t)ldg * n * 8));
@@ -544,7 +587,7 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
   PH_REQUIRE(S_out != nullptr, "ssgsea_csc: null S_out");
   const int64_t zx = Xp[n];
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   DevBuf dXp, dXi, dXx, dRx, dS, dsmall;
   PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
   PH_TRY(dXi.alloc((size_t)zx * 4));
@@ -639,7 +682,7 @@ int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, cons
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X_or_x && S_out && k_full, "ucell: null X/S_out/k_full");
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   RankedInput ri;
   PH_TRY(dense_average_ranks(ctx, Xp, Xi, X_or_x, g, n, ri));
   PH_TRY(launch_map(ctx, ri.R, (int64_t)g * n, 0, rmax + 1.0, ri.d_gmax));            // R/plaid.R:278
@@ -665,7 +708,7 @@ int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, con
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X_or_x && S_out, "aucell: null X/S_out");
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   RankedInput ri;
   PH_TRY(dense_average_ranks(ctx, Xp, Xi, X_or_x, g, n, ri));
   PH_TRY(launch_map(ctx, ri.R, (int64_t)g * n, 1, auc_max_rank, ri.d_gmax));         // R/plaid.R:306
@@ -685,7 +728,7 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X_or_x && S_out, "scse: null X/S_out");
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   const bool sparse = Xp != nullptr;
   const int64_t nvals = sparse ? (int64_t)Xp[n] : (int64_t)g * n;
   DevBuf dX, dXp, dXi, dS, dsmall, dcol;
@@ -747,7 +790,7 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   if (m == 0) return PLAIDHIP_OK;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   const int64_t ldg = even_ld(g);
   DevBuf dX, dy, dmean, dF, dT, dws, dS, dsm, dsmall;
   PH_TRY(dX.alloc((size_t)ldg * n * 8));
@@ -830,7 +873,7 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   PH_REQUIRE(X && S_out, "gsva: null X/S_out");
   PH_REQUIRE(rowtf == 0 || rowtf == 1, "Error: unknown row transform %d", rowtf);                   // R/plaid.R:348
   GenesetHolder gh;
-  PH_TRY(plaidhip_geneset_create(ctx, g, m, Gp, Gi, &gh.gs));
+  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   const int64_t ldg = even_ld(g);
   DevBuf dX, dR, dS, dy, dmom, dws, dsmall;
   PH_TRY(dX.alloc((size_t)ldg * n * 8));

@@ -53,6 +53,9 @@ struct plaidhip_ctx {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   int num_cu = 256;
+  // prepared gene-set collections of the host-level entry points (api.cpp: acquire_geneset), most recent last
+  struct cached_geneset { uint64_t hash, hash2; int32_t g, m; struct plaidhip_geneset* gs; };
+  std::vector<cached_geneset> gs_cache;
   int precision = 0;   // PLAIDHIP_PRECISION_*: 0 fp64 throughout (default), 1 fp32 operand staging in the dense SpMM
 };
 
