@@ -1116,13 +1116,16 @@ static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                        int ignore_zero, const uint32_t* flags, double* med) {
   if (n == 0) return PLAIDHIP_OK;
-  static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");   // tools/: "sort" | "select" | unset
-  const bool want_sort = force && force[0] == 's' && force[1] == 'o';
-  const bool want_select = force && force[0] == 's' && force[1] == 'e';
-  const bool want_bits = force && force[0] == 'b';
+  // default: register-resident radix selection up to 6,144 values per column, wave-per-column streaming beyond
+  // (switch-over measured).  PLAIDHIP_MEDIAN_KERNEL = stream | radix | bits | sample | sort |
+  // select forces one of the kernels (tools/ and tests; the older ones are kept as cross-checks)
+  static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");
+  const bool f2 = force && force[0] == 's';
+  const bool want_stream = (f2 && force[1] == 't') || (!force && m > 6144);
   const bool want_radix = (force && force[0] == 'r') || (!force && m <= 6144);
-  const bool want_sample = force && force[0] == 's' && force[1] == 'a';
-  const bool want_stream = (force && force[0] == 's' && force[1] == 't') || (!force && m > 6144);
+  const bool want_bits = force && force[0] == 'b';
+  const bool want_sample = f2 && force[1] == 'a';
+  const bool want_select = f2 && force[1] == 'e';   // "sort" (or anything else): the LDS bitonic sort when it fits
   if (want_stream) {
     const int cap = ctx->num_cu * 8;                      // 8 workgroups x 4 wavefronts per CU
     const int need = (n + 3) / 4;
@@ -1133,9 +1136,7 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
     else if (m <= 6144) launch_radix<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_radix<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (want_sample) {
-    // measured on MI355X: the bitwise register kernel wins up to ~16k sets per column (0.57 vs
-    // 0.78 ms at m = 5k), the sample-bracket kernel beyond (m = 50k: 2.5 vs 5.0 ms per 4,096 columns)
-    // sample-bracket selection: BLOCK 512 up to 16k sets, 1024 beyond; the sample grows with m so
+    // workgroup-per-column sample-bracket selection (superseded by the streaming kernel's sampled start): BLOCK 512 up to 16k sets, 1024 beyond; the sample grows with m so
     // that the expected number of keys inside the bracket (4 m / sqrt(samples)) stays below cap/2
     const int block = m <= 16384 ? 512 : 1024;
     const int cap = block * 8;
