@@ -537,7 +537,7 @@ int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
   PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_MIN, 0, 1.0, dR.as<double>(), ldg, nullptr));
   PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,
-                               dS.as<double>(), m, nullptr));
+                               dS.as<double>(), m, nullptr, /*x_exact_in_f32=*/true));   // integer ranks
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
@@ -570,7 +570,7 @@ int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t
   PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
   PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5,
-                               dS.as<double>(), m, d_flags));
+                               dS.as<double>(), m, d_flags, /*x_exact_in_f32=*/alpha == 0.0));   // plain average ranks
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
@@ -912,7 +912,7 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
   PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, 0.0, dS.as<double>(),
-                               m, d_flags));
+                               m, d_flags, /*x_exact_in_f32=*/!(tau > 0.0)));   // signed average ranks
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));   // :360 plaid()
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));

@@ -172,7 +172,8 @@ void p_adjust_fdr(const double* p, int64_t m, double* q);
 // kernels_spmm.hip
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
-                          double beta, double* S, int64_t lds, uint32_t* flags);
+                          double beta, double* S, int64_t lds, uint32_t* flags,
+                          bool x_exact_in_f32 = false);   // X holds (half-)integer ranks: fp32 staging loses nothing
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,

@@ -1236,9 +1236,15 @@ static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int st
 
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
-                          double beta, double* S, int64_t lds, uint32_t* flags) {
+                          double beta, double* S, int64_t lds, uint32_t* flags, bool x_exact_in_f32) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (ctx->precision == PLAIDHIP_PRECISION_MIXED && (g_ablate == 0 || g_ablate == 4) && (ldx & 1) == 0 &&
+  // fp32 staging: opt-in, or free of any rounding when X holds ranks (integers / half-integers <= 20,448 are
+  // exact in fp32, and so are the four-term fp32 partial sums of the kernel: < 2^17 with one fractional bit)
+  if (x_exact_in_f32) {
+    const char* e = getenv("PLAIDHIP_RANKS_F32");   // "0": keep rank inputs on the fp64 kernels (tests compare the two)
+    if (e != nullptr && e[0] == '0') x_exact_in_f32 = false;
+  }
+  if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && (g_ablate == 0 || g_ablate == 4) && (ldx & 1) == 0 &&
       (reinterpret_cast<uintptr_t>(X) & 15) == 0 && gs->slices.size() == 1 && gs->slices[0].waves == 16) {
     // opt-in: fp32 operand staging (plaidhip_set_precision); one gene slice and the 1024-thread schedule only
     SpmmArgs a{};

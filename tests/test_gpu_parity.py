@@ -547,3 +547,22 @@ def test_spmm_mixed_precision_mode_is_opt_in_and_within_the_bar():
     ctx.set_precision("f64")
     assert np.array_equal(ctx.plaid_dense(X, Gp, Gi, "mean", False), exact)
     ctx.close()
+
+
+def test_rank_inputs_take_the_fp32_staged_kernel_without_any_rounding(hip_ctx, monkeypatch):
+    """replaid.sing / replaid.ssgsea(alpha = 0) / replaid.gsva(tau = 0) feed (half-)integer ranks <= 20,448 to the
+    crossprod: those are exact in fp32 and so are the kernel's four-term fp32 partial sums, so the fp32-staged
+    pair kernel is used for them by default and must give the fp64 kernels' scores BIT FOR BIT"""
+    from plaid_amd import synth as sy
+    g, n, m = 20000, 9, 300
+    Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PLAIDHIP_RANKS_F32", flag)
+        outs[flag] = (hip_ctx.sing_dense(X, Gp, Gi), hip_ctx.ssgsea_dense(X, Gp, Gi, 0.0), hip_ctx.gsva(X - 8.0, Gp, Gi, 0.0))
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, b)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(outs["1"][0], _oracle().replaid_sing(X, rn, G, rn))
