@@ -1133,6 +1133,8 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
                        lds, m, n, ignore_zero, flags, med);
   } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 4096) launch_radix<256, 16>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 5120) launch_radix<256, 20>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 6144) launch_radix<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_radix<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (want_sample) {

@@ -325,7 +325,7 @@ def test_c2_full_size_properties(hip_ctx):
     close(N2, N1)
 
 
-@pytest.mark.parametrize("m", [1, 2, 3, 64, 2048, 2049, 5000, 6144, 6145, 16384, 20000, 33000, 50000, 65536, 65537, 70000])
+@pytest.mark.parametrize("m", [1, 2, 3, 64, 2048, 2049, 4096, 4097, 5000, 5120, 5121, 6144, 6145, 16384, 20000, 33000, 50000, 65536, 65537, 70000])
 def test_medians_every_kernel_size_class(hip_ctx, m):
     """column lengths across the register-resident classes (<=2048/6144/16384/32768/65536), the
     radix-select fallback beyond, heavy ties, both parities of the valid count"""
