@@ -198,10 +198,7 @@ __device__ __forceinline__ void regs_sort32(double (&v)[32]) {
   regs_disperse32(v, 3);
 }
 
-// NATURAL: store to un-swizzled positions.  Only legal when the thread owns a whole aligned
-// 32-key group (b_lo == 0): the swizzle permutes inside such groups only, so no other thread
-// reads or writes these slots in the same pass.  Used for the very last pass of the sort.
-template <bool CHECK, bool NATURAL = false>
+template <bool CHECK>
 __device__ __forceinline__ void bitonic_pass_D(unsigned char* lds, uint32_t n, uint32_t tid, int b_top) {
   const int b_lo = b_top >= 4 ? b_top - 4 : 0;
   const uint32_t t_lo = tid & ((1u << b_lo) - 1u), t_hi = tid >> b_lo;
@@ -222,7 +219,7 @@ __device__ __forceinline__ void bitonic_pass_D(unsigned char* lds, uint32_t n, u
   for (int s = 0; s < 32; ++s) {
     const uint32_t f = (uint32_t)s << b_lo;
     if (!CHECK || (base1 | f) < n)
-      *reinterpret_cast<double*>(lds + (NATURAL ? ((base1 | f) << 3) : (P1 ^ (swz(f) << 3)))) = v[s];
+      *reinterpret_cast<double*>(lds + (P1 ^ (swz(f) << 3))) = v[s];
   }
 }
 
@@ -283,11 +280,32 @@ __device__ __forceinline__ void bitonic_finish_regs(unsigned char* lds, uint32_t
       __syncthreads();
       const int b_lo = b_top >= 4 ? b_top - 4 : 0;
       const uint32_t span_beg = (tid >> b_lo) << (b_lo + 5), span_end = span_beg + (32u << b_lo);
-      if (lk == L && b_top < 5) {          // last pass of the whole sort: leave the keys in natural order
-        if (span_end <= n) bitonic_pass_D<false, true>(lds, n, tid, b_top);
-        else if (span_beg < n) bitonic_pass_D<true, true>(lds, n, tid, b_top);
-      } else if (span_end <= n) bitonic_pass_D<false>(lds, n, tid, b_top);
+      if (span_end <= n) bitonic_pass_D<false>(lds, n, tid, b_top);
       else if (span_beg < n) bitonic_pass_D<true>(lds, n, tid, b_top);
+    }
+  }
+  __syncthreads();
+  // un-swizzle: the searches that follow want the keys at their natural positions.  Thread t moves keys
+  // t, t + T, t + 2T, ...: both the swizzled reads and the natural writes of 32 neighbouring lanes fall into
+  // 32 different banks.  (Storing the last merge pass straight to natural positions -- 32 consecutive keys
+  // per thread -- is a 32-way bank conflict on every store and cost a third of the whole kernel.)
+  // (eight keys per thread and round: the rounds touch disjoint aligned 32-key groups, one barrier each)
+  {
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    for (int k0 = 0; k0 < 32; k0 += 8) {
+      if ((uint32_t)k0 * T >= n) break;      // uniform: nothing left
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t i = t + (uint32_t)(k0 + k) * T;
+        v[k] = (i < n) ? *reinterpret_cast<const double*>(lds + (swz(i) << 3)) : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t i = t + (uint32_t)(k0 + k) * T;
+        if (i < n) *reinterpret_cast<double*>(lds + (i << 3)) = v[k];
+      }
     }
   }
   __syncthreads();
