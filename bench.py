@@ -1,18 +1,26 @@
 #!/usr/bin/env python
-"""Headline benchmark: sample x geneset scores/sec of plaid() at 20k genes on MI355X.
+"""Headline benchmark: sample x geneset scores/sec of the plaid hot path at 20k genes on MI355X.
 
-A "step" is one pass of the hot path over one resident batch: S = G^T X (sparse 0/1
-membership x dense expression, 1/|set| scaling) followed by normalize_medians()
-(R/plaid.R:60-87).  Workload at N=1 = BASELINE.json configs[1] (C2): synthetic dense
-20,000 genes x 10,000 samples x 5,000 gene sets, inputs resident in HBM.  With --gpus N
-(launched by torch.distributed.run, one rank per GPU) every rank holds its own 10,000-sample
-shard (weak scaling); the only data-path collectives are the two scalar all-reduces
-normalize_medians needs across shards (min(x)==0 flags, mean of medians).  The optional
-gather of the score shards to rank 0 is timed separately and never part of `value`.
+A "step" is one pass of the hot path over one resident batch of synthetic input.
 
-Prints ONE JSON line (rank 0).  `roofline` is the SpMM kernel's algorithmic HBM bytes /
-its HIP-event time; `cpu_baseline` times the plain-C oracle (the reference is R and cannot
-run here) on a bounded column sample of the same workload, one core.
+  headline (`value`, every N)   BASELINE.json configs[1] = C2: plaid() on dense 20,000 genes x 10,000 samples per
+                                GPU x 5,000 gene sets: S = G^T X (1/|set| scaling) + normalize_medians()
+                                (R/plaid.R:60-87).  With --gpus N every rank holds its own 10,000-sample shard
+                                (weak scaling); the data-path collectives are the two scalar all-reduces
+                                normalize_medians needs across shards.
+  "c3" block (N = 1)            configs[2]: replaid.ssgsea(alpha = 0.25) on SPARSE 20,000 x 100,000 cells (5 % stored)
+                                x 50,000 sets, full size: sparse_colranks -> max(rX) -> scatter crossprod -> medians.
+  "c4" block (N = 1)            configs[3]: replaid.ssgsea(alpha = 0.25) on DENSE 20,000 x 50,000 x 50,000, full size:
+                                colranks (bucket ranker, fused power) -> crossprod -> medians.  (The reference multiplies
+                                the sparse G here too, R/plaid.R:253 -> :80; the dense MFMA contraction is priced in
+                                DESIGN.md and tools/.)
+  "c5_shard" block (N > 1)      configs[4] per GPU: the c3 pipeline on a 125,000-cell CSC shard per rank with the
+                                three scalar all-reduces of plaid_amd/sharded.py (sharded_ssgsea_csc).
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel's algorithmic HBM bytes / its HIP-event time (plus
+the LDS-return roof the fp64 gather kernels actually sit on); `cpu_baseline` times the plain-C oracle (the reference is
+R and cannot run here) on a bounded column sample of the same workload: one core (reference-faithful) and all cores
+(OpenMP over columns).  Every block carries its own roofline / cpu_baseline / parity entries.
 """
 from __future__ import annotations
 
@@ -26,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_PEAK_GBPS = 157286.4    # 256 CUs x 256 B/clk x 2.4 GHz (MI355X_MICROARCH.md, LDS: ds_read_b64/b128)
 
 
 def parse():
@@ -35,48 +44,103 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genes", type=int, default=20000)
-    ap.add_argument("--samples", type=int, default=10000, help="samples per GPU")
-    ap.add_argument("--sets", type=int, default=5000)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="columns timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--samples", type=int, default=10000, help="C2 samples per GPU")
+    ap.add_argument("--sets", type=int, default=5000, help="C2 gene sets")
+    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4"],
+                    help="N = 1: which blocks to run next to the C2 headline (default: all)")
+    ap.add_argument("--c3-cells", type=int, default=100000)
+    ap.add_argument("--c4-samples", type=int, default=50000)
+    ap.add_argument("--c5-cells-per-gpu", type=int, default=125000)
+    ap.add_argument("--big-sets", type=int, default=50000, help="gene sets of the c3 / c4 / c5 blocks")
+    ap.add_argument("--block-steps", type=int, default=5, help="timed steps of the c3 / c4 / c5 blocks")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="C2 columns timed on the CPU oracle (0 = skip all CPU legs)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-mixed", action="store_true", help="skip the secondary mixed-precision (fp32-staged) measurement")
     return ap.parse_args()
 
 
-def main():
-    a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+def _traffic(kernel, shape):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(f"{kernel}/{shape}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
-    import plaid_amd
-    from plaid_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
+def _roof(kernel, alg_bytes, ms, traffic=None, lds_bytes=None, extra=None):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
+         "kernel_ms": round(ms, 4)}
+    if lds_bytes is not None:
+        la = lds_bytes / (ms * 1e-3) / 1e9
+        r["lds_roof"] = {"achieved": round(la, 1), "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": round(la / LDS_PEAK_GBPS, 4),
+                         "bytes": int(lds_bytes), "note": "bytes the kernel gathers from LDS per launch / kernel time"}
+    if extra:
+        r.update(extra)
+    return r
+
+
+class Events:
+    """HIP events on the context's stream around the phases of a step (torch events see exactly that stream)"""
+
+    def __init__(self, torch, stream, steps, marks):
+        self.torch, self.stream, self.marks = torch, stream, marks
+        self.ev = [[torch.cuda.Event(enable_timing=True) for _ in range(marks)] for _ in range(steps)]
+
+    def rec(self, k, i):
+        if k is not None:
+            self.ev[k][i].record(self.stream)
+
+    def phase_ms(self, i):
+        import numpy as np
+        return float(np.mean([e[i].elapsed_time(e[i + 1]) for e in self.ev]))
+
+
+def _timed(torch, dist, use_dist, dev, steps, warmup, step):
+    for _ in range(warmup):
+        step(None)
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
 
+
+def _cpu_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _rel_err(a, b):
+    import numpy as np
+    with np.errstate(all="ignore"):
+        return float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-9)))
+
+
+# ----------------------------------------------------------------------------------------- C2 (headline)
+def run_c2(a, env):
+    import numpy as np
+    torch, dist, ctx, dev, stream = env["torch"], env["dist"], env["ctx"], env["dev"], env["stream"]
+    world, rank, use_dist = env["world"], env["rank"], env["use_dist"]
+    from plaid_amd import synth
     g, n, m = a.genes, a.samples, a.sets
-    stream = torch.cuda.Stream(device=dev)
-    ctx = plaid_amd.Context(local_rank, stream.cuda_stream)
-
-    # ---- synthetic inputs, resident in HBM before the timed region -----------------------
     Gp, Gi = synth.geneset_csc(g, m)
     z = int(Gp[-1])
     gs = ctx.geneset(g, Gp, Gi)
+    info = gs.info()
     X = torch.empty((n, g), dtype=torch.float64, device=dev)      # row-major (n, g) == R's g x n
     col0 = rank * n                                               # this rank's sample shard
     for j0 in range(0, n, 1024):
@@ -88,71 +152,43 @@ def main():
     med = torch.empty(n, dtype=torch.float64, device=dev)
     red = torch.zeros(4, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev = Events(torch, stream, a.steps, 4)
 
     def step(k=None):
         with torch.cuda.stream(stream):
             flags.zero_()
-            if k is not None:
-                ev[k][0].record(stream)
+            ev.rec(k, 0)
             ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
-            if k is not None:
-                ev[k][1].record(stream)
+            ev.rec(k, 1)
             if use_dist:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX)                  # min(x)==0 over all shards
             ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
             ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
+            ev.rec(k, 2)
             if use_dist:
                 dist.all_reduce(red, op=dist.ReduceOp.SUM)                    # mean(medx) over all shards
             ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
-            if k is not None:
-                ev[k][2].record(stream)
+            ev.rec(k, 3)
 
-    for _ in range(a.warmup):
-        step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(k)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    elapsed = _timed(torch, dist, use_dist, dev, a.steps, a.warmup, step)
     ms_step = 1e3 * elapsed / a.steps
-    spmm_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    norm_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    spmm_ms, med_ms, shift_ms = ev.phase_ms(0), ev.phase_ms(1), ev.phase_ms(2)
     scores = float(world) * n * m
     value = scores / (elapsed / a.steps)
 
-    # ---- secondary, reported beside the headline, never in `value`: the opt-in mixed-precision crossprod
-    #      (sample columns staged as fp32 in LDS, sums fp64), same workload, same step ---------------------
+    # secondary, never in `value`: the opt-in mixed-precision crossprod (fp32 operand staging, fp64 sums)
     mixed = None
-    if not a.no_mixed and world == 1:   # N = 1 only, like cpu_baseline: no collective may depend on an optional block
+    if not a.no_mixed and world == 1:
         try:
             ctx.set_precision("mixed")
             msteps = max(3, min(a.steps, 10))
-            mev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(msteps)]
             step()
             torch.cuda.synchronize()
             tm = time.perf_counter()
-            for k in range(msteps):
-                with torch.cuda.stream(stream):
-                    mev[k][0].record(stream)
+            for _ in range(msteps):
                 step()
-                with torch.cuda.stream(stream):
-                    mev[k][1].record(stream)
             torch.cuda.synchronize()
             tm = (time.perf_counter() - tm) / msteps
-            # the SpMM is the first kernel of a step: time it alone once more with events around it
             sp_ev = []
             for _ in range(msteps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -172,27 +208,17 @@ def main():
         finally:
             ctx.set_precision("f64")
 
-    # ---- roofline of the dominant kernel (SpMM): algorithmic bytes per launch --------------
-    # g*n*b_X + (4 z + 4 (m+1)) + m*n*b_S with b = 8 (fp64 in, fp64 out)
+    # roofline of the dominant kernel: SURVEY.md 8(d): g*n*b + (4 z + 4 (m+1)) + m*n*b with b = 8
     alg_bytes = g * n * 8 + 4 * z + 4 * (m + 1) + m * n * 8
-    # dense X with 16-byte aligned columns takes the two-columns-per-pass kernel (kernels_spmm.hip)
-    spmm_kernel = "spmm_colpair_f64" if (g % 2 == 0 and os.environ.get("PLAIDHIP_SPMM_KERNEL") != "single") \
-        else "spmm_colgather_f64"
-    achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"{spmm_kernel}/{g}x{n}x{m}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"kernel": spmm_kernel, "bound": "hbm", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": round(spmm_ms, 4)}
+    spmm_kernel = "spmm_colpair_f64" if g % 2 == 0 else "spmm_colgather_f64"
+    # every padded membership slot of the plan returns 8 bytes per sample column from LDS
+    lds_bytes = float(info["padded_slots"]) * 8.0 * n
+    roofline = _roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes)
+    kernels = {
+        "col_medians": _roof("col_medians_radix_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms),
+        "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+    }
 
-    # ---- optional gather of the score shards to rank 0 (reported, never in `value`) --------
     gather = None
     if use_dist and not a.no_gather:
         try:
@@ -210,7 +236,6 @@ def main():
         except Exception as exc:  # pragma: no cover
             gather = {"error": str(exc)[:200]}
 
-    # ---- CPU baseline + parity spot-check on a bounded sample (rank 0, N = 1 only) ---------
     cpu = None
     parity = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
@@ -220,13 +245,19 @@ def main():
         t1 = time.perf_counter()
         Sraw = c_oracle.plaid_dense(Xh, Gp, Gi, "mean", False)
         t2 = time.perf_counter()
-        c_oracle.normalize_medians(Sraw)
+        c_oracle.normalize_medians(Sraw.copy())
         t3 = time.perf_counter()
+        nt = _cpu_threads()
+        t4 = time.perf_counter()
+        Sall = c_oracle.crossprod_dense(Xh, Gp, Gi, "mean", nt)
+        c_oracle.normalize_medians_mt(Sall, None, nt)
+        t5 = time.perf_counter()
         cpu = {"value": round(m * nc / (t3 - t1), 1), "unit": "scores/s", "cores": 1, "kind": "port",
                "sample": f"first {nc} of {n} sample columns x {m} sets, plain-C oracle (oracle/plaid_oracle.c): "
                          f"crossprod {t2 - t1:.2f} s + normalize_medians {t3 - t2:.2f} s",
+               "all_cores": {"value": round(m * nc / (t5 - t4), 1), "cores": nt,
+                             "note": "same code, OpenMP over sample columns (not what the single-threaded reference does)"},
                "cpu_count": os.cpu_count()}
-        # checker: the GPU's un-normalised scores for the same columns
         with torch.cuda.stream(stream):
             ctx.dev_spmm_dense(gs, X.data_ptr(), g, nc, S.data_ptr(), m, "mean", 1.0, 0.0, None)
         torch.cuda.synchronize()
@@ -241,23 +272,333 @@ def main():
             ctx.set_precision("f64")
             Sm = S[:nc].cpu().numpy().T
             mixed["max_rel_err_vs_oracle"] = float(np.max(np.abs(Sm - Sraw) / np.maximum(np.abs(Sraw), 1e-300)))
+    out = {
+        "value": value, "ms_per_step": ms_step, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "gather": gather, "mixed_precision": mixed, "kernels": kernels,
+        "phases_ms": {"spmm": round(spmm_ms, 4), "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4),
+                      "normalize_medians": round(med_ms + shift_ms, 4)},
+        "config": {"workload": f"C2 dense plaid(): {g} genes x {n} samples/GPU x {m} gene sets "
+                               f"(z={z} memberships), inputs resident in HBM",
+                   "genes": g, "samples_per_gpu": n, "sets": m, "memberships": z,
+                   "parallelism": f"sample-shard x{world}"},
+    }
+    gs.close()
+    del X, S
+    torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------------------- sparse X generator
+def device_sparse_cells(torch, dev, g, n, seed, density=0.05, levels=50):
+    """n cells of the sparse workload generated ON the device (~5 % stored values per cell, values
+    log1p(count / size factor) with ~50 levels per cell), as CSC tensors.  Returns (p int32[n+1], i int32, x float64,
+    nnz, longest column)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    ps, idx, val = [torch.zeros(1, dtype=torch.int64, device=dev)], [], []
+    B = 4096
+    for j0 in range(0, n, B):
+        b = min(B, n - j0)
+        mask = torch.rand((b, g), device=dev, generator=gen) < density
+        cnt = mask.sum(dim=1)
+        nz = mask.nonzero(as_tuple=False)                  # sorted by cell, then gene
+        k = torch.empty(nz.shape[0], device=dev, dtype=torch.float64).geometric_(0.12, generator=gen).clamp_(max=levels)
+        sf = 0.5 + torch.rand(b, device=dev, dtype=torch.float64, generator=gen)
+        val.append(torch.log1p(k / sf[nz[:, 0]]))
+        idx.append(nz[:, 1].to(torch.int32))
+        ps.append(cnt)
+        del mask, nz, k
+    cnt = torch.cat(ps)
+    p = torch.cumsum(cnt, 0)
+    nnz = int(p[-1].item())
+    assert nnz < 2**31 - 1, "more than 2^31-1 stored values: 32-bit dgCMatrix slots"
+    return p.to(torch.int32), torch.cat(idx), torch.cat(val), nnz, int(cnt.max().item())
+
+
+def ssgsea_csc_oracle(c_oracle, np, Xp, Xi, Xx, g, Gp, Gi, alpha, threads):
+    """replaid.ssgsea on a dgCMatrix, phase by phase, on the C oracle (R/plaid.R:244-255)"""
+    t = [time.perf_counter()]
+    r = c_oracle.sparse_colranks_mt(Xp, Xx, "average", False, threads)
+    r = r ** (1.0 + alpha)
+    gmax = max(r.max() if r.size else 0.0, 0.0)
+    t.append(time.perf_counter())
+    k = np.diff(Gp).astype(np.float64)
+    S = c_oracle.crossprod_csc(Xp, Xi, r, g, Gp, Gi, "mean", threads)
+    S /= gmax
+    S -= (0.5 * k / (1e-8 + k))[:, None]                    # the "- 0.5" of :251 reaches every gene of a set
+    t.append(time.perf_counter())
+    c_oracle.normalize_medians_mt(S, None, threads)
+    t.append(time.perf_counter())
+    return S, [t[i + 1] - t[i] for i in range(3)]
+
+
+def ssgsea_dense_oracle(c_oracle, np, X, Gp, Gi, alpha, threads):
+    t = [time.perf_counter()]
+    R = c_oracle.colranks_dense_mt(X, "average", False, threads)
+    R **= (1.0 + alpha)
+    R /= R.max()
+    R -= 0.5
+    t.append(time.perf_counter())
+    S = c_oracle.crossprod_dense(R, Gp, Gi, "mean", threads)
+    t.append(time.perf_counter())
+    c_oracle.normalize_medians_mt(S, None, threads)
+    t.append(time.perf_counter())
+    return S, [t[i + 1] - t[i] for i in range(3)]
+
+
+# ----------------------------------------------------------------------------------------- C3 / C5 (sparse ssGSEA)
+def run_sparse_ssgsea(a, env, n, label, collective):
+    import numpy as np
+    torch, dist, ctx, dev, stream = env["torch"], env["dist"], env["ctx"], env["dev"], env["stream"]
+    world, rank = env["world"], env["rank"]
+    from plaid_amd import synth
+    g, m, alpha = a.genes, a.big_sets, 0.25
+    Gp, Gi = synth.geneset_csc(g, m)
+    z = int(Gp[-1])
+    t0 = time.perf_counter()
+    gs = ctx.geneset(g, Gp, Gi)
+    t_plan = time.perf_counter() - t0
+    with torch.cuda.stream(stream):
+        Xp, Xi, Xx, nnz, max_nnz = device_sparse_cells(torch, dev, g, n, 20250615 + 7919 * rank)
+        Rx = torch.empty_like(Xx)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        med = torch.empty(n, dtype=torch.float64, device=dev)
+        small = torch.zeros(8, dtype=torch.float64, device=dev)     # [0:2] {sum, count}; [2] max(rX)
+    red, gmax = small[0:2], small[2:3]
+    torch.cuda.synchronize()
+    steps = a.block_steps
+    ev = Events(torch, stream, steps, 5)
+
+    def step(k=None):
+        with torch.cuda.stream(stream):
+            flags.zero_()
+            ev.rec(k, 0)
+            ctx.dev_colranks_csc(Xp.data_ptr(), Xx.data_ptr(), n, max_nnz, Rx.data_ptr(), "average", False, 1.0 + alpha,
+                                 colmax.data_ptr())
+            ctx.dev_max(colmax.data_ptr(), n, gmax.data_ptr())
+            ev.rec(k, 1)
+            if collective:
+                dist.all_reduce(gmax, op=dist.ReduceOp.MAX)                   # max(rX) over all shards
+            ctx.dev_spmm_csc(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
+                             flags.data_ptr(), gmax.data_ptr(), nnz=nnz)
+            ev.rec(k, 2)
+            if collective:
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
+            ev.rec(k, 3)
+            if collective:
+                dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
+            ev.rec(k, 4)
+
+    elapsed = _timed(torch, dist, collective, dev, steps, 1, step)
+    rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
+    scatter = nnz * 8 < g * n
+    spmm_alg = 12.0 * nnz + 4.0 * (n + 1) + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
+    out = {
+        "workload": f"{label}: replaid.ssgsea(alpha={alpha}) on sparse {g} genes x {n} cells"
+                    f"{'/GPU' if collective else ''} ({nnz} stored values, {100.0 * nnz / (g * n):.2f} %) x {m} gene sets "
+                    f"(z={z}), fp64, inputs resident in HBM",
+        "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
+        "scores_per_s": round(float(world if collective else 1) * n * m / (elapsed / steps), 1),
+        "phases_ms": {"sparse_colranks+max": round(rank_ms, 4), "crossprod": round(spmm_ms, 4),
+                      "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
+        "rank_keys_per_s": round(nnz / (rank_ms * 1e-3), 1),
+        "geneset_plan_s": round(t_plan, 2),
+        "kernels": {
+            "sparse_colranks": _roof("colranks_bucket_kernel<256,8>" if max_nnz <= 2048 else "colranks_bucket_kernel", 16.0 * nnz, rank_ms),
+            "crossprod": _roof("spmm_scatter_csc_f64" if scatter else "spmm_colpair_f64<csc>", spmm_alg, spmm_ms,
+                               extra={"lds_atomic_adds_per_s": round(nnz * (z / g) / (spmm_ms * 1e-3), 1)} if scatter else None),
+            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms),
+            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+        },
+    }
+    if not collective and rank == 0 and a.cpu_sample > 0:
+        from oracle import c_oracle
+        nc = min(2048, n)
+        ph = Xp[:nc + 1].cpu().numpy()
+        zc = int(ph[-1])
+        ih, xh = Xi[:zc].cpu().numpy(), Xx[:zc].cpu().numpy()
+        S1, t1 = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, 1)
+        nt = _cpu_threads()
+        _, tn = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, nt)
+        out["cpu_baseline"] = {
+            "value": round(m * nc / sum(t1), 1), "unit": "scores/s", "cores": 1, "kind": "port",
+            "sample": f"first {nc} of {n} cells x {m} sets, plain-C oracle: sparse_colranks+pow {t1[0]:.2f} s, crossprod "
+                      f"(Gustavson order) {t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
+            "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
+        # checker: the GPU pipeline on exactly that sample (the three global scalars couple all cells)
+        with torch.cuda.stream(stream):
+            flags.zero_()
+            ctx.dev_colranks_csc(Xp.data_ptr(), Xx.data_ptr(), nc, max_nnz, Rx.data_ptr(), "average", False, 1.0 + alpha,
+                                 colmax.data_ptr())
+            ctx.dev_max(colmax.data_ptr(), nc, gmax.data_ptr())
+            ctx.dev_spmm_csc(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), nc, S.data_ptr(), m, "mean", 1.0, -0.5,
+                             flags.data_ptr(), gmax.data_ptr(), nnz=zc)
+            ctx.dev_col_medians(S.data_ptr(), m, m, nc, None, med.data_ptr(), flags.data_ptr())
+            ctx.dev_sum(med.data_ptr(), nc, red.data_ptr())
+            ctx.dev_shift_columns(S.data_ptr(), m, m, nc, med.data_ptr(), 0.0, red.data_ptr())
+        torch.cuda.synchronize()
+        Sg = S[:nc].cpu().numpy().T
+        out["parity"] = {"max_abs_err_vs_oracle": float(np.max(np.abs(Sg - S1))), "max_rel_err_vs_oracle": _rel_err(Sg, S1),
+                         "columns": nc, "note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"}
+    gs.close()
+    del Xp, Xi, Xx, Rx, S
+    torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------------------- C4 (dense ssGSEA)
+def run_c4(a, env):
+    import numpy as np
+    torch, dist, ctx, dev, stream = env["torch"], env["dist"], env["ctx"], env["dev"], env["stream"]
+    from plaid_amd import synth
+    g, n, m, alpha = a.genes, a.c4_samples, a.big_sets, 0.25
+    Gp, Gi = synth.geneset_csc(g, m)
+    z = int(Gp[-1])
+    gs = ctx.geneset(g, Gp, Gi)
+    info = gs.info()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20250614)
+    with torch.cuda.stream(stream):
+        X = torch.empty((n, g), dtype=torch.float64, device=dev)
+        for j0 in range(0, n, 8192):
+            j1 = min(n, j0 + 8192)
+            X[j0:j1] = torch.randn((j1 - j0, g), dtype=torch.float64, device=dev, generator=gen) * 2.0 + 8.0   # N(8, 2^2)
+        R = torch.empty_like(X)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        med = torch.empty(n, dtype=torch.float64, device=dev)
+        small = torch.zeros(8, dtype=torch.float64, device=dev)
+    red, gmax = small[0:2], small[2:3]
+    torch.cuda.synchronize()
+    steps = a.block_steps
+    ev = Events(torch, stream, steps, 5)
+
+    def pipeline(ncols, k=None):
+        flags.zero_()
+        ev.rec(k, 0)
+        ctx.dev_colranks_dense(X.data_ptr(), g, g, ncols, R.data_ptr(), g, "average", False, 1.0 + alpha, colmax.data_ptr())
+        ctx.dev_max(colmax.data_ptr(), ncols, gmax.data_ptr())
+        ev.rec(k, 1)
+        ctx.dev_spmm_dense(gs, R.data_ptr(), g, ncols, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(), gmax.data_ptr())
+        ev.rec(k, 2)
+        ctx.dev_col_medians(S.data_ptr(), m, m, ncols, None, med.data_ptr(), flags.data_ptr())
+        ctx.dev_sum(med.data_ptr(), ncols, red.data_ptr())
+        ev.rec(k, 3)
+        ctx.dev_shift_columns(S.data_ptr(), m, m, ncols, med.data_ptr(), 0.0, red.data_ptr())
+        ev.rec(k, 4)
+
+    def step(k=None):
+        with torch.cuda.stream(stream):
+            pipeline(n, k)
+
+    elapsed = _timed(torch, dist, False, dev, steps, 1, step)
+    rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
+    spmm_alg = 8.0 * g * n + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
+    out = {
+        "workload": f"C4: replaid.ssgsea(alpha={alpha}) on dense {g} genes x {n} samples x {m} gene sets (z={z}), fp64, "
+                    "crossprod with the sparse membership (what the reference multiplies, R/plaid.R:253 -> :80), "
+                    "inputs resident in HBM",
+        "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
+        "scores_per_s": round(float(n) * m / (elapsed / steps), 1),
+        "phases_ms": {"colranks+pow+max": round(rank_ms, 4), "crossprod": round(spmm_ms, 4),
+                      "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
+        "rank_keys_per_s": round(float(g) * n / (rank_ms * 1e-3), 1),
+        "kernels": {
+            "colranks": _roof("colranks_bucket_kernel<512,40>", 16.0 * g * n, rank_ms),
+            "crossprod": _roof("spmm_colpair_f64", spmm_alg, spmm_ms, lds_bytes=float(info["padded_slots"]) * 8.0 * n),
+            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms),
+            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+        },
+        "dense_gemm_equivalent": {"flop": 2.0 * g * n * m, "note": "the dense contraction config 4 names would be "
+                                  f"{2.0 * g * n * m:.2e} flop (x3 issues as a bf16 split) against {2.0 * z * n:.2e} for this "
+                                  "crossprod: see DESIGN.md (C4 row) for the measured MFMA rate beside this time"},
+    }
+    if a.cpu_sample > 0:
+        from oracle import c_oracle
+        nc = min(512, n)
+        Xh = np.asfortranarray(X[:nc].cpu().numpy().T)
+        S1, t1 = ssgsea_dense_oracle(c_oracle, np, Xh.copy(order="F"), Gp, Gi, alpha, 1)
+        nt = _cpu_threads()
+        _, tn = ssgsea_dense_oracle(c_oracle, np, Xh.copy(order="F"), Gp, Gi, alpha, nt)
+        out["cpu_baseline"] = {
+            "value": round(m * nc / sum(t1), 1), "unit": "scores/s", "cores": 1, "kind": "port",
+            "sample": f"first {nc} of {n} samples x {m} sets, plain-C oracle: colranks+pow {t1[0]:.2f} s, crossprod "
+                      f"{t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
+            "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
+        with torch.cuda.stream(stream):
+            pipeline(nc)
+        torch.cuda.synchronize()
+        Sg = S[:nc].cpu().numpy().T
+        out["parity"] = {"max_abs_err_vs_oracle": float(np.max(np.abs(Sg - S1))), "max_rel_err_vs_oracle": _rel_err(Sg, S1),
+                         "columns": nc, "note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"}
+    gs.close()
+    del X, R, S
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    import plaid_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(local_rank, stream.cuda_stream)
+    env = {"torch": torch, "dist": dist, "ctx": ctx, "dev": dev, "stream": stream, "world": world, "rank": rank,
+           "use_dist": use_dist}
+
+    c2 = run_c2(a, env)
+    blocks = {}
+    if world == 1 and not use_dist:
+        for name, fn in (("c3", lambda: run_sparse_ssgsea(a, env, a.c3_cells, "C3", False)), ("c4", lambda: run_c4(a, env))):
+            if a.config in ("all", name):
+                try:
+                    blocks[name] = fn()
+                except Exception as exc:  # a failing secondary block must not take the headline line with it
+                    blocks[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+                    torch.cuda.empty_cache()
+    elif a.config == "all":
+        try:
+            blocks["c5_shard"] = run_sparse_ssgsea(a, env, a.c5_cells_per_gpu, "C5 shard", True)
+        except Exception as exc:
+            blocks["c5_shard"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
 
     if rank == 0:
         out = {
             "metric": "sample x geneset scores/sec at 20k genes (plaid(): crossprod + median normalisation)",
-            "value": round(value, 1), "unit": "scores/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "value": round(c2["value"], 1), "unit": "scores/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(c2["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2 dense plaid(): {g} genes x {n} samples/GPU x {m} gene sets "
-                                   f"(z={z} memberships), inputs resident in HBM",
-                       "genes": g, "samples_per_gpu": n, "sets": m, "memberships": z,
-                       "parallelism": f"sample-shard x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "phases_ms": {"spmm": round(spmm_ms, 4), "normalize_medians": round(norm_ms, 4)},
-            "parity": parity, "gather": gather, "mixed_precision": mixed,
+            "config": c2["config"], "roofline": c2["roofline"], "cpu_baseline": c2["cpu_baseline"],
+            "phases_ms": c2["phases_ms"], "kernels": c2["kernels"], "parity": c2["parity"], "gather": c2["gather"],
+            "mixed_precision": c2["mixed_precision"],
         }
+        out.update(blocks)
         print(json.dumps(out))
-    gs.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

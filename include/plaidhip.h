@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLAIDHIP_VERSION 100 /* 0.1.0 */
+#define PLAIDHIP_VERSION 200 /* 0.2.0 */
 
 enum plaidhip_status {
   PLAIDHIP_OK = 0,
@@ -78,6 +78,20 @@ int plaidhip_synchronize(plaidhip_ctx* ctx);
  * sums stay fp64; applies to dense X with 8,192 < genes <= 20,448, everything else keeps fp64.        */
 enum { PLAIDHIP_PRECISION_F64 = 0, PLAIDHIP_PRECISION_MIXED = 1 };
 int plaidhip_set_precision(plaidhip_ctx* ctx, int mode);
+/* Enqueue on `stream` (a hipStream_t) from now on; NULL means the device's null stream, e.g. the
+ * default stream of a host framework (plaidhip_init treats NULL as "create a private stream", so a
+ * caller that wants the null stream says so here).  A private stream created by init is destroyed. */
+int plaidhip_set_stream(plaidhip_ctx* ctx, void* stream);
+/* Kernel-selection knobs of one context (tests and tools use them to pin a path; the defaults choose
+ * by shape).  Unknown option or value: PLAIDHIP_EINVAL.                                              */
+enum plaidhip_option {
+  PLAIDHIP_OPT_SPMM_DENSE_KERNEL = 1,  /* 0 auto (default) | 1 one-column kernel | 2 pair kernel wherever it applies */
+  PLAIDHIP_OPT_SPMM_SPARSE_KERNEL = 2, /* 0 auto: by nnz(X) (default) | 1 scatter | 2 gather                        */
+  PLAIDHIP_OPT_NT_STORE = 3,           /* -1 auto (default) | 0 plain stores of S | 1 streaming stores              */
+  PLAIDHIP_OPT_RANKS_F32 = 4,          /* 1 (default): rank inputs take the fp32-staged crossprod (exact) | 0: fp64 */
+  PLAIDHIP_OPT_RANK_KERNEL = 5         /* 0 auto (default) | 1 sorting network | 2 bucket ranker                    */
+};
+int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value);
 /* device memory helpers for hosts without a tensor library (R) */
 int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr);
 int plaidhip_free(plaidhip_ctx* ctx, void* dptr);
@@ -112,9 +126,12 @@ int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]);
 int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
                                 int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
                                 double beta, void* S, int64_t lds, void* flags);
-/* same with X as CSC (dgCMatrix) -- sparse branch of Matrix::crossprod at R/plaid.R:107. */
+/* same with X as CSC (dgCMatrix) -- sparse branch of Matrix::crossprod at R/plaid.R:107.
+ * `nnz`: number of stored values of X when the caller knows it (Xp[n] on the host), else -1.  It picks
+ * the kernel: sparse-aware scatter below 12.5 % stored values, column gather above; with -1 both are
+ * enqueued and the one that does not apply returns at once (the value is then read on the device). */
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
-                              const void* Xi, const void* Xx, int32_t n, int stat, double alpha,
+                              const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                               const void* alpha_div, double beta, void* S, int64_t lds, void* flags);
 
 /* colranks(), dense branch: t(matrixStats::colRanks(as.matrix(X), ties.method))
@@ -127,8 +144,12 @@ int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ld
                                     int64_t ldr, void* colmax);
 /* sparse_colranks() (R/plaid.R:631-650): ranks of the stored non-zeros of each CSC column
  * among themselves; only @x is produced, pattern unchanged (R/plaid.R:645-646).          */
+/* `max_col_nnz`: an upper bound on the number of stored values of any column (it sizes the workgroups
+ * and their LDS; the number of rows of X is always valid, a tight bound is faster).  The call is
+ * stream-ordered like every dev entry point: nothing is read back to size the launch.               */
 int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
-                                  int ties, int is_signed, double power, void* Rx, void* colmax);
+                                  int32_t max_col_nnz, int ties, int is_signed, double power, void* Rx,
+                                  void* colmax);
 
 /* colranks() on a dgCMatrix WITHOUT keep.zero (R/plaid.R:602-609 -> sparseMatrixStats::colRanks):
  * the zeros are ranked too and the result is DENSE g x n -- same numbers as the dense branch on

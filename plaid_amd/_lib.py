@@ -15,6 +15,14 @@ OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ENODEVICE = range(6)
 STAT = {"mean": 0, "sum": 1}
 TIES = {"average": 0, "min": 1, "max": 2}
 FLAG_HAS_NEG, FLAG_HAS_ZERO, FLAG_HAS_NAN = 1, 2, 4
+# enum plaidhip_option and its values (include/plaidhip.h)
+OPTIONS = {
+    "spmm_dense_kernel": (1, {"auto": 0, "single": 1, "pair": 2}),
+    "spmm_sparse_kernel": (2, {"auto": 0, "scatter": 1, "gather": 2}),
+    "nt_store": (3, {"auto": -1, "off": 0, "on": 1}),
+    "ranks_f32": (4, {"off": 0, "on": 1}),
+    "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2}),
+}
 
 
 class PlaidHipError(RuntimeError):
@@ -34,6 +42,8 @@ SIGNATURES = {
     "plaidhip_finalize": [_vp],
     "plaidhip_synchronize": [_vp],
     "plaidhip_set_precision": [_vp, _int],
+    "plaidhip_set_stream": [_vp, _vp],
+    "plaidhip_set_option": [_vp, _int, _int],
     "plaidhip_malloc": [_vp, C.c_size_t, C.POINTER(_vp)],
     "plaidhip_free": [_vp, _vp],
     "plaidhip_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
@@ -42,9 +52,9 @@ SIGNATURES = {
     "plaidhip_geneset_destroy": [_vp],
     "plaidhip_geneset_info": [_vp, C.POINTER(_i64)],
     "plaidhip_dev_spmm_dense_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
-    "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
-    "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _int, _int, _f64, _vp, _vp],
+    "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _vp],
     "plaidhip_dev_colranks_csc_dense_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_minflags": [_vp, _vp, _i64, _vp],
     "plaidhip_dev_col_medians": [_vp, _vp, _i64, _i32, _i32, _int, _vp, _vp],

@@ -41,6 +41,12 @@ int ensure_workspace(plaidhip_ctx* ctx, size_t bytes) {
   return PLAIDHIP_OK;
 }
 
+int32_t host_max_col_nnz(const int32_t* Xp, int32_t n) {
+  int32_t mx = 0;
+  for (int32_t c = 0; c < n; ++c) mx = std::max(mx, Xp[c + 1] - Xp[c]);
+  return mx;
+}
+
 int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask) {
   const uint32_t bit = 1u << (ctx->device & 31);
   if (*done_mask & bit) return PLAIDHIP_OK;
@@ -153,6 +159,20 @@ int normalize_on_device(plaidhip_ctx* ctx, double* dS, int32_t m, int32_t n, int
   return PLAIDHIP_OK;
 }
 
+// dgCMatrix slots handed over by a host language: @p non-decreasing from 0, @i inside [0, g)
+int check_host_csc(const int32_t* Xp, const int32_t* Xi, int32_t g, int32_t n) {
+  PH_REQUIRE(Xp != nullptr, "null Xp");
+  PH_REQUIRE(Xp[0] == 0, "Xp[0] = %d, expected 0", Xp[0]);
+  for (int32_t c = 0; c < n; ++c)
+    PH_REQUIRE(Xp[c + 1] >= Xp[c], "Xp decreases at column %d (more than 2^31-1 stored values? split the matrix by columns)", c);
+  if (Xi != nullptr) {
+    const int64_t zx = Xp[n];
+    for (int64_t q = 0; q < zx; ++q)
+      PH_REQUIRE(Xi[q] >= 0 && Xi[q] < g, "Xi[%lld] = %d outside [0, %d)", (long long)q, Xi[q], g);
+  }
+  return PLAIDHIP_OK;
+}
+
 int check_host_common(const void* G_p, int32_t g, int32_t n, int32_t m) {
   PH_REQUIRE(g > 0 && n >= 0 && m >= 0, "bad dims g=%d n=%d m=%d", g, n, m);
   PH_REQUIRE(G_p != nullptr, "null Gp");
@@ -165,7 +185,6 @@ extern "C" {
 
 int plaidhip_version(void) { return PLAIDHIP_VERSION; }
 
-// not part of include/plaidhip.h: selects a diagnostic SpMM variant for tools/bench_spmm.py
 int plaidhip_set_precision(plaidhip_ctx* ctx, int mode) {
   PH_CTX(ctx);
   PH_REQUIRE(mode == PLAIDHIP_PRECISION_F64 || mode == PLAIDHIP_PRECISION_MIXED, "set_precision: unknown mode %d", mode);
@@ -173,7 +192,47 @@ int plaidhip_set_precision(plaidhip_ctx* ctx, int mode) {
   return PLAIDHIP_OK;
 }
 
+int plaidhip_set_stream(plaidhip_ctx* ctx, void* stream) {
+  PH_CTX(ctx);
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream) PH_HIP(hipStreamDestroy(ctx->stream));
+  ctx->stream = reinterpret_cast<hipStream_t>(stream);   // nullptr: the null stream
+  ctx->own_stream = false;
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
+  PH_CTX(ctx);
+  switch (option) {
+    case PLAIDHIP_OPT_SPMM_DENSE_KERNEL:
+      PH_REQUIRE(value >= 0 && value <= 2, "set_option: dense kernel %d (0 auto, 1 one-column, 2 pair)", value);
+      ctx->opt_dense_kernel = value;
+      break;
+    case PLAIDHIP_OPT_SPMM_SPARSE_KERNEL:
+      PH_REQUIRE(value >= 0 && value <= 2, "set_option: sparse kernel %d (0 auto, 1 scatter, 2 gather)", value);
+      ctx->opt_sparse_kernel = value;
+      break;
+    case PLAIDHIP_OPT_NT_STORE:
+      PH_REQUIRE(value >= -1 && value <= 1, "set_option: nt_store %d (-1 auto, 0, 1)", value);
+      ctx->opt_nt_store = value;
+      break;
+    case PLAIDHIP_OPT_RANKS_F32:
+      PH_REQUIRE(value == 0 || value == 1, "set_option: ranks_f32 %d (0, 1)", value);
+      ctx->opt_ranks_f32 = value;
+      break;
+    case PLAIDHIP_OPT_RANK_KERNEL:
+      PH_REQUIRE(value >= 0 && value <= 2, "set_option: rank kernel %d (0 auto, 1 network, 2 bucket)", value);
+      ctx->opt_rank_kernel = value;
+      break;
+    default:
+      PH_REQUIRE(false, "set_option: unknown option %d", option);
+  }
+  return PLAIDHIP_OK;
+}
+
+#ifdef PLAIDHIP_DIAG
 int plaidhip_debug_set_ablation(int mode, void* dbg) { debug_set_ablation(mode, dbg); return PLAIDHIP_OK; }
+#endif
 
 const char* plaidhip_last_error_string(void) { return g_err; }
 
@@ -284,7 +343,7 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
 }
 
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
-                              const void* Xi, const void* Xx, int32_t n, int stat, double alpha,
+                              const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                               const void* alpha_div, double beta, void* S, int64_t lds, void* flags) {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm_csc: null geneset");
@@ -293,7 +352,7 @@ int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
   PH_REQUIRE(lds >= gs->m, "spmm_csc: lds=%lld < m=%d", (long long)lds, gs->m);
   PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_csc: bad stat %d", stat);
   return launch_spmm_csc_f64(ctx, gs, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
-                             static_cast<const double*>(Xx), n, stat, alpha,
+                             static_cast<const double*>(Xx), n, nnz, stat, alpha,
                              static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                              static_cast<uint32_t*>(flags));
 }
@@ -317,13 +376,14 @@ int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ld
 }
 
 int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
-                                  int ties, int is_signed, double power, void* Rx, void* colmax) {
+                                  int32_t max_col_nnz, int ties, int is_signed, double power, void* Rx,
+                                  void* colmax) {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties));
-  PH_REQUIRE(n >= 0, "colranks_csc: n=%d", n);
+  PH_REQUIRE(n >= 0 && max_col_nnz >= 0, "colranks_csc: n=%d max_col_nnz=%d", n, max_col_nnz);
   PH_REQUIRE(n == 0 || Xp != nullptr, "colranks_csc: null Xp");
   return launch_colranks_csc_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const double*>(Xx),
-                                 n, ties, is_signed, power, static_cast<double*>(Rx),
+                                 n, max_col_nnz, ties, is_signed, power, static_cast<double*>(Rx),
                                  static_cast<double*>(colmax));
 }
 
@@ -412,6 +472,7 @@ int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, 
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(Xp != nullptr && (n == 0 || S_out), "plaid_csc: null Xp/S_out");
+  PH_TRY(check_host_csc(Xp, Xi, g, n));
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   const int64_t zx = Xp[n];
   GenesetHolder gh;
@@ -429,7 +490,7 @@ int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, 
   PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
   PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), n, stat,
+  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), n, zx, stat,
                              1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
   if (normalize)
     PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
@@ -481,6 +542,7 @@ int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx
   PH_CTX(ctx);
   PH_TRY(check_ties(ties));
   PH_REQUIRE(n >= 0 && Xp != nullptr, "colranks_csc: bad arguments");
+  PH_TRY(check_host_csc(Xp, nullptr, 0, n));
   const int64_t zx = Xp[n];
   if (zx == 0) return PLAIDHIP_OK;
   PH_REQUIRE(Xx && Rx_out, "colranks_csc: null Xx/Rx_out");
@@ -490,8 +552,8 @@ int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx
   PH_TRY(dR.alloc((size_t)zx * 8));
   PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
   PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
-  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, ties, is_signed, 1.0,
-                                 dR.as<double>(), nullptr));
+  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, host_max_col_nnz(Xp, n), ties, is_signed,
+                                 1.0, dR.as<double>(), nullptr));
   PH_HIP(hipMemcpyAsync(Rx_out, dR.p, (size_t)zx * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
@@ -502,6 +564,7 @@ int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int3
   PH_CTX(ctx);
   PH_TRY(check_ties(ties));
   PH_REQUIRE(g >= 0 && n >= 0 && Xp != nullptr, "colranks_csc_dense: bad arguments");
+  PH_TRY(check_host_csc(Xp, Xi, g, n));
   if ((int64_t)g * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(R_out != nullptr, "colranks_csc_dense: null R_out");
   const int64_t zx = Xp[n];
@@ -583,6 +646,7 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(Xp != nullptr, "ssgsea_csc: null Xp");
+  PH_TRY(check_host_csc(Xp, Xi, g, n));
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(S_out != nullptr, "ssgsea_csc: null S_out");
   const int64_t zx = Xp[n];
@@ -604,12 +668,12 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
   PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
   // sparse branch: ranks of the non-zeros only, zeros stay 0 (R/plaid.R:600-601, 631-650); the
   // "- 0.5" of R/plaid.R:251 applies to the zeros too, which the (alpha, beta) epilogue covers.
-  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, PLAIDHIP_TIES_AVERAGE, 0,
-                                 1.0 + alpha, dRx.as<double>(), d_colmax));
+  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, host_max_col_nnz(Xp, n),
+                                 PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha, dRx.as<double>(), d_colmax));
   double* d_gmax = d_red + 2;   // max(rX), stays on the device
   PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dRx.as<double>(), n,
+  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dRx.as<double>(), n, zx,
                              PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5, dS.as<double>(), m, d_flags));
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -643,6 +707,7 @@ int dense_average_ranks(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
     PH_TRY(launch_colranks_dense_f64(ctx, ri.dX.as<double>(), g, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.R, g,
                                      ri.d_colmax));
   } else {
+    PH_TRY(check_host_csc(Xp, Xi, g, n));
     const int64_t zx = Xp[n];
     PH_TRY(ri.dXp.alloc((size_t)(n + 1) * 4));
     PH_TRY(ri.dXi.alloc((size_t)zx * 4));
@@ -730,6 +795,7 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   GenesetHolder gh;
   PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   const bool sparse = Xp != nullptr;
+  if (sparse) PH_TRY(check_host_csc(Xp, Xi, g, n));
   const int64_t nvals = sparse ? (int64_t)Xp[n] : (int64_t)g * n;
   DevBuf dX, dXp, dXi, dS, dsmall, dcol;
   PH_TRY(dX.alloc((size_t)nvals * 8));
@@ -759,7 +825,7 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   PH_TRY(dS.alloc((size_t)m * n * 8));
   const int stat = score_mean ? PLAIDHIP_STAT_MEAN : PLAIDHIP_STAT_SUM;
   if (sparse) {
-    PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dX.as<double>(), n, stat, 1.0,
+    PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dX.as<double>(), n, nvals, stat, 1.0,
                                nullptr, 0.0, dS.as<double>(), m, nullptr));
   } else {
     PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), g, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m,

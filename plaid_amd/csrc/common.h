@@ -57,6 +57,12 @@ struct plaidhip_ctx {
   struct cached_geneset { uint64_t hash, hash2; int32_t g, m; struct plaidhip_geneset* gs; };
   std::vector<cached_geneset> gs_cache;
   int precision = 0;   // PLAIDHIP_PRECISION_*: 0 fp64 throughout (default), 1 fp32 operand staging in the dense SpMM
+  // plaidhip_set_option (include/plaidhip.h: enum plaidhip_option)
+  int opt_dense_kernel = 0;    // 0 auto | 1 one-column | 2 pair wherever it applies
+  int opt_sparse_kernel = 0;   // 0 auto | 1 scatter | 2 gather
+  int opt_nt_store = -1;       // -1 auto | 0 | 1
+  int opt_ranks_f32 = 1;       // rank inputs take the fp32-staged crossprod
+  int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
 };
 
 // Prepared membership (built by geneset.cpp, see the header comment there).
@@ -179,15 +185,18 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
                                 bool auto_select);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
-                        const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
+                        const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz /* -1: unknown */, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
-void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ only)
+#ifdef PLAIDHIP_DIAG
+void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ build only, make diag)
+#endif
 // kernels_rank.hip
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
                               int ties, int is_signed, double power, double* R, int64_t ldr,
                               double* colmax);
-int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
+int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n, int32_t max_col_nnz,
                             int ties, int is_signed, double power, double* Rx, double* colmax);
+int32_t host_max_col_nnz(const int32_t* Xp, int32_t n);   // longest column of a host-side CSC pointer array
 int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                                   int32_t g, int32_t n, int ties, int is_signed, double power, double* R,
                                   int64_t ldr, double* colmax);

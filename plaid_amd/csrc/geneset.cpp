@@ -97,13 +97,17 @@ struct TilePlan {
 };
 
 // Relative cost of one extra LDS pass (a 2-way conflict inside one lane group) against a whole
-// extra gather step; PLAIDHIP_CONFLICT_COST overrides (>= 1 disables conflicted steps).
+// extra gather step; PLAIDHIP_CONFLICT_COST overrides it in the tools/ build (>= 1 disables conflicted steps).
 double conflict_cost() {
+#ifdef PLAIDHIP_DIAG
   static const double c = [] {
     const char* e = getenv("PLAIDHIP_CONFLICT_COST");
     return e ? atof(e) : 0.2;
   }();
   return c;
+#else
+  return 0.2;
+#endif
 }
 
 // Number of steps T (a multiple of 8) for a tile whose longest lane has Lmax reads and whose slot
@@ -199,16 +203,18 @@ struct HostPlan {
 // SIMD w % 4; w / 4 is its age there).  The SIMD arbiter serves the oldest ready wave first, so with
 // equal shares the older waves finish early and the youngest one ends up alone on the SIMD, which a
 // single wave cannot keep busy.  Shares proportional to the speed each age actually gets let all
-// waves reach the end-of-column barrier together.  PLAIDHIP_WAVE_WEIGHTS="a,b,c,d" overrides.
+// waves reach the end-of-column barrier together.  PLAIDHIP_WAVE_WEIGHTS="a,b,c,d" overrides (tools/ build).
 void wave_weights(int waves, std::vector<double>& wt, const double* share16) {
   double age[4] = {1.0, 1.0, 1.0, 1.0};
   if (waves == 16) { age[0] = share16[0]; age[1] = share16[1]; age[2] = share16[2]; age[3] = share16[3]; }
+#ifdef PLAIDHIP_DIAG
   if (const char* e = getenv("PLAIDHIP_WAVE_WEIGHTS")) {
     double a, b, c, d;
     if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4 && a > 0 && b > 0 && c > 0 && d > 0) {
       age[0] = a; age[1] = b; age[2] = c; age[3] = d;
     }
   }
+#endif
   wt.resize(waves);
   for (int w = 0; w < waves; ++w) wt[w] = age[std::min(3, w / 4)];
 }
@@ -503,8 +509,10 @@ int upload(plaidhip_ctx* ctx, const std::vector<T>& h, T** d) {
 
 namespace plaidhip {
 int spmm_block_for_genes(int32_t g) {
-  static const char* e = getenv("PLAIDHIP_SPMM_BLOCK");   // tuning knob (tools/)
+#ifdef PLAIDHIP_DIAG
+  static const char* e = getenv("PLAIDHIP_SPMM_BLOCK");   // tuning knob (tools/ build)
   if (e && g > 2048) return atoi(e) == 512 ? 512 : 1024;
+#endif
   return g > 8192 ? 1024 : (g > 2048 ? 512 : 256);
 }
 }  // namespace plaidhip

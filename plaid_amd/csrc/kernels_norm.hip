@@ -554,16 +554,10 @@ affine_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n, double 
   }
 }
 
-// out[0] = min, out[1] = max over non-NaN values (single workgroup, deterministic)
-__global__ void __launch_bounds__(1024)
-minmax_kernel(const double* __restrict__ v, int64_t count, double* out) {
-  __shared__ double s_mn[1024], s_mx[1024];
+// min / max over non-NaN values, two stages (deterministic): every workgroup of stage one reduces a slice of v to
+// {min, max} (part[b], part[nb + b]); one workgroup folds the partials into out[0] = min, out[1] = max
+__device__ __forceinline__ void block_minmax_1024(double mn, double mx, double* s_mn, double* s_mx, double& omn, double& omx) {
   const int tid = threadIdx.x;
-  double mn = INFINITY, mx = -INFINITY;
-  for (int64_t i = tid; i < count; i += 1024) {
-    const double x = v[i];
-    if (x == x) { mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
-  }
   s_mn[tid] = mn; s_mx[tid] = mx;
   __syncthreads();
   for (int h = 512; h >= 1; h >>= 1) {
@@ -573,7 +567,34 @@ minmax_kernel(const double* __restrict__ v, int64_t count, double* out) {
     }
     __syncthreads();
   }
-  if (tid == 0) { out[0] = s_mn[0]; out[1] = s_mx[0]; }
+  omn = s_mn[0]; omx = s_mx[0];
+}
+
+__global__ void __launch_bounds__(1024)
+minmax_partial_kernel(const double* __restrict__ v, int64_t count, double* __restrict__ part) {
+  __shared__ double s_mn[1024], s_mx[1024];
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 1024) {
+    const double x = v[i];
+    if (x == x) { mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+  }
+  double omn, omx;
+  block_minmax_1024(mn, mx, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) { part[blockIdx.x] = omn; part[gridDim.x + blockIdx.x] = omx; }
+}
+
+__global__ void __launch_bounds__(1024)
+minmax_final_kernel(const double* __restrict__ part, int nb, double* out) {
+  __shared__ double s_mn[1024], s_mx[1024];
+  double mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    const double a = part[i], b = part[nb + i];
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  double omn, omx;
+  block_minmax_1024(mn, mx, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) { out[0] = omn; out[1] = omx; }
 }
 
 int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar) {
@@ -605,7 +626,14 @@ int launch_affine(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t 
 }
 
 int launch_minmax(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
-  hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, count, out);
+  int64_t nb64 = (count + 8 * 1024 - 1) / (8 * 1024);
+  const int cap = ctx->num_cu * 2;
+  const int nb = nb64 < 1 ? 1 : (nb64 > cap ? cap : (int)nb64);
+  int rc = ensure_workspace(ctx, (size_t)nb * 2 * sizeof(double));
+  if (rc != PLAIDHIP_OK) return rc;
+  double* part = reinterpret_cast<double*>(ctx->ws);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(1024), 0, ctx->stream, v, count, part);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nb, out);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }
@@ -1118,8 +1146,12 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   if (n == 0) return PLAIDHIP_OK;
   // default: register-resident radix selection up to 6,144 values per column, wave-per-column streaming beyond
   // (switch-over measured).  PLAIDHIP_MEDIAN_KERNEL = stream | radix | bits | sample | sort |
-  // select forces one of the kernels (tools/ and tests; the older ones are kept as cross-checks)
+  // select forces one of the kernels in the tools/ build (make diag; the older ones are kept as cross-checks)
+#ifdef PLAIDHIP_DIAG
   static const char* force = getenv("PLAIDHIP_MEDIAN_KERNEL");
+#else
+  const char* const force = nullptr;
+#endif
   const bool f2 = force && force[0] == 's';
   const bool want_stream = (f2 && force[1] == 't') || (!force && m > 6144);
   const bool want_radix = (force && force[0] == 'r') || (!force && m <= 6144);

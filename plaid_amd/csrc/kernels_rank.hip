@@ -13,6 +13,7 @@
 // (R: NA stays NA) and do not disturb the ranks of the others.
 #include "common.h"
 #include "device_sort.h"
+#include "rank_bucket.h"
 
 namespace plaidhip {
 
@@ -34,7 +35,9 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
                     int32_t n, int ties, int is_signed, double power, double* __restrict__ R,
                     int64_t ldr, double* __restrict__ colmax, uint64_t* gkeys, int64_t gkeys_stride,
                     const int32_t* __restrict__ Xi_dense,  // non-null: CSC input, DENSE result (zeros ranked)
-                    double* __restrict__ dense_scratch) {  // g_dense doubles per workgroup
+                    double* __restrict__ dense_scratch,    // g_dense doubles per workgroup
+                    const int32_t* __restrict__ col_list,  // non-null: rank only these columns (left over by the
+                    const int32_t* __restrict__ col_count) { // bucket kernel; both live in device memory)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
@@ -53,7 +56,9 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
     s_f64 = reinterpret_cast<double*>(smem_raw + gkeys_stride * 8 + 16);
   }
 
-  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+  const int ncols = (col_list != nullptr) ? *col_count : n;
+  for (int ci = blockIdx.x; ci < ncols; ci += gridDim.x) {
+    const int c = (col_list != nullptr) ? col_list[ci] : ci;
     const double* xc;
     double* rc;
     uint32_t cnt;
@@ -94,7 +99,7 @@ colranks_f64_kernel(const double* __restrict__ Xv,  // values: dense matrix or C
     bitonic_sort_f64_lds(keys, cnt);  // starts and ends with a barrier
     const uint32_t nvalid = cnt - s_u32[0];
 
-    double vmax = -INFINITY;
+    double vmax = (Xp != nullptr && Xi_dense == nullptr) ? 0.0 : -INFINITY;   // sparse ranks: the implicit zeros
     for (uint32_t i = tid; i < cnt; i += nthr) {
       const double x0 = xc[i];
       const double x = is_signed ? fabs(x0) : x0;
@@ -131,7 +136,8 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
                      const int32_t* __restrict__ Xp, int32_t n, int ties, int is_signed, double power,
                      double* __restrict__ R, int64_t ldr, double* __restrict__ colmax, int L,
                      int32_t key_bytes, const int32_t* __restrict__ Xi_dense,
-                     double* __restrict__ dense_scratch) {
+                     double* __restrict__ dense_scratch, const int32_t* __restrict__ col_list,
+                     const int32_t* __restrict__ col_count) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
@@ -139,7 +145,9 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
   uint32_t* s_u32 = reinterpret_cast<uint32_t*>(smem_raw + key_bytes);
   double* s_f64 = reinterpret_cast<double*>(smem_raw + key_bytes + 16);
 
-  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+  const int ncols = (col_list != nullptr) ? *col_count : n;
+  for (int ci = blockIdx.x; ci < ncols; ci += gridDim.x) {
+    const int c = (col_list != nullptr) ? col_list[ci] : ci;
     const double* xc;
     double* rc;
     uint32_t cnt;
@@ -206,7 +214,7 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
     const double* sk = reinterpret_cast<const double*>(keys);
     int steps = 0;
     while ((1u << steps) <= nvalid) ++steps;              // ceil(log2(nvalid + 1))
-    double vmax = -INFINITY;
+    double vmax = (Xp != nullptr && Xi_dense == nullptr) ? 0.0 : -INFINITY;   // sparse ranks: the implicit zeros
     for (uint32_t i0 = tid; i0 < cnt; i0 += 2 * nthr) {
       const uint32_t i1 = i0 + nthr;
       const bool has1 = i1 < cnt;
@@ -268,32 +276,15 @@ colranks_regs_kernel(const double* __restrict__ Xv, int64_t ldx, int32_t g_dense
   }
 }
 
-__global__ void max_col_nnz_kernel(const int32_t* Xp, int32_t n, int32_t* out) {
-  int32_t v = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int32_t d = Xp[i + 1] - Xp[i];
-    v = d > v ? d : v;
-  }
-  for (int off = 32; off >= 1; off >>= 1) {
-    const int32_t o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+__global__ void fill_f64_kernel(double* p, int32_t n, double v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense,
-                        const int32_t* Xp, int32_t n, int32_t max_len, int ties, int is_signed,
-                        double power, double* R, int64_t ldr, double* colmax,
-                        const int32_t* Xi_dense = nullptr) {
-  if (n == 0 || max_len == 0) return PLAIDHIP_OK;
-  // CSC input with dense result: persistent grid, one scratch column per workgroup
-  double* dscratch = nullptr;
-  int grid_cap = n;
-  size_t ws_off = 0;
-  if (Xi_dense != nullptr) {
-    grid_cap = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
-    ws_off = (size_t)grid_cap * (size_t)g_dense * 8;
-  }
+// the sorting-network kernels: all columns (col_list == nullptr) or the columns the bucket kernel left over
+static int launch_network(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense, const int32_t* Xp,
+                          int32_t n, int32_t max_len, int ties, int is_signed, double power, double* R, int64_t ldr,
+                          double* colmax, const int32_t* Xi_dense, double* dscratch, int grid_cap, size_t ws_off,
+                          const int32_t* col_list, const int32_t* col_count) {
   const int block = max_len > 8192 ? 1024 : (max_len > 2048 ? 512 : 256);
   const size_t scratch = 16 + 16 * sizeof(double);
   if (max_len > 8192 && max_len <= kMaxLdsGenes) {
@@ -305,40 +296,118 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
     const int threads = (1 << L) / 32;
     const int32_t key_bytes = ((max_len + 31) & ~31) * 8;     // swizzle permutes inside 32-key groups
     const size_t smem = (size_t)key_bytes + scratch;
-    if (Xi_dense != nullptr) {
-      int rc = ensure_workspace(ctx, ws_off);
-      if (rc != PLAIDHIP_OK) return rc;
-      dscratch = reinterpret_cast<double*>(ctx->ws);
-    }
     hipLaunchKernelGGL(colranks_regs_kernel, dim3(grid_cap), dim3(threads), smem, ctx->stream, Xv, ldx,
                        g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, L, key_bytes, Xi_dense,
-                       dscratch);
+                       dscratch, col_list, col_count);
   } else if (max_len <= kMaxLdsGenes) {
     PH_FULL_LDS(ctx, &colranks_f64_kernel<false>);
     const int64_t key_slots = ((int64_t)max_len + 1) & ~1ll;  // keep scratch 16-B aligned
     const size_t smem = (size_t)key_slots * 8 + scratch;
-    if (Xi_dense != nullptr) {
-      int rc = ensure_workspace(ctx, ws_off);
-      if (rc != PLAIDHIP_OK) return rc;
-      dscratch = reinterpret_cast<double*>(ctx->ws);
-    }
     hipLaunchKernelGGL(colranks_f64_kernel<false>, dim3(grid_cap), dim3(block), smem, ctx->stream, Xv, ldx,
                        g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax, (uint64_t*)nullptr,
-                       key_slots, Xi_dense, dscratch);
+                       key_slots, Xi_dense, dscratch, col_list, col_count);
   } else {
     // large columns: keys live in a global scratch slice per workgroup (L2-resident)
     const int grid = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
     const int64_t stride = ((int64_t)max_len + 1) & ~1ll;
-    int rc = ensure_workspace(ctx, ws_off + (size_t)grid * stride * 8);
-    if (rc != PLAIDHIP_OK) return rc;
-    if (Xi_dense != nullptr) dscratch = reinterpret_cast<double*>(ctx->ws);
     hipLaunchKernelGGL(colranks_f64_kernel<true>, dim3(grid), dim3(1024), scratch, ctx->stream, Xv,
                        ldx, g_dense, Xp, n, ties, is_signed, power, R, ldr, colmax,
                        reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ctx->ws) + ws_off), stride,
-                       Xi_dense, dscratch);
+                       Xi_dense, dscratch, col_list, col_count);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
+}
+
+template <int BLOCK, int KPT>
+static int launch_bucket(plaidhip_ctx* ctx, const RankBucketArgs& a, int32_t max_len, int grid) {
+  using L = RankBucketLayout<BLOCK, KPT>;
+  const size_t keys_bytes = (size_t)kRankMisc + (size_t)max_len * 8;
+  const size_t smem = keys_bytes > (size_t)L::hist_bytes ? keys_bytes : (size_t)L::hist_bytes;
+  PH_FULL_LDS(ctx, (&colranks_bucket_kernel<BLOCK, KPT>));
+  hipLaunchKernelGGL((colranks_bucket_kernel<BLOCK, KPT>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+// longest column the bucket kernel takes: 8 bytes per key + its scratch must fit the CU's LDS
+constexpr int kMaxBucketKeys = (kLdsBytes - kRankMisc) / 8;   // 20,352
+
+static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense,
+                        const int32_t* Xp, int32_t n, int32_t max_len, int ties, int is_signed,
+                        double power, double* R, int64_t ldr, double* colmax,
+                        const int32_t* Xi_dense = nullptr) {
+  if (n == 0) return PLAIDHIP_OK;
+  if (max_len == 0) {
+    // nothing to rank; a sparse column's maximum is its implicit zeros (max(rX) of R/plaid.R:251 is then 0)
+    if (colmax != nullptr) {
+      hipLaunchKernelGGL(fill_f64_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0,
+                         ctx->stream, colmax, n, Xp != nullptr ? 0.0 : -INFINITY);
+      PH_HIP(hipGetLastError());
+    }
+    return PLAIDHIP_OK;
+  }
+  // kernel choice: the bucket ranker for every column that fits the LDS (measured); the sorting
+  // network beyond, as the bucket kernel's fallback for clustered columns, and when the context asks for it
+  const bool can_bucket = max_len <= kMaxBucketKeys;
+  const bool use_bucket = can_bucket && (ctx->opt_rank_kernel == 2 || (ctx->opt_rank_kernel == 0 && max_len > 256));
+  // workspace: [densify scratch (CSC input, dense result)] [fallback counter + list] [global key scratch]
+  int grid_cap = n;
+  size_t ws_off = 0;
+  if (Xi_dense != nullptr) {
+    grid_cap = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
+    ws_off = (size_t)grid_cap * (size_t)g_dense * 8;
+  }
+  const size_t fb_off = ws_off;
+  if (use_bucket) ws_off += ((size_t)n * 4 + 16 + 255) & ~(size_t)255;
+  size_t ws_need = ws_off;
+  if (max_len > kMaxLdsGenes) {
+    const int grid = n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu;
+    ws_need += (size_t)grid * (size_t)(((int64_t)max_len + 1) & ~1ll) * 8;
+  }
+  if (ws_need > 0) {
+    const int rc = ensure_workspace(ctx, ws_need);
+    if (rc != PLAIDHIP_OK) return rc;
+  }
+  double* dscratch = Xi_dense != nullptr ? reinterpret_cast<double*>(ctx->ws) : nullptr;
+  if (!use_bucket)
+    return launch_network(ctx, Xv, ldx, g_dense, Xp, n, max_len, ties, is_signed, power, R, ldr, colmax, Xi_dense,
+                          dscratch, grid_cap, ws_off, nullptr, nullptr);
+
+  int32_t* fb_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctx->ws) + fb_off);
+  int32_t* fb_list = fb_count + 4;
+  PH_HIP(hipMemsetAsync(fb_count, 0, 16, ctx->stream));
+  RankBucketArgs a{};
+  a.Xv = Xv;
+  a.ldx = ldx;
+  a.g_dense = g_dense;
+  a.Xp = Xp;
+  a.n = n;
+  a.ties = ties;
+  a.is_signed = is_signed;
+  a.power = power;
+  const double q4 = power * 4.0;
+  a.pow_q4 = (power != 1.0 && q4 >= 1.0 && q4 <= 16.0 && q4 == (double)(int)q4) ? (int)q4 : 0;
+  a.R = R;
+  a.ldr = ldr;
+  a.colmax = colmax;
+  a.Xi_dense = Xi_dense;
+  a.dense_scratch = dscratch;
+  a.fb_count = fb_count;
+  a.fb_list = fb_list;
+  int rc;
+  // 512 threads x 40 keys for a 20k-gene column: 1,024 threads would cap the kernel at 128 registers, short of
+  // the 120 a thread needs for its keys and their state alone
+  if (max_len <= 2048) rc = launch_bucket<256, 8>(ctx, a, max_len, grid_cap);
+  else if (max_len <= 4096) rc = launch_bucket<256, 16>(ctx, a, max_len, grid_cap);
+  else if (max_len <= 8192) rc = launch_bucket<512, 16>(ctx, a, max_len, grid_cap);
+  else if (max_len <= 12288) rc = launch_bucket<512, 24>(ctx, a, max_len, grid_cap);
+  else rc = launch_bucket<512, 40>(ctx, a, max_len, grid_cap);
+  if (rc != PLAIDHIP_OK) return rc;
+  // columns the bucket kernel gave up on (clustered values): a small persistent grid reads the device-side list
+  const int fb_grid = grid_cap < ctx->num_cu ? grid_cap : ctx->num_cu;
+  return launch_network(ctx, Xv, ldx, g_dense, Xp, n, max_len, ties, is_signed, power, R, ldr, colmax, Xi_dense,
+                        dscratch, fb_grid, ws_off, fb_list, fb_count);
 }
 
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
@@ -353,19 +422,10 @@ int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const in
   return launch_ranks(ctx, Xx, 0, g, Xp, n, g, ties, is_signed, power, R, ldr, colmax, Xi);
 }
 
-int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
+// stream-ordered: the caller states the longest column (include/plaidhip.h), nothing is read back
+int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n, int32_t max_col_nnz,
                             int ties, int is_signed, double power, double* Rx, double* colmax) {
-  if (n == 0) return PLAIDHIP_OK;
-  // the LDS size depends on the longest column: one small reduction + 4-byte D2H
-  int rc = ensure_workspace(ctx, 256);
-  if (rc != PLAIDHIP_OK) return rc;
-  int32_t* d_max = reinterpret_cast<int32_t*>(ctx->ws);
-  PH_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
-  hipLaunchKernelGGL(max_col_nnz_kernel, dim3(256), dim3(256), 0, ctx->stream, Xp, n, d_max);
-  int32_t h_max = 0;
-  PH_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return launch_ranks(ctx, Xx, 0, 0, Xp, n, h_max, ties, is_signed, power, Rx, 0, colmax);
+  return launch_ranks(ctx, Xx, 0, 0, Xp, n, max_col_nnz, ties, is_signed, power, Rx, 0, colmax);
 }
 
 }  // namespace plaidhip

@@ -28,9 +28,14 @@
 
 namespace plaidhip {
 
-// diagnostic kernel variants (tools/ only, plaidhip_debug_set_ablation)
+// diagnostic kernel variants: only in the tools/ build (make diag, -DPLAIDHIP_DIAG); the product library
+// instantiates the plain kernels alone
+#ifdef PLAIDHIP_DIAG
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
+#else
+static constexpr int g_ablate = 0;
+#endif
 
 struct SpmmArgs {
   const double* X;
@@ -788,13 +793,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_SCATTER2
 }
 
-// how a sparse X is multiplied: PLAIDHIP_SPMM_SPARSE = scatter | gather | auto (default: decided on
-// the device from nnz(X): scatter below 12.5 % stored values)
-static int sparse_mode() {
-  const char* e = getenv("PLAIDHIP_SPMM_SPARSE");
-  if (e == nullptr) return 0;
-  return strcmp(e, "scatter") == 0 ? 1 : (strcmp(e, "gather") == 0 ? 2 : 0);
-}
+// how a sparse X is multiplied: plaidhip_set_option(PLAIDHIP_OPT_SPMM_SPARSE_KERNEL): 0 auto (scatter below
+// 12.5 % stored values, decided on the device from nnz(X)), 1 scatter, 2 gather
+static int sparse_mode(const plaidhip_ctx* ctx) { return ctx->opt_sparse_kernel; }
 
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
@@ -1059,12 +1060,15 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
   int grid = ctx->num_cu;
   const int npairs = (a.n + 1) / 2;
   if (grid > npairs) grid = npairs;
-  if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
+#ifdef PLAIDHIP_DIAG
+  if (g_ablate == 4) {   // in-kernel stamps
     a.dbg = g_dbg;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_mixed<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     hipLaunchKernelGGL(spmm_colpair_mixed<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else {
+  } else
+#endif
+  {
     hipLaunchKernelGGL(spmm_colpair_mixed<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
   PH_HIP(hipGetLastError());
@@ -1072,16 +1076,15 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
 }
 
 
-static int nt_store_mode(const plaidhip_geneset* gs) {
-  if (const char* e = getenv("PLAIDHIP_NT_STORE")) return atoi(e) != 0;
+static int nt_store_mode(const plaidhip_ctx* ctx, const plaidhip_geneset* gs) {
+  if (ctx->opt_nt_store >= 0) return ctx->opt_nt_store;
   return gs->rows_in_order ? 1 : 0;
 }
 
-// which dense-X kernel: PLAIDHIP_SPMM_KERNEL = pair | single (default: pair where it applies)
-static int pair_kernel_mode() {   // read per launch (tests flip it): 0 single, 1 default, 2 pair wherever possible
-  const char* e = getenv("PLAIDHIP_SPMM_KERNEL");
-  if (e == nullptr) return 1;
-  return strcmp(e, "single") == 0 ? 0 : (strcmp(e, "pair") == 0 ? 2 : 1);
+// which dense-X kernel (plaidhip_set_option(PLAIDHIP_OPT_SPMM_DENSE_KERNEL)): 0 one-column, 1 default (pair where
+// it applies), 2 pair wherever possible
+static int pair_kernel_mode(const plaidhip_ctx* ctx) {
+  return ctx->opt_dense_kernel == 1 ? 0 : (ctx->opt_dense_kernel == 2 ? 2 : 1);
 }
 
 static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx,
@@ -1104,7 +1107,7 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.npairs = (n + 1) / 2;
   a.nslices = (int32_t)pl.slices.size();
   a.ktiles = pl.ktiles;
-  a.nt_store = nt_store_mode(gs);
+  a.nt_store = nt_store_mode(ctx, gs);
   a.slices = pl.d_slices;
   a.wave_tile_off = pl.d_wave_tile_off;
   a.meta_j = pl.d_meta_j;
@@ -1127,7 +1130,9 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   if (Xp != nullptr) {   // sparse X
     PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, true>));
     hipLaunchKernelGGL((spmm_colpair_f64<false, 0, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (g_ablate == 2) {   // no index loads (tools/ only, wrong scores)
+  }
+#ifdef PLAIDHIP_DIAG
+  else if (g_ablate == 2) {   // no index loads (wrong scores)
     a.dbg = g_dbg;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
@@ -1152,14 +1157,18 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     hipLaunchKernelGGL(spmm_colpair_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else {
+  }
+#endif
+  else {
     hipLaunchKernelGGL(spmm_colpair_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }
 
+#ifdef PLAIDHIP_DIAG
 void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_cast<unsigned long long*>(dbg); }
+#endif
 
 template <bool CSC_X, int BLOCK>
 static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) {
@@ -1172,8 +1181,9 @@ static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) 
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > a.n) grid = a.n;
+#ifdef PLAIDHIP_DIAG
   if constexpr (!CSC_X && BLOCK >= 512) {
-    if (g_ablate != 0) {   // diagnostic kernels (tools/ only)
+    if (g_ablate != 0) {   // diagnostic kernels
       a.dbg = g_dbg;
 #define PLAIDHIP_ABL(N)                                                                              \
   if (g_ablate == N) {                                                                                \
@@ -1187,6 +1197,7 @@ static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) 
       return PLAIDHIP_OK;
     }
   }
+#endif
   hipLaunchKernelGGL((spmm_colgather_f64<CSC_X, BLOCK>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
@@ -1220,9 +1231,9 @@ static int launch_colgather(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmA
   return PLAIDHIP_OK;
 }
 
-static void fill_args(SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int stat, double alpha,
+static void fill_args(const plaidhip_ctx* ctx, SpmmArgs& a, const plaidhip_geneset* gs, int32_t n, int stat, double alpha,
                       const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
-  a.nt_store = nt_store_mode(gs);
+  a.nt_store = nt_store_mode(ctx, gs);
   a.alpha_div = alpha_div;
   a.n = n;
   a.m = gs->m;
@@ -1240,22 +1251,19 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
   // fp32 staging: opt-in, or free of any rounding when X holds ranks (integers / half-integers <= 20,448 are
   // exact in fp32, and so are the four-term fp32 partial sums of the kernel: < 2^17 with one fractional bit)
-  if (x_exact_in_f32) {
-    const char* e = getenv("PLAIDHIP_RANKS_F32");   // "0": keep rank inputs on the fp64 kernels (tests compare the two)
-    if (e != nullptr && e[0] == '0') x_exact_in_f32 = false;
-  }
+  if (!ctx->opt_ranks_f32) x_exact_in_f32 = false;   // PLAIDHIP_OPT_RANKS_F32 = 0: rank inputs stay on the fp64 kernels (tests compare the two)
   if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && (g_ablate == 0 || g_ablate == 4) && (ldx & 1) == 0 &&
       (reinterpret_cast<uintptr_t>(X) & 15) == 0 && gs->slices.size() == 1 && gs->slices[0].waves == 16) {
     // opt-in: fp32 operand staging (plaidhip_set_precision); one gene slice and the 1024-thread schedule only
     SpmmArgs a{};
     a.X = X;
     a.ldx = ldx;
-    fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+    fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
     return launch_colpair_mixed(ctx, gs, a);
   }
   {
     // two columns per pass when X allows 16-byte loads of both columns of a pair
-    const int mode = pair_kernel_mode();
+    const int mode = pair_kernel_mode(ctx);
     const bool aligned = (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6 || g_ablate == 7;
     if (diag && mode != 0 && aligned && !gs->pair.slices.empty())
@@ -1264,18 +1272,20 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   SpmmArgs a{};
   a.X = X;
   a.ldx = ldx;
-  fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
   return launch_colgather<false>(ctx, gs, a);
 }
 
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
-                        const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
+                        const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (g_ablate == 0 && pair_kernel_mode() != 0 && !gs->pair.slices.empty()) {
-    // sparse-aware scatter or dense-work gather: both are enqueued in auto mode and the one that does
-    // not apply returns at once (nnz(X) is only known on the device in a stream-ordered pipeline)
-    const int sm = sparse_mode();
+  if (g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
+    // sparse-aware scatter or dense-work gather.  With nnz(X) from the caller the choice is made here (one
+    // launch); without it (nnz < 0: only the device knows) both are enqueued and the one that does not apply
+    // returns at once.
+    int sm = sparse_mode(ctx);
+    if (sm == 0 && nnz >= 0) sm = (nnz * 8 < (int64_t)gs->g * n) ? 1 : 2;
     if (sm != 2) {
       const int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);
       if (rc != PLAIDHIP_OK || sm == 1) return rc;
@@ -1286,7 +1296,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
   a.Xp = Xp;
   a.Xi = Xi;
   a.Xx = Xx;
-  fill_args(a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
   return launch_colgather<true>(ctx, gs, a);
 }
 

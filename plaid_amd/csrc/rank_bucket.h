@@ -1,0 +1,478 @@
+// Bucket ranker: per-sample column ranks WITHOUT sorting (gfx950, wave64).
+//
+// colranks() / sparse_colranks() need, for every element x_i of a column,
+//     lb = #{x_j < x_i}   and   ub = #{x_j <= x_i}
+// (rank = lb + 1 | ub | (lb + 1 + ub) / 2 for ties.method min | max | average: R/plaid.R:611-619,
+// 631-650) -- counts, not an order.  One workgroup per column:
+//
+//   1. the column is read ONCE, coalesced, into registers (KPT keys per thread) as order-preserving
+//      u64 keys (exact IEEE order, -0 == +0, NaN set aside);
+//   2. a coarse histogram over K1 equal key-space intervals of [min, max] gives the column's
+//      empirical CDF; every coarse interval is cut into as many equal FINE buckets as it holds keys,
+//      so there are as many fine buckets as keys and a key's fine bucket is an interpolated rank
+//      estimate that is monotone in the key.  A second histogram + prefix sum over the fine buckets
+//      gives `start` = #{keys in earlier fine buckets} (all of them smaller);
+//   3. fine buckets hold ~1 key for any locally smooth distribution; what is left is settled exactly
+//      inside the bucket: the keys of multi-key buckets are scattered to their bucket's slots in LDS
+//      (8 bytes per key: a 20k-gene column fills the CU's LDS, which is why the histograms live in
+//      the same LDS BEFORE the keys and everything a key needs afterwards rests in registers) and
+//      each owner counts the keys of its bucket below / not above its own.
+//   4. ties: a bucket with more than kBigT keys is first compared with one representative key; if
+//      all its keys are equal (single-cell data: ~50 distinct values per column, or a dense column
+//      that is 95 % zeros) the bounds are `start` and `start + count` with no scan at all.
+//   5. a bucket that is large AND mixed (clustered values two histogram levels cannot separate)
+//      would make the in-bucket scan quadratic: the column is handed to the sorting-network kernel
+//      instead (device-side list, no host round trip).  Exactness never depends on the data.
+//
+// The owner of element i ends up with its bounds in registers, so the ranks go back to HBM as one
+// coalesced write of the column in input order; fused: signed ranks, rank^power, column maximum.
+#pragma once
+#ifndef PH_POW
+#define PH_POW pow
+#endif
+
+#include "common.h"
+#include "device_sort.h"
+
+namespace plaidhip {
+
+constexpr int kBigT = 8;              // buckets with more keys are tested for "all keys equal"
+constexpr int kFallbackCount = 256;   // a mixed bucket beyond this many keys sends the column to the network kernel
+constexpr int kRankMisc = 1024;       // bytes of reduction scratch in front of the histograms / keys
+
+struct RankBucketArgs {
+  const double* Xv;          // values: dense matrix or CSC @x
+  int64_t ldx;
+  int32_t g_dense;           // dense: column length
+  const int32_t* Xp;         // CSC column pointers (nullptr: dense)
+  int32_t n;
+  int32_t ties, is_signed;
+  double power;
+  int32_t pow_q4;            // 4 * power when that is an integer in 1..16 (power by square roots), else 0
+  double* R;
+  int64_t ldr;
+  double* colmax;
+  const int32_t* Xi_dense;   // non-null: CSC input, DENSE result (zeros ranked)
+  double* dense_scratch;     // g_dense doubles per workgroup
+  int32_t* fb_count;         // device counter + list of columns left to the network kernel
+  int32_t* fb_list;
+};
+
+// r^(q/4) for r > 0 by (correctly rounded) square roots and multiplications: a few ulp, ~6x cheaper than pow()
+__device__ __forceinline__ double pow_quarters(double r, int q) {
+  double res = 1.0, base = r;
+  for (int e = q >> 2; e; e >>= 1) {
+    if (e & 1) res *= base;
+    base *= base;
+  }
+  if (q & 3) {
+    const double s = sqrt(r);
+    if (q & 2) res *= s;
+    if (q & 1) res *= sqrt(s);
+  }
+  return res;
+}
+
+// Wave-level scans / reductions on DPP (row shifts inside the four rows of 16 lanes, then the two row
+// broadcasts): no lane-address registers to keep alive, unlike ds_bpermute-based shuffles.
+#define PH_DPP(old, src, ctrl, rmask) \
+  ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false))
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += PH_DPP(0u, v, kDppShr1, 0xf);
+  v += PH_DPP(0u, v, kDppShr2, 0xf);
+  v += PH_DPP(0u, v, kDppShr4, 0xf);
+  v += PH_DPP(0u, v, kDppShr8, 0xf);
+  v += PH_DPP(0u, v, kDppBcast15, 0xa);
+  v += PH_DPP(0u, v, kDppBcast31, 0xc);
+  return v;
+}
+
+template <bool IS_MIN>
+__device__ __forceinline__ uint64_t wave_minmax_u64(uint64_t v) {   // result valid in lane 63
+  const uint32_t idl = IS_MIN ? 0xffffffffu : 0u;
+#define PH_STEP64(ctrl, rmask)                                                            \
+  {                                                                                        \
+    const uint32_t lo_ = PH_DPP(idl, (uint32_t)v, ctrl, rmask);                            \
+    const uint32_t hi_ = PH_DPP(idl, (uint32_t)(v >> 32), ctrl, rmask);                    \
+    const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                       \
+    v = IS_MIN ? (o_ < v ? o_ : v) : (o_ > v ? o_ : v);                                    \
+  }
+  PH_STEP64(kDppShr1, 0xf) PH_STEP64(kDppShr2, 0xf) PH_STEP64(kDppShr4, 0xf) PH_STEP64(kDppShr8, 0xf)
+  PH_STEP64(kDppBcast15, 0xa) PH_STEP64(kDppBcast31, 0xc)
+#undef PH_STEP64
+  return v;
+}
+
+__device__ __forceinline__ double wave_max_f64_dpp(double x) {   // result valid in lane 63; -inf identity
+  uint64_t v = (uint64_t)__double_as_longlong(x);
+#define PH_STEPF(ctrl, rmask)                                                             \
+  {                                                                                        \
+    const uint32_t lo_ = PH_DPP(0u, (uint32_t)v, ctrl, rmask);                             \
+    const uint32_t hi_ = PH_DPP(0xfff00000u, (uint32_t)(v >> 32), ctrl, rmask);            \
+    const double o_ = __longlong_as_double((long long)(((uint64_t)hi_ << 32) | lo_));      \
+    const double c_ = __longlong_as_double((long long)v);                                  \
+    v = (uint64_t)__double_as_longlong(o_ > c_ ? o_ : c_);                                 \
+  }
+  PH_STEPF(kDppShr1, 0xf) PH_STEPF(kDppShr2, 0xf) PH_STEPF(kDppShr4, 0xf) PH_STEPF(kDppShr8, 0xf)
+  PH_STEPF(kDppBcast15, 0xa) PH_STEPF(kDppBcast31, 0xc)
+#undef PH_STEPF
+  return __longlong_as_double((long long)v);
+}
+
+// exclusive prefix sum over the workgroup's threads; s_wave: BLOCK/64 words of LDS; ends with a barrier
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t lane, uint32_t wave) {
+  const uint32_t inc = wave_incl_scan_u32(v);
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; ++w) {
+    const uint32_t t = s_wave[w];
+    base += ((uint32_t)w < wave) ? t : 0u;
+  }
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <int BLOCK, int KPT>
+struct RankBucketLayout {
+  static constexpr int CAP = BLOCK * KPT;
+  static constexpr int K1 = CAP >= 16384 ? 4096 : (CAP >= 8192 ? 2048 : (CAP >= 4096 ? 1024 : 512));
+  static constexpr int NBIG = ((CAP / (kBigT + 1) + 4) & ~3);
+  static constexpr int off_c1 = kRankMisc;                   // K1 counters, [K1] end marker, [K1 + 1] trash
+  static constexpr int off_c2 = off_c1 + (K1 + 4) * 4;       // CAP counters, [CAP] end marker, [CAP + 1] trash
+  static constexpr int off_rep = off_c2 + (CAP + 4) * 4;     // NBIG u64
+  static constexpr int off_mixed = off_rep + NBIG * 8;       // NBIG words
+  static constexpr int hist_bytes = off_mixed + NBIG * 4;
+  static constexpr int off_keys = kRankMisc;                 // 8 bytes per key, overlays the histograms
+  static_assert(K1 % BLOCK == 0 && KPT % 4 == 0, "scan shapes");
+  static_assert(hist_bytes % 16 == 0 && off_c2 % 16 == 0 && off_rep % 16 == 0, "alignment");
+};
+
+// Per-key state word after the fine prefix sum.
+//   settled  (bit 31 = 0): bits 14:0 start, bits 30:16 count            -> lb = start, ub = start + count
+//   to scan  (bit 31 = 1): bits 14:0 start, bits 22:15 slot, bits 30:23 count - 1 (count <= 256)
+__device__ __forceinline__ uint32_t st_settled(uint32_t start, uint32_t count) { return start | (count << 16); }
+__device__ __forceinline__ uint32_t st_scan(uint32_t start, uint32_t count, uint32_t slot) {
+  return 0x80000000u | start | (slot << 15) | ((count - 1u) << 23);
+}
+
+template <int BLOCK, int KPT>
+__global__ void __launch_bounds__(BLOCK)
+colranks_bucket_kernel(RankBucketArgs a) {
+  using L = RankBucketLayout<BLOCK, KPT>;
+  constexpr int K1 = L::K1, CAP = L::CAP;
+  constexpr int LOG2K1 = K1 == 4096 ? 12 : (K1 == 2048 ? 11 : (K1 == 1024 ? 10 : 9));
+  constexpr int NW = BLOCK / 64;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // misc scratch: [0,64) scan words, [64,192) minima, [192,320) maxima, [384,512) f64 maxima, [512] flag
+  uint32_t* s_wave = reinterpret_cast<uint32_t*>(smem_raw);
+  uint64_t* s_min = reinterpret_cast<uint64_t*>(smem_raw + 64);
+  uint64_t* s_max = reinterpret_cast<uint64_t*>(smem_raw + 192);
+  double* s_f64 = reinterpret_cast<double*>(smem_raw + 384);
+  uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem_raw + 512);
+  uint32_t* c1 = reinterpret_cast<uint32_t*>(smem_raw + L::off_c1);
+  uint32_t* c2 = reinterpret_cast<uint32_t*>(smem_raw + L::off_c2);
+  uint64_t* rep = reinterpret_cast<uint64_t*>(smem_raw + L::off_rep);
+  uint32_t* mixed = reinterpret_cast<uint32_t*>(smem_raw + L::off_mixed);
+  uint64_t* lkeys = reinterpret_cast<uint64_t*>(smem_raw + L::off_keys);
+
+  for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
+    // an opaque copy of the thread id per column: nothing derived from it is hoisted out of the column loop
+    // (LICM would keep dozens of per-thread addresses alive across all phases and spill)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const double* xc;
+    double* rc;
+    uint32_t cnt;
+    if (a.Xi_dense != nullptr) {
+      // colranks(sparse X, keep.zero = FALSE): the reference ranks the densified column (R/plaid.R:603-609)
+      double* dcol = a.dense_scratch + (int64_t)blockIdx.x * a.g_dense;
+      for (int i = (int)tid; i < a.g_dense; i += BLOCK) dcol[i] = 0.0;
+      __syncthreads();
+      const int p0 = a.Xp[c], p1 = a.Xp[c + 1];
+      for (int p = p0 + (int)tid; p < p1; p += BLOCK) dcol[a.Xi_dense[p]] = a.Xv[p];
+      __syncthreads();
+      cnt = (uint32_t)a.g_dense;
+      xc = dcol;
+      rc = a.R + (int64_t)c * a.ldr;
+    } else if (a.Xp != nullptr) {
+      const int p0 = a.Xp[c];
+      cnt = (uint32_t)(a.Xp[c + 1] - p0);
+      xc = a.Xv + p0;
+      rc = a.R + p0;
+    } else {
+      cnt = (uint32_t)a.g_dense;
+      xc = a.Xv + (int64_t)c * a.ldx;
+      rc = a.R + (int64_t)c * a.ldr;
+    }
+    // The KPT items of a thread are handled in groups of four; a group takes part when any of its 4 * BLOCK
+    // elements exists (the same for every thread: no divergence, straight-line code inside a group).  Lanes
+    // past the end and NaN are "invalid": they run the same instructions on trash slots of the histograms.
+#define PH_GROUP(j0) ((uint32_t)(j0) * BLOCK < cnt)
+#define PH_FOR_ITEMS(...)                                        \
+  _Pragma("unroll") for (int j0 = 0; j0 < KPT; j0 += 4) {        \
+    if (PH_GROUP(j0)) {                                          \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {            \
+        const int j = j0 + u;                                    \
+        __VA_ARGS__                                              \
+      }                                                          \
+    }                                                            \
+  }
+
+    // ---- 1. the column -> registers as ordered keys ------------------------------------------------
+    uint64_t key[KPT];
+    uint64_t validmask = 0, nanmask = 0, negmask = 0;
+    uint64_t kmin = ~0ull, kmax = 0ull;
+    {
+      const uint32_t last = cnt - 1u;
+#pragma unroll
+      for (int j0 = 0; j0 < KPT; j0 += 4) {
+        if (PH_GROUP(j0)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t i = tid + (uint32_t)(j0 + u) * BLOCK;
+            // clamped index instead of a guarded load: no exec games, every load of the column in flight at once
+            key[j0 + u] = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(xc + (i < cnt ? i : last)));
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) key[j0 + u] = ~0ull;
+        }
+      }
+      // zero the histograms (and the tie flags) while the loads are in flight
+      {
+        uint4* z = reinterpret_cast<uint4*>(smem_raw + L::off_c1);
+        constexpr int NZ = (L::hist_bytes - L::off_c1) / 16;
+        for (int i = (int)tid; i < NZ; i += BLOCK) z[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) *s_flag = 0;
+      }
+      PH_FOR_ITEMS({
+        const uint32_t i = tid + (uint32_t)j * BLOCK;
+        const bool inr = i < cnt;
+        double xv = __longlong_as_double((long long)key[j]);
+        negmask |= (inr && xv < 0.0) ? (1ull << j) : 0u;
+        if (a.is_signed) xv = fabs(xv);
+        const bool isnan_ = xv != xv;
+        nanmask |= (inr && isnan_) ? (1ull << j) : 0u;
+        const bool ok = inr && !isnan_;
+        validmask |= ok ? (1ull << j) : 0u;
+        const uint64_t u = (uint64_t)__double_as_longlong(xv + 0.0);       // -0 -> +0
+        const uint64_t k = ((long long)u < 0) ? ~u : (u | 0x8000000000000000ull);
+        key[j] = ok ? k : ~0ull;
+        kmin = (ok && k < kmin) ? k : kmin;
+        kmax = (ok && k > kmax) ? k : kmax;
+      })
+    }
+    kmin = wave_minmax_u64<true>(kmin);
+    kmax = wave_minmax_u64<false>(kmax);
+    if (lane == 63) { s_min[wave] = kmin; s_max[wave] = kmax; }
+    __syncthreads();
+    kmin = ~0ull;
+    kmax = 0ull;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint64_t o1 = s_min[w], o2 = s_max[w];
+      kmin = o1 < kmin ? o1 : kmin;
+      kmax = o2 > kmax ? o2 : kmax;
+    }
+    const uint64_t lo = kmin;                                         // ~0 when the column has no real key at all
+    const uint64_t range = kmax > kmin ? kmax - kmin : 0ull;
+    const int rbits = range ? 64 - __clzll((long long)range) : 0;
+    const int shift1 = rbits > LOG2K1 ? rbits - LOG2K1 : 0;          // (range >> shift1) < K1
+
+    // ---- 2a. coarse histogram over key space ---------------------------------------------------------
+    PH_FOR_ITEMS({
+      const uint32_t b = (uint32_t)((key[j] - lo) >> shift1);
+      atomicAdd(&c1[((validmask >> j) & 1ull) ? b : (uint32_t)(K1 + 1)], 1u);
+    })
+    __syncthreads();
+    {
+      constexpr int PER = K1 / BLOCK;
+      uint32_t s = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) s += c1[tid * PER + q];
+      uint32_t ex = block_excl_scan<BLOCK>(s, s_wave, lane, wave);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t v = c1[tid * PER + q];
+        c1[tid * PER + q] = ex;
+        ex += v;
+      }
+      if (tid == BLOCK - 1) c1[K1] = ex;    // end marker = number of valid keys
+    }
+    __syncthreads();
+
+    // ---- 2b. fine bucket = CDF(coarse) + interpolation inside the coarse interval -----------------------
+    uint32_t st[KPT];    // first: fine id | slot << 16; then the state word above
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) st[j] = 0;
+    PH_FOR_ITEMS({
+      const bool ok = (validmask >> j) & 1u;
+      const uint64_t d = ok ? key[j] - lo : 0ull;
+      const uint32_t b = (uint32_t)(d >> shift1);
+      const uint32_t cb = c1[b], cn = c1[b + 1] - cb;
+      const uint64_t rem = d - ((uint64_t)b << shift1);
+      const uint32_t fr = shift1 >= 32 ? (uint32_t)(rem >> (shift1 - 32)) : (uint32_t)(rem << (32 - shift1));
+      uint32_t f = cb + (uint32_t)(((uint64_t)fr * cn) >> 32);
+      f = ok ? f : (uint32_t)(CAP + 1);
+      const uint32_t slot = atomicAdd(&c2[f], 1u);
+      st[j] = f | (slot << 16);
+    })
+    __syncthreads();
+    {
+      // exclusive scan of the fine counts, packed with the number of "big" buckets in the high half
+      uint4* c2v = reinterpret_cast<uint4*>(c2) + tid * (KPT / 4);
+      uint32_t s = 0;
+#pragma unroll
+      for (int q = 0; q < KPT / 4; ++q) {
+        const uint4 v = c2v[q];
+        s += v.x + v.y + v.z + v.w;
+        s += (v.x > (uint32_t)kBigT ? 0x10000u : 0u) + (v.y > (uint32_t)kBigT ? 0x10000u : 0u) +
+             (v.z > (uint32_t)kBigT ? 0x10000u : 0u) + (v.w > (uint32_t)kBigT ? 0x10000u : 0u);
+      }
+      uint32_t ex = block_excl_scan<BLOCK>(s, s_wave, lane, wave);
+#pragma unroll
+      for (int q = 0; q < KPT / 4; ++q) {
+        const uint4 v = c2v[q];
+        uint4 o;
+        o.x = ex; ex += v.x + (v.x > (uint32_t)kBigT ? 0x10000u : 0u);
+        o.y = ex; ex += v.y + (v.y > (uint32_t)kBigT ? 0x10000u : 0u);
+        o.z = ex; ex += v.z + (v.z > (uint32_t)kBigT ? 0x10000u : 0u);
+        o.w = ex; ex += v.w + (v.w > (uint32_t)kBigT ? 0x10000u : 0u);
+        c2v[q] = o;
+      }
+      if (tid == BLOCK - 1) c2[CAP] = ex;
+    }
+    __syncthreads();
+    uint64_t bigmask = 0;
+    PH_FOR_ITEMS({
+      const bool ok = (validmask >> j) & 1u;
+      const uint32_t f = st[j] & 0xffffu, slot = st[j] >> 16;
+      const uint32_t p0 = c2[f], p1 = c2[f + 1];
+      const uint32_t start = p0 & 0xffffu, count = (p1 - p0) & 0xffffu;
+      const bool big = ok && count > (uint32_t)kBigT;
+      if (big) {
+        bigmask |= 1ull << j;              // keeps (fine id, slot) until the tie test below is through
+        rep[p0 >> 16] = key[j];          // any key of the bucket (racing stores of whole 8-byte words)
+      }
+      const uint32_t w = count > 1u ? st_scan(start, count, slot & 0xffu) : st_settled(start, 1u);
+      st[j] = big ? st[j] : (ok ? w : 0u);
+    })
+    __syncthreads();
+    if (bigmask) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if ((bigmask >> j) & 1u) {
+          const uint32_t bi = c2[st[j] & 0xffffu] >> 16;
+          if (rep[bi] != key[j]) mixed[bi] = 1u;
+        }
+    }
+    __syncthreads();
+    if (bigmask) {
+      bool giveup = false;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if ((bigmask >> j) & 1u) {
+          const uint32_t f = st[j] & 0xffffu, slot = st[j] >> 16;
+          const uint32_t p0 = c2[f], p1 = c2[f + 1];
+          const uint32_t start = p0 & 0xffffu, count = (p1 - p0) & 0xffffu;
+          if (mixed[p0 >> 16] == 0u) {
+            st[j] = st_settled(start, count);                  // every key of the bucket is this key
+          } else if (count <= (uint32_t)kFallbackCount) {
+            st[j] = st_scan(start, count, slot);
+          } else {
+            st[j] = 0;
+            giveup = true;
+          }
+        }
+      if (giveup) *s_flag = 1u;
+    }
+    __syncthreads();                        // everyone is done with the histograms: the keys may overwrite them
+    if (*s_flag != 0u) {
+      if (tid == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = c;
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 3. keys of multi-key, not-all-equal buckets -> their bucket's slots in LDS; count inside ----------
+    PH_FOR_ITEMS({
+      if (st[j] >> 31) lkeys[(st[j] & 0x7fffu) + ((st[j] >> 15) & 0xffu)] = key[j];
+    })
+    __syncthreads();
+    // the in-bucket counts first (the keys die here), then the output pass
+    uint64_t zeromask = 0;
+    PH_FOR_ITEMS({
+      const uint32_t start = st[j] & 0x7fffu;
+      uint32_t lb = start, ub = start + ((st[j] >> 16) & 0x7fffu);
+      if (st[j] >> 31) {
+        const uint32_t count = ((st[j] >> 23) & 0xffu) + 1u;
+        const uint64_t k = key[j];
+        uint32_t less = 0, leq = 0;
+        for (uint32_t s = 0; s < count; ++s) {
+          const uint64_t o = lkeys[start + s];
+          less += (o < k) ? 1u : 0u;
+          leq += (o <= k) ? 1u : 0u;
+        }
+        lb = start + less;
+        ub = start + leq;
+      }
+      st[j] = lb | (ub << 16);
+      zeromask |= (key[j] == 0x8000000000000000ull) ? (1ull << j) : 0u;
+    })
+    double vmax = (a.Xp != nullptr && a.Xi_dense == nullptr) ? 0.0 : -INFINITY;   // sparse ranks: the implicit zeros
+    const bool generic_pow = a.pow_q4 == 0 && a.power != 1.0;   // uniform
+    if (generic_pow) __syncthreads();                           // every in-bucket count is done: the LDS is free again
+    double* lrank = reinterpret_cast<double*>(lkeys);
+    PH_FOR_ITEMS({
+      const uint32_t i = tid + (uint32_t)j * BLOCK;
+      const uint32_t lb = st[j] & 0xffffu, ub = st[j] >> 16;
+      double r = (a.ties == PLAIDHIP_TIES_MIN) ? (double)(lb + 1)
+                                               : ((a.ties == PLAIDHIP_TIES_MAX) ? (double)ub : 0.5 * (double)(lb + 1 + ub));
+      if (a.pow_q4 > 0) r = pow_quarters(r, a.pow_q4);
+      const bool ok = (validmask >> j) & 1u;
+      if (!generic_pow) vmax = (ok && r > vmax) ? r : vmax;     // max |value| of the column (before the sign goes on)
+      if (a.is_signed) r = ((zeromask >> j) & 1u) ? 0.0 : (((negmask >> j) & 1u) ? -r : r);
+      r = ((nanmask >> j) & 1u) ? __longlong_as_double(0x7ff8000000000000ll) : r;
+      if (i < cnt) {
+        if (generic_pow) lrank[i] = r;                          // (signed) plain rank; the power goes on below
+        else __builtin_nontemporal_store(r, rc + i);
+      }
+    })
+    if (generic_pow) {
+      // rank^power for an arbitrary exponent: ONE copy of pow() in a rolled loop over this thread's own ranks
+      // (staged in LDS; unrolled KPT times it would not fit the register file)
+      for (uint32_t i = tid; i < cnt; i += BLOCK) {
+        const double v = lrank[i];
+        double r = v;
+        if (v == v && v != 0.0) {
+          const double pr = PH_POW(fabs(v), a.power);
+          vmax = pr > vmax ? pr : vmax;
+          r = v < 0.0 ? -pr : pr;
+        }
+        __builtin_nontemporal_store(r, rc + i);
+      }
+    }
+    if (a.colmax != nullptr) {
+      vmax = wave_max_f64_dpp(vmax);
+      if (lane == 63) s_f64[wave] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        double v = s_f64[0];
+        for (int w = 1; w < NW; ++w) v = s_f64[w] > v ? s_f64[w] : v;
+        a.colmax[c] = v;
+      }
+    }
+    __syncthreads();
+#undef PH_GROUP
+#undef PH_FOR_ITEMS
+  }
+}
+
+}  // namespace plaidhip

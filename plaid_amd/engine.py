@@ -19,7 +19,20 @@ def _as_f64_fortran(a) -> np.ndarray:
     return np.asfortranarray(a, dtype=np.float64)
 
 
+_INT32_MAX = 2**31 - 1
+
+
 def _as_i32(a) -> np.ndarray:
+    """dgCMatrix-style index arrays are 32-bit at the boundary (include/plaidhip.h).  scipy hands over int64
+    for large matrices: refuse, instead of wrapping, anything a 32-bit slot cannot hold (more than 2^31-1
+    stored values: split the matrix by columns first, as `chunked_crossprod` does, R/plaid.R:100-123)."""
+    a = np.asarray(a)
+    if a.dtype != np.int32 and a.size:
+        lo, hi = int(a.min()), int(a.max())
+        if lo < -_INT32_MAX - 1 or hi > _INT32_MAX:
+            raise _lib.PlaidHipError(_lib.EUNSUPPORTED,
+                                     f"index value {hi if hi > _INT32_MAX else lo} does not fit the 32-bit dgCMatrix slots of the "
+                                     "C ABI (more than 2^31-1 stored values?): split the matrix by columns")
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
@@ -57,14 +70,28 @@ class Geneset:
 
 class Context:
     """plaidhip_ctx: one device + one stream.  `stream` is a raw hipStream_t value (e.g.
-    `torch.cuda.current_stream().cuda_stream`) or None for a private stream."""
+    `torch.cuda.current_stream().cuda_stream`; 0 is the device's null stream, which is what torch's default
+    stream is) or None for a private non-blocking stream."""
 
     def __init__(self, device: int = 0, stream: int | None = None):
         self.lib = _lib.load()
         h = C.c_void_p()
-        check(self.lib.plaidhip_init(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        check(self.lib.plaidhip_init(int(device), None, C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self.stream = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream: int):
+        """enqueue on this hipStream_t from now on (0: the null stream)"""
+        check(self.lib.plaidhip_set_stream(self.handle, C.c_void_p(int(stream)) if stream else None))
+        self.stream = int(stream)
+
+    def set_option(self, name: str, value):
+        """kernel-selection knobs (plaidhip_set_option): see _lib.OPTIONS"""
+        code, values = _lib.OPTIONS[name]
+        check(self.lib.plaidhip_set_option(self.handle, code, values[value] if isinstance(value, str) else int(value)))
 
     def close(self):
         if self.handle:
@@ -96,8 +123,9 @@ class Context:
 
     def dev_spmm_csc(self, gs: Geneset, Xp: int, Xi: int, Xx: int, n: int, S: int, lds: int,
                      stat="mean", alpha=1.0, beta=0.0, flags: int | None = None,
-                     alpha_div: int | None = None):
-        check(self.lib.plaidhip_dev_spmm_csc_f64(self.handle, gs.handle, Xp, Xi, Xx, n, STAT[stat], alpha,
+                     alpha_div: int | None = None, nnz: int = -1):
+        """nnz: stored values of X when the caller knows it (one kernel is launched), -1: decided on the device"""
+        check(self.lib.plaidhip_dev_spmm_csc_f64(self.handle, gs.handle, Xp, Xi, Xx, n, int(nnz), STAT[stat], alpha,
                                                  alpha_div, beta, S, lds, flags))
 
     def dev_colranks_dense(self, X: int, ldx: int, g: int, n: int, R: int, ldr: int, ties="average",
@@ -105,10 +133,11 @@ class Context:
         check(self.lib.plaidhip_dev_colranks_dense_f64(self.handle, X, ldx, g, n, TIES[ties], int(signed),
                                                        power, R, ldr, colmax))
 
-    def dev_colranks_csc(self, Xp: int, Xx: int, n: int, Rx: int, ties="average", signed=False,
+    def dev_colranks_csc(self, Xp: int, Xx: int, n: int, max_col_nnz: int, Rx: int, ties="average", signed=False,
                          power=1.0, colmax: int | None = None):
-        check(self.lib.plaidhip_dev_colranks_csc_f64(self.handle, Xp, Xx, n, TIES[ties], int(signed), power,
-                                                     Rx, colmax))
+        """max_col_nnz: upper bound on the stored values of a column (sizes the launch; nrow(X) is always valid)"""
+        check(self.lib.plaidhip_dev_colranks_csc_f64(self.handle, Xp, Xx, n, int(max_col_nnz), TIES[ties], int(signed),
+                                                     power, Rx, colmax))
 
     def dev_minflags(self, S: int, count: int, flags: int):
         check(self.lib.plaidhip_dev_minflags(self.handle, S, count, flags))

@@ -30,6 +30,35 @@ def shard_bounds(n: int, world: int, rank: int):
     return lo, hi
 
 
+class CscShard:
+    """This rank's sample columns of a dgCMatrix: the three CSC slots as tensors (`p` re-based to start at 0,
+    int32; `i` int32; `x` float64) plus what the host knows about them without touching the device:
+    nnz (p[-1]) and the longest column (sizes the rank launch)."""
+
+    def __init__(self, p, i, x, g: int, nnz: int | None = None, max_col_nnz: int | None = None):
+        self.p, self.i, self.x, self.g = p, i, x, int(g)
+        self.n = int(p.shape[0]) - 1
+        if nnz is None or max_col_nnz is None:                     # one small D2H at construction, none per step
+            d = (p[1:] - p[:-1])
+            nnz = int(p[-1].item()) if self.n > 0 else 0
+            max_col_nnz = int(d.max().item()) if self.n > 0 else 0
+        self.nnz, self.max_col_nnz = int(nnz), int(max_col_nnz)
+
+    @staticmethod
+    def from_scipy(X, lo: int, hi: int, device=None):
+        """columns [lo, hi) of a scipy CSC matrix"""
+        import torch
+        p = np.asarray(X.indptr[lo:hi + 1], dtype=np.int64)
+        i = np.asarray(X.indices[p[0]:p[-1]], dtype=np.int32)
+        x = np.asarray(X.data[p[0]:p[-1]], dtype=np.float64)
+        p = (p - p[0]).astype(np.int32)
+        d = np.diff(p)
+        t = [torch.from_numpy(np.ascontiguousarray(a)) for a in (p, i, x)]
+        if device is not None:
+            t = [a.to(device) for a in t]
+        return CscShard(t[0], t[1], t[2], X.shape[0], int(p[-1]), int(d.max()) if len(d) else 0)
+
+
 class HipPhaseEngine:
     """Phases of the hot path on one GPU, on torch CUDA tensors (float64, row-major
     (n_local, g) == column-major g x n_local)."""
@@ -39,10 +68,44 @@ class HipPhaseEngine:
         self.torch = torch
         self.ctx, self.gs, self.device = ctx, geneset, device
 
+    def _same_stream(self):
+        # the library enqueues on ITS stream: tensors allocated, zeroed or all-reduced on another stream would race
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if self.ctx.stream is None or int(self.ctx.stream) != int(cur):
+            raise RuntimeError("HipPhaseEngine: the plaidhip context must enqueue on torch's current stream "
+                               f"(context stream {self.ctx.stream}, torch current stream {cur}): create the Context with "
+                               "stream=<that stream>.cuda_stream and call inside `with torch.cuda.stream(<that stream>)`")
+
+    def spmm_csc(self, X: CscShard, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None):
+        """crossprod with a CSC shard; `values` replaces X.x (e.g. the ranks of the stored values)"""
+        self._same_stream()
+        t = self.torch
+        S = t.empty((X.n, self.gs.m), dtype=t.float64, device=self.device)
+        if X.n > 0:
+            xx = X.x if values is None else values
+            self.ctx.dev_spmm_csc(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
+                                  stat, alpha, beta, flags.data_ptr() if flags is not None else None,
+                                  alpha_div.data_ptr() if alpha_div is not None else None, nnz=X.nnz)
+        return S
+
+    def sparse_colranks(self, X: CscShard, ties="average", signed=False, power=1.0):
+        """sparse_colranks() of the shard: ranks of the stored values (same pattern) and max(rX) of the shard"""
+        self._same_stream()
+        t = self.torch
+        Rx = t.empty_like(X.x)
+        colmax = t.zeros(max(X.n, 1), dtype=t.float64, device=self.device)
+        gmax = t.zeros(1, dtype=t.float64, device=self.device)       # implicit zeros: max(rX) >= 0
+        if X.n > 0:
+            self.ctx.dev_colranks_csc(X.p.data_ptr(), X.x.data_ptr(), X.n, X.max_col_nnz, Rx.data_ptr(), ties, signed,
+                                      power, colmax.data_ptr())
+            self.ctx.dev_max(colmax.data_ptr(), X.n, gmax.data_ptr())
+        return Rx, gmax
+
     def new_flags(self):
         return self.torch.zeros(4, dtype=self.torch.int32, device=self.device)
 
     def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None):
+        self._same_stream()
         t = self.torch
         n = X.shape[0]
         S = t.empty((n, self.gs.m), dtype=t.float64, device=self.device)
@@ -52,6 +115,7 @@ class HipPhaseEngine:
         return S
 
     def colranks(self, X, ties="average", signed=False, power=1.0):
+        self._same_stream()
         t = self.torch
         n, g = X.shape
         R = t.empty_like(X)
@@ -63,6 +127,7 @@ class HipPhaseEngine:
         return R, gmax
 
     def medians(self, S, flags):
+        self._same_stream()
         t = self.torch
         n, m = S.shape
         med = t.empty(max(n, 1), dtype=t.float64, device=self.device)
@@ -73,6 +138,7 @@ class HipPhaseEngine:
         return med, red
 
     def shift(self, S, med, red):
+        self._same_stream()
         n, m = S.shape
         if n > 0:
             self.ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
@@ -101,6 +167,35 @@ def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)         # mean(medx) over all samples
         engine.shift(S, med, red)
     return S
+
+
+def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
+                      values=None, group=None):
+    """plaid() on a CSC shard (sparse branch of Matrix::crossprod, R/plaid.R:107); same collectives as sharded_plaid"""
+    import torch.distributed as dist
+    world, _ = _world(group)
+    flags = engine.new_flags()
+    S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values)
+    if normalize:
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        med, red = engine.medians(S, flags)
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+        engine.shift(S, med, red)
+    return S
+
+
+def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
+    """replaid.ssgsea on a dgCMatrix shard (BASELINE config 5's workload): sparse_colranks of the stored values
+    (R/plaid.R:600-601, 631-650), rank^(1+alpha), global max(rX) = one all_reduce(MAX), then the crossprod with the
+    `/max - 0.5` folded into its epilogue (the -0.5 reaches the implicit zeros too) and the median normalisation"""
+    import torch.distributed as dist
+    world, _ = _world(group)
+    Rx, gmax = engine.sparse_colranks(X_local, "average", False, 1.0 + alpha)
+    if world > 1:
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group)
 
 
 def sharded_sing(engine, X_local, group=None):

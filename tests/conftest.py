@@ -39,3 +39,19 @@ def hip_ctx():
     ctx = plaid_amd.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def pinned_ctx(hip_ctx):
+    """the session context with kernel-selection options pinned for one test (plaidhip_set_option), reset afterwards"""
+    defaults = {"spmm_dense_kernel": "auto", "spmm_sparse_kernel": "auto", "nt_store": "auto", "ranks_f32": 1,
+                "rank_kernel": "auto"}
+
+    def pin(**opts):
+        for k, v in defaults.items():
+            hip_ctx.set_option(k, opts.get(k, v))
+        return hip_ctx
+
+    yield pin
+    for k, v in defaults.items():
+        hip_ctx.set_option(k, v)

@@ -165,10 +165,10 @@ def test_spmm_gene_sliced(hip_ctx, g):
 @pytest.mark.parametrize("kernel", ["pair", "single"])
 @pytest.mark.parametrize("g,n,m", [(37, 1, 3), (1000, 5, 70), (10224, 9, 130), (10226, 8, 130), (20000, 33, 700),
                                    (25001, 7, 150), (45000, 4, 90), (333, 3, 40)])
-def test_spmm_both_dense_kernels(hip_ctx, monkeypatch, kernel, g, n, m):
+def test_spmm_both_dense_kernels(pinned_ctx, kernel, g, n, m):
     """the two-columns-per-pass kernel (1-5 gene slices, odd n) and the one-column kernel give the oracle's scores"""
     from plaid_amd import synth as sy
-    monkeypatch.setenv("PLAIDHIP_SPMM_KERNEL", kernel)
+    hip_ctx = pinned_ctx(spmm_dense_kernel=kernel)
     Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(g, 400), sort_by_size=False)
     X = sy.dense_columns(g, 0, n) - 8.0
     rn = [str(k) for k in range(g)]
@@ -186,11 +186,11 @@ def test_spmm_both_dense_kernels(hip_ctx, monkeypatch, kernel, g, n, m):
 @pytest.mark.parametrize("mode", ["scatter", "gather", "auto"])
 @pytest.mark.parametrize("g,n,m,dens", [(500, 3, 40, 0.05), (20000, 9, 700, 0.05), (20000, 5, 24000, 0.03),
                                         (30001, 4, 300, 0.3), (64, 2, 5, 1.0)])
-def test_spmm_sparse_x_scatter_and_gather(hip_ctx, monkeypatch, mode, g, n, m, dens):
+def test_spmm_sparse_x_scatter_and_gather(pinned_ctx, mode, g, n, m, dens):
     """dgCMatrix X: the scatter kernel (work ~ stored values; 1-2 chunks of LDS accumulators), the gather kernel
     and the on-device choice between them all give the oracle's scores, incl. empty columns and the epilogues"""
     from plaid_amd import synth as sy
-    monkeypatch.setenv("PLAIDHIP_SPMM_SPARSE", mode)
+    hip_ctx = pinned_ctx(spmm_sparse_kernel=mode)
     Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(g, 300), sort_by_size=False)
     rng = np.random.default_rng(g + m)
     X = np.where(rng.random((g, n)) < dens, np.round(rng.gamma(2.0, 1.0, size=(g, n)), 1), 0.0)
@@ -207,12 +207,11 @@ def test_spmm_sparse_x_scatter_and_gather(hip_ctx, monkeypatch, mode, g, n, m, d
 
 
 @pytest.mark.parametrize("g,n", [(10001, 5), (20001, 3), (333, 2)])
-def test_spmm_pair_kernel_odd_genes_strided(monkeypatch, g, n):
+def test_spmm_pair_kernel_odd_genes_strided(g, n):
     """device-level call with ldx = g + 1 (even) and odd g: the last gene of the last slice is staged separately"""
     import torch
     import plaid_amd
     from plaid_amd import synth as sy
-    monkeypatch.setenv("PLAIDHIP_SPMM_KERNEL", "pair")
     m = 90
     rng = np.random.default_rng(g)
     sets = [np.array([0, g // 2, g - 1])]                   # the odd last gene is a member
@@ -222,6 +221,7 @@ def test_spmm_pair_kernel_odd_genes_strided(monkeypatch, g, n):
     X = sy.dense_columns(g, 0, n)
     dev = torch.device("cuda", 0)
     ctx = plaid_amd.Context(0)
+    ctx.set_option("spmm_dense_kernel", "pair")
     gs = ctx.geneset(g, Gp, Gi)
     Xd = torch.zeros((n, g + 1), dtype=torch.float64, device=dev)
     Xd[:, :g] = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
@@ -549,7 +549,7 @@ def test_spmm_mixed_precision_mode_is_opt_in_and_within_the_bar():
     ctx.close()
 
 
-def test_rank_inputs_take_the_fp32_staged_kernel_without_any_rounding(hip_ctx, monkeypatch):
+def test_rank_inputs_take_the_fp32_staged_kernel_without_any_rounding(pinned_ctx):
     """replaid.sing / replaid.ssgsea(alpha = 0) / replaid.gsva(tau = 0) feed (half-)integer ranks <= 20,448 to the
     crossprod: those are exact in fp32 and so are the kernel's four-term fp32 partial sums, so the fp32-staged
     pair kernel is used for them by default and must give the fp64 kernels' scores BIT FOR BIT"""
@@ -559,10 +559,200 @@ def test_rank_inputs_take_the_fp32_staged_kernel_without_any_rounding(hip_ctx, m
     X = sy.dense_columns(g, 0, n, tied=True)
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("PLAIDHIP_RANKS_F32", flag)
+        hip_ctx = pinned_ctx(ranks_f32=int(flag))
         outs[flag] = (hip_ctx.sing_dense(X, Gp, Gi), hip_ctx.ssgsea_dense(X, Gp, Gi, 0.0), hip_ctx.gsva(X - 8.0, Gp, Gi, 0.0))
     for a, b in zip(outs["1"], outs["0"]):
         assert np.array_equal(a, b)
     rn = [str(k) for k in range(g)]
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
     close(outs["1"][0], _oracle().replaid_sing(X, rn, G, rn))
+
+
+# ---------------------------------------------------------------- the bucket ranker against the sorting network
+def _rank_cases(g, rng):
+    """columns that stress every branch of the bucket ranker: continuous, rounded (heavy ties), 95 % zeros,
+    a constant column, two clusters far apart, values two histogram levels cannot separate (fallback to the
+    network kernel), +-inf, NaN, negative zero, denormals"""
+    cols = [rng.normal(8, 2, g), np.round(rng.normal(8, 2, g), 1),
+            np.where(rng.random(g) < 0.95, 0.0, np.round(rng.gamma(2.0, 1.0, g), 1)),
+            np.full(g, 3.25), np.where(rng.random(g) < 0.5, 1e-300, 1e300) * rng.random(g),
+            np.where(rng.random(g) < 0.5, 1.0, 1.0 + 1e-12 * rng.integers(0, 3, g)),
+            rng.choice([-np.inf, np.inf, 0.0, -0.0, 5e-324, -5e-324, 1.0], g),
+            np.where(rng.random(g) < 0.01, np.nan, rng.normal(0, 1, g)),
+            rng.integers(-3, 4, g).astype(float), np.exp(rng.normal(0, 8, g)),
+            1.0 + rng.integers(0, 40, g) * 2.0 ** -52]
+    return np.asfortranarray(np.stack(cols, axis=1))
+
+
+@pytest.mark.parametrize("g", [1, 5, 64, 257, 2048, 2049, 4096, 5000, 8192, 8193, 12288, 12289, 20000, 20352])
+def test_bucket_ranker_matches_oracle_on_hard_columns(pinned_ctx, g):
+    """every workgroup shape of the bucket ranker, all tie rules, signed and unsigned: bit-exact against the C
+    oracle and against the sorting-network kernel (NaN columns: network only, the oracle takes no NaN)"""
+    from oracle import c_oracle
+    X = _rank_cases(g, np.random.default_rng(g))
+    ok = ~np.isnan(X).any(axis=0)
+    for tm in ("average", "min", "max"):
+        for signed in (False, True):
+            got = pinned_ctx(rank_kernel="bucket").colranks_dense(X, tm, signed)
+            ref = pinned_ctx(rank_kernel="network").colranks_dense(X, tm, signed)
+            assert np.array_equal(got, ref, equal_nan=True), (g, tm, signed)
+            assert np.array_equal(got[:, ok], c_oracle.colranks_dense(X[:, ok], tm, signed)), (g, tm, signed)
+    # sparse ranks (stored values only) through the same kernel
+    if g >= 64:
+        ctx = pinned_ctx(rank_kernel="bucket")
+        lens = np.array([0, 1, g // 3, g, 7, 0, g // 2])
+        Xp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        Xx = np.round(np.random.default_rng(g + 1).gamma(2.0, 1.0, size=Xp[-1]), 1) + 0.1
+        for tm in ("average", "min"):
+            assert np.array_equal(ctx.colranks_csc(Xp, Xx, tm), c_oracle.sparse_colranks(Xp, Xx, tm))
+
+
+def test_bucket_ranker_power_and_colmax(pinned_ctx):
+    """rank^(1 + alpha) fused into the bucket kernel: quarter exponents by square roots, any other by pow()"""
+    from plaid_amd import synth as sy
+    g, n, m = 20000, 6, 300
+    Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    for alpha in (0.25, 0.5, 1.0, 0.3):
+        outs = [pinned_ctx(rank_kernel=k).ssgsea_dense(X, Gp, Gi, alpha) for k in ("bucket", "network")]
+        np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12, atol=1e-14)
+        close(outs[0], _oracle().replaid_ssgsea(X, rn, G, rn, alpha=alpha))
+
+
+# ---------------------------------------------------------------- BASELINE target shapes: 20k genes x 50k gene sets
+@pytest.fixture(scope="module")
+def g50k():
+    """the synthetic 50,000-set collection of configs 3-5 (z ~ 6.9e6 memberships), built once per module"""
+    from plaid_amd import synth as sy
+    g, m = 20000, 50000
+    Gp, Gi = sy.geneset_csc(g, m)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    return g, m, Gp, Gi, G, [str(k) for k in range(g)]
+
+
+@pytest.mark.parametrize("mode", ["scatter", "gather", "auto"])
+def test_c3_shape_ssgsea_csc_50k_sets(pinned_ctx, g50k, mode):
+    """config 3 per sample: sparse X (5 % stored, ~50 levels per cell), sparse_colranks, alpha = 0.25, 50,000 sets
+    = 3 chunks of LDS accumulators in the scatter kernel; every way of multiplying a sparse X, against the oracle"""
+    from plaid_amd import synth as sy
+    g, m, Gp, Gi, G, rn = g50k
+    n = 8
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, n))
+    ctx = pinned_ctx(spmm_sparse_kernel=mode)
+    close(ctx.ssgsea_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, 0.25), _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
+    close(ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
+
+
+@pytest.mark.parametrize("rank_kernel", ["bucket", "network"])
+def test_c4_shape_ssgsea_and_sing_dense_fp64_50k_sets(pinned_ctx, g50k, rank_kernel):
+    """config 4 per sample in the default fp64 mode: dense 20k-gene columns (the register-blocked network / the
+    bucket ranker with the fused power), 50,000 sets through the pair kernel, median normalisation at m = 50k"""
+    from plaid_amd import synth as sy
+    g, m, Gp, Gi, G, rn = g50k
+    n = 8
+    X = sy.dense_columns(g, 0, n)
+    Xt = sy.dense_columns(g, 0, n, tied=True)
+    ctx = pinned_ctx(rank_kernel=rank_kernel, ranks_f32=0)        # keep every crossprod on the fp64 kernels
+    close(ctx.ssgsea_dense(X, Gp, Gi, 0.25), _oracle().replaid_ssgsea(X, rn, G, rn, alpha=0.25))
+    close(ctx.ssgsea_dense(Xt, Gp, Gi, 0.25), _oracle().replaid_ssgsea(Xt, rn, G, rn, alpha=0.25))
+    close(ctx.sing_dense(Xt, Gp, Gi), _oracle().replaid_sing(Xt, rn, G, rn))
+    close(ctx.plaid_dense(X, Gp, Gi), _oracle().plaid(X, rn, G, rn))
+
+
+def test_c2_last_columns_of_the_bench_generator(hip_ctx):
+    """config 2: plaid() on columns 9,990-9,999 of the very matrix bench.py scores (20k genes x 5k sets)"""
+    from oracle import c_oracle
+    from plaid_amd import synth as sy
+    g, m = 20000, 5000
+    Gp, Gi = sy.geneset_csc(g, m)
+    X = sy.dense_columns(g, 9990, 10000)
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", False), c_oracle.plaid_dense(X, Gp, Gi, "mean", False))
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", True), c_oracle.plaid_dense(X, Gp, Gi, "mean", True))
+
+
+# ---------------------------------------------------------------- randomised stress (tools/stress_parity.py)
+@pytest.mark.parametrize("seed", range(200))
+def test_stress_parity_random_case(hip_ctx, seed):
+    """one random shape / density / value pattern / precision mode per seed through every host entry point"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        failures = mod.run_case(hip_ctx, seed)
+    finally:
+        hip_ctx.set_precision("f64")
+        hip_ctx.set_option("spmm_sparse_kernel", "auto")
+    assert not failures, failures
+
+
+# ---------------------------------------------------------------- stream order: a whole step inside one hipGraph
+def test_c3_step_is_capturable_in_a_hip_graph():
+    """no plaidhip_dev_* call synchronises or reads anything back (include/plaidhip.h): a full sparse ssGSEA step
+    (sparse_colranks -> max -> crossprod -> normalize_medians) is captured in a hipGraph, replayed on new data of
+    the same shape, and matches the oracle"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, n, m = 6000, 40, 900
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=300)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n, density=0.06)
+    zx = int(Xp[-1])
+    cap = zx + 64                                              # fixed-size buffers: the graph is shape-static
+    dXp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    dXi = torch.zeros(cap, dtype=torch.int32, device=dev)
+    dXx = torch.zeros(cap, dtype=torch.float64, device=dev)
+    dRx = torch.zeros(cap, dtype=torch.float64, device=dev)
+    S = torch.zeros((n, m), dtype=torch.float64, device=dev)
+    colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+    small = torch.zeros(8, dtype=torch.float64, device=dev)      # [0:2] {sum, count}, [2] max(rX)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    med = torch.zeros(n, dtype=torch.float64, device=dev)
+    max_nnz = 1024
+
+    def upload(Xp_, Xi_, Xx_):
+        dXp.copy_(torch.from_numpy(Xp_.astype(np.int32)))
+        dXi[:len(Xi_)].copy_(torch.from_numpy(Xi_.astype(np.int32)))
+        dXx[:len(Xx_)].copy_(torch.from_numpy(Xx_))
+
+    def step():
+        flags.zero_()
+        ctx.dev_colranks_csc(dXp.data_ptr(), dXx.data_ptr(), n, max_nnz, dRx.data_ptr(), "average", False, 1.25,
+                             colmax.data_ptr())
+        ctx.dev_max(colmax.data_ptr(), n, small.data_ptr() + 16)
+        ctx.dev_spmm_csc(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
+                         flags.data_ptr(), small.data_ptr() + 16)            # nnz unknown to the host: decided on the device
+        ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+        ctx.dev_sum(med.data_ptr(), n, small.data_ptr())
+        ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, small.data_ptr())
+
+    with torch.cuda.stream(stream):
+        upload(Xp, Xi, Xx)
+        step()                                                  # warm-up: sizes the context's workspace once
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        step()
+    # new data of the same shape class, then replay
+    Xp2, Xi2, Xx2 = sy.sparse_columns(g, 100, 100 + n, density=0.06)
+    assert int(Xp2[-1]) <= cap and int(np.diff(Xp2).max()) <= max_nnz
+    with torch.cuda.stream(stream):
+        upload(Xp2, Xi2, Xx2)
+    stream.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    Xs2 = sp.csc_matrix((Xx2, Xi2, Xp2), shape=(g, n))
+    close(S.cpu().numpy().T, _oracle().replaid_ssgsea(Xs2, rn, G, rn, alpha=0.25))
+    gs.close()
+    ctx.close()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/plaidhip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
-    assert lib.plaidhip_version() == 100
+    assert lib.plaidhip_version() == 200
 
 
 def test_no_cpu_fallback():
@@ -247,3 +247,39 @@ def test_pair_plan_schedules_every_membership_once(g, m):
     assert conflicts <= 0.25 * chunks * 8                       # a minority of the steps carries one
     if m >= 300:
         assert int(Gp[-1]) / (chunks * 512) > 0.5               # slot efficiency stays sane (full tiles)
+
+
+def test_product_library_has_no_diagnostic_surface():
+    """ablation / stamp kernel variants, the env-var tuning knobs and plaidhip_debug_set_ablation exist only in the
+    tools/ build (-DPLAIDHIP_DIAG, `make diag`): the product library neither exports the setter nor reads the
+    environment on any launch path"""
+    import re
+    from plaid_amd import _lib
+    lib = _lib.load()
+    assert not hasattr(lib, "plaidhip_debug_set_ablation")
+    csrc = os.path.join(ROOT, "plaid_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".cpp", ".hip", ".h")):
+            continue
+        depth, diag = 0, []
+        for line in open(os.path.join(csrc, name)):
+            t = line.strip()
+            if t.startswith("#if"):
+                diag.append("PLAIDHIP_DIAG" in t and not t.startswith("#ifndef"))
+            elif t.startswith("#else") and diag:
+                diag[-1] = False
+            elif t.startswith("#endif") and diag:
+                diag.pop()
+            elif re.search(r"\bgetenv\s*\(", t) and not t.startswith("//"):
+                assert any(diag), f"{name}: getenv outside #ifdef PLAIDHIP_DIAG: {t}"
+
+
+def test_int32_slots_refuse_values_that_do_not_fit():
+    """scipy hands over int64 index arrays for big matrices: wrapping them into the 32-bit dgCMatrix slots of the C ABI
+    would read garbage; the host layer refuses instead (the R-side answer is chunking, R/plaid.R:100-123)"""
+    import numpy as np
+    from plaid_amd import _lib
+    from plaid_amd.engine import _as_i32
+    assert _as_i32(np.array([0, 5, 2**31 - 1], dtype=np.int64)).dtype == np.int32
+    with pytest.raises(_lib.PlaidHipError):
+        _as_i32(np.array([0, 2**31], dtype=np.int64))

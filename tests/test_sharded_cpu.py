@@ -47,6 +47,29 @@ class OraclePhaseEngine:
         gmax = torch.tensor([R.max() if R.size else -np.inf], dtype=torch.float64)
         return torch.from_numpy(np.ascontiguousarray(R.T)), gmax
 
+    def _epilogue(self, raw, stat, alpha, beta, alpha_div, flags):
+        w = 1.0 / (1e-8 + self.k) if stat == "mean" else np.ones_like(self.k)
+        a = alpha / float(alpha_div.item()) if alpha_div is not None else alpha
+        with np.errstate(all="ignore"):
+            S = a * (raw * w[:, None]) + beta * (self.k * w)[:, None]
+        if flags is not None and S.size:
+            flags[0] = max(int(flags[0]), int((S < 0).any()))
+            flags[1] = max(int(flags[1]), int((S == 0).any()))
+            flags[2] = max(int(flags[2]), int(np.isnan(S).any()))
+        return torch.from_numpy(np.ascontiguousarray(S.T))
+
+    def spmm_csc(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None):
+        xx = (X.x if values is None else values).numpy()
+        Xs = sp.csc_matrix((xx, X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))
+        return self._epilogue(np.asarray((self.G.T @ Xs).todense()), stat, alpha, beta, alpha_div, flags)
+
+    def sparse_colranks(self, X, ties="average", signed=False, power=1.0):
+        Xs = sp.csc_matrix((X.x.numpy(), X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))
+        R = po.sparse_colranks(Xs, signed=signed, ties_method=ties).data if X.nnz else np.zeros(0)
+        R = R ** power if power != 1.0 else R
+        gmax = torch.tensor([max(R.max(), 0.0) if R.size else 0.0], dtype=torch.float64)
+        return torch.from_numpy(np.ascontiguousarray(R, dtype=np.float64)), gmax
+
     def medians(self, S, flags):
         ignore_zero = bool(flags[1]) and not bool(flags[0])
         if S.shape[0] == 0:
@@ -82,6 +105,13 @@ def _worker(rank, world, port, n, case, out_path):
         res["plaid"] = sharded.sharded_plaid(eng, Xl)
         res["sing"] = sharded.sharded_sing(eng, Xl)
         res["ssgsea"] = sharded.sharded_ssgsea(eng, Xl, alpha=0.25)
+        # the sparse workload of config 5: CSC shards, sparse_colranks, same scalars
+        Xz = np.where(np.random.default_rng(5).random(X.shape) < 0.85, 0.0, X)
+        if case == "zeros":
+            Xz[:, n - 1] = 0.0                                     # a cell without stored values
+        shard = sharded.CscShard.from_scipy(sp.csc_matrix(Xz), lo, hi)
+        res["plaid_csc"] = sharded.sharded_plaid_csc(eng, shard)
+        res["ssgsea_csc"] = sharded.sharded_ssgsea_csc(eng, shard, alpha=0.25)
         full = {k: sharded.gather_scores(v, n, dst=0) for k, v in res.items()}
         if rank == 0:
             np.savez(out_path, **{k: v.numpy().T for k, v in full.items()})
@@ -105,6 +135,23 @@ def test_sharded_equals_unsharded_gloo(tmp_path, n, case):
     np.testing.assert_allclose(got["plaid"], po.plaid(X, rn, G, rn), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(got["sing"], po.replaid_sing(X, rn, G, rn), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(got["ssgsea"], po.replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-10, atol=1e-12)
+    Xz = np.where(np.random.default_rng(5).random(X.shape) < 0.85, 0.0, X)
+    if case == "zeros":
+        Xz[:, n - 1] = 0.0
+    Xs = sp.csc_matrix(Xz)
+    np.testing.assert_allclose(got["plaid_csc"], po.plaid(Xs, rn, G, rn), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(got["ssgsea_csc"], po.replaid_ssgsea(Xs, rn, G, rn, alpha=0.25), rtol=1e-10, atol=1e-12)
+
+
+def test_csc_shard_bookkeeping():
+    """CscShard re-bases the column pointers and knows nnz / the longest column without a device round trip per step"""
+    X = sp.random(50, 9, density=0.3, format="csc", random_state=1)
+    sh = sharded.CscShard.from_scipy(X, 3, 7)
+    assert sh.n == 4 and int(sh.p[0]) == 0 and sh.nnz == X[:, 3:7].nnz
+    assert sh.max_col_nnz == int(np.diff(X.indptr[3:8]).max())
+    assert np.array_equal(sh.i.numpy(), X[:, 3:7].indices) and np.array_equal(sh.x.numpy(), X[:, 3:7].data)
+    empty = sharded.CscShard.from_scipy(X, 9, 9)
+    assert empty.n == 0 and empty.nnz == 0 and empty.max_col_nnz == 0
 
 
 def test_single_process_path_needs_no_process_group():
