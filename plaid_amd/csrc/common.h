@@ -24,7 +24,9 @@ constexpr int kPadSlotsPair = 16;
 constexpr int kMaxLdsGenesPair = kLdsBytes / 16 - kPadSlotsPair;   // 10224
 constexpr int kMaxPairSlices = 8;
 // scatter kernel (sparse X): fp64 accumulators of one chunk of gene sets in LDS
-constexpr int kScatterChunk = 20480;   // 160 KiB / 8
+constexpr int kScatterTrash = 64;                      // accumulators behind a chunk that padded id slots add into
+constexpr int kScatterStage = 16 * 64 * 16;            // bytes: per wavefront 64 staged {segment, count, value} entries
+constexpr int kScatterChunk = 20480 - kScatterTrash - kScatterStage / 8;   // 160 KiB / 8, less trash slots and staging
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -121,7 +123,8 @@ struct plaidhip_pair_plan {
 
 // Scatter plan (sparse X): G transposed, gene-major.  The sets are cut into chunks of `ch` (the
 // LDS accumulators of one chunk); the sets of gene i inside chunk c are stored as whole segments
-// of 128 u16 ids (a dword = two ids per lane) relative to the chunk start (0xffff = padding): segments seg[c*g + i] ..
+// of 128 u16 ids (a dword = two ids per lane) relative to the chunk start (padding: a trash accumulator behind the chunk,
+// or 0xffff in every high half of a segment whose second instruction is empty): segments seg[c*g + i] ..
 // seg[c*g + i + 1] - 1 of d_ids.  (seg has nch*g + 1 entries, chunk-major, so the ranges of
 // consecutive (chunk, gene) pairs are contiguous.)
 struct plaidhip_scatter_plan {
@@ -189,6 +192,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 #ifdef PLAIDHIP_DIAG
 void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ build only, make diag)
+void debug_set_rank_stamps(void* dbg);          // per-phase cycle stamps of the bucket rank kernel
 #endif
 // kernels_rank.hip
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,

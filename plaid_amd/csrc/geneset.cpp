@@ -621,7 +621,10 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
   if (m > 0) {
     // scatter plan (sparse X): gene-major membership in 128-id segments (one dword = 2 ids per lane) per (chunk of sets, gene)
     plaidhip_scatter_plan& sp = gs->scatter;
-    sp.ch = std::min<int32_t>(m, kScatterChunk);
+    // as few chunks as the LDS allows: every chunk is one more pass over the column's stored values.  (Dealing
+    // eight smaller chunks to the eight XCDs so that an XCD's L2 holds only its share of the id lists was measured:
+    // 1.7x SLOWER -- the passes are bound by their chains of dependent loads, not by L2 misses.)
+    sp.ch = std::min<int32_t>((m + 15) & ~15, kScatterChunk);   // multiple of 16: the trash slots keep their banks
     sp.nch = (m + sp.ch - 1) / sp.ch;
     std::vector<int32_t> cnt((size_t)sp.nch * g, 0);
     for (int32_t j = 0; j < m; ++j)
@@ -629,13 +632,82 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     std::vector<int32_t> seg((size_t)sp.nch * g + 1, 0);
     for (size_t i = 0; i < cnt.size(); ++i) seg[i + 1] = seg[i] + (cnt[i] + 127) / 128;
     sp.nseg = seg.back();
-    std::vector<uint16_t> ids(((size_t)sp.nseg + 1) * 128, (uint16_t)0xffffu);   // + one all-padding segment (index nseg)
+    // padded slots add into trash accumulators behind the chunk (no compare, no branch per lane; slot ch + lane % 16:
+    // no bank collision among the padding lanes of a 16-lane group); + one all-padding segment (index nseg)
+    std::vector<uint16_t> ids(((size_t)sp.nseg + 1) * 128);
+    for (size_t q = 0; q < ids.size(); ++q) ids[q] = (uint16_t)(sp.ch + (int)(((q & 127) >> 1) & 15));
     std::fill(cnt.begin(), cnt.end(), 0);
-    for (int32_t j = 0; j < m; ++j)      // increasing j: ids inside a segment list are sorted
+    for (int32_t j = 0; j < m; ++j)
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
         const size_t cell = (size_t)(j / sp.ch) * g + Gi[p];
         ids[(size_t)seg[cell] * 128 + cnt[cell]++] = (uint16_t)(j % sp.ch);
       }
+    // Bank-conflict-free order inside every (chunk, gene) list.  The kernel turns a segment into two ds_add_f64
+    // wave-instructions (the low and the high u16 of each lane's dword).  Measured (tools/ubench/lds_atomics.hip): the
+    // LDS executes a 64-bit atomic in four groups of 16 consecutive lanes, 2 cycles per group when the 16 accumulators
+    // sit on 16 different 8-byte banks (slot mod 16), and N times that for an N-way collision -- 8.4 cycles per
+    // instruction conflict-free, 32 with random ids.  The ids of a list are static, so they are dealt to the
+    // (instruction, 16-lane group) cells such that a group holds each residue mod 16 at most once where the counts
+    // allow it (a residue with more ids than the list has groups keeps the few collisions left), and the padding
+    // lanes of a group get trash accumulators on the banks the group does not use.
+    {
+      std::vector<uint16_t> byres[16];
+      std::vector<int> gload, gres;    // ids per group, ids of the current residue per group
+      std::vector<std::vector<uint16_t>> grp;
+      for (size_t cell = 0; cell + 1 < seg.size(); ++cell) {
+        const int N = cnt[cell];
+        const int nsg = seg[cell + 1] - seg[cell];
+        uint16_t* base = ids.data() + (size_t)seg[cell] * 128;
+        if (N == 0) continue;
+        // instructions of 64 lanes are filled one after the other (their number, not their occupancy, is the cost):
+        // a list of N ids takes ceil(N / 64) of the 2 * nsg instruction slots; an unused second instruction of the
+        // last segment is marked by 0xffff in every high half and skipped by the kernel
+        const int nins = (N + 63) / 64, ngr = 4 * nins;
+        for (auto& v : byres) v.clear();
+        for (int q = 0; q < N; ++q) byres[base[q] & 15].push_back(base[q]);
+        int order[16];
+        for (int r = 0; r < 16; ++r) order[r] = r;
+        std::sort(order, order + 16, [&](int x, int y) { return byres[x].size() > byres[y].size(); });
+        gload.assign(ngr, 0);
+        grp.assign(ngr, std::vector<uint16_t>());
+        for (int oi = 0; oi < 16; ++oi) {
+          const std::vector<uint16_t>& cls = byres[order[oi]];
+          if (cls.empty()) break;
+          gres.assign(ngr, 0);
+          for (uint16_t id : cls) {
+            int best = -1;
+            for (int gq = 0; gq < ngr; ++gq) {
+              if (gload[gq] >= 16) continue;
+              if (best < 0 || gres[gq] < gres[best] || (gres[gq] == gres[best] && gload[gq] < gload[best])) best = gq;
+            }
+            grp[best].push_back(id);
+            ++gload[best];
+            ++gres[best];
+          }
+        }
+        // group q = (instruction q / 4, lanes 16 * (q & 3) ..): instruction i is the low (i even) or high (i odd)
+        // half of segment i / 2; lane l holds list positions 2 l and 2 l + 1 of its segment
+        if (nins & 1)
+          for (int l = 0; l < 64; ++l) base[(size_t)(nsg - 1) * 128 + 2 * l + 1] = (uint16_t)0xffffu;
+        for (int gq = 0; gq < ngr; ++gq) {
+          const int ins = gq >> 2, quarter = gq & 3, sgm = ins >> 1, half = ins & 1;
+          bool used[16] = {false};
+          for (uint16_t id : grp[gq]) used[id & 15] = true;
+          int next_free = 0;
+          for (int l = 0; l < 16; ++l) {
+            uint16_t v;
+            if (l < (int)grp[gq].size()) {
+              v = grp[gq][l];
+            } else {
+              while (used[(sp.ch + next_free) & 15]) ++next_free;     // a trash accumulator on an idle bank
+              v = (uint16_t)(sp.ch + next_free);
+              used[(sp.ch + next_free) & 15] = true;
+            }
+            base[(size_t)sgm * 128 + 2 * (16 * quarter + l) + half] = v;
+          }
+        }
+      }
+    }
     std::vector<double> w(m), k(m);
     for (int32_t j = 0; j < m; ++j) {
       k[j] = (double)(Gp[j + 1] - Gp[j]);

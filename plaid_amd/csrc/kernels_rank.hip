@@ -280,6 +280,11 @@ __global__ void fill_f64_kernel(double* p, int32_t n, double v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
+#ifdef PLAIDHIP_DIAG
+static unsigned long long* g_rank_dbg = nullptr;   // tools/ build: per-phase stamps of the bucket kernel
+void debug_set_rank_stamps(void* dbg) { g_rank_dbg = static_cast<unsigned long long*>(dbg); }
+#endif
+
 // the sorting-network kernels: all columns (col_list == nullptr) or the columns the bucket kernel left over
 static int launch_network(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_t g_dense, const int32_t* Xp,
                           int32_t n, int32_t max_len, int ties, int is_signed, double power, double* R, int64_t ldr,
@@ -395,6 +400,9 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
   a.dense_scratch = dscratch;
   a.fb_count = fb_count;
   a.fb_list = fb_list;
+#ifdef PLAIDHIP_DIAG
+  a.dbg = g_rank_dbg;
+#endif
   int rc;
   // 512 threads x 40 keys for a 20k-gene column: 1,024 threads would cap the kernel at 128 registers, short of
   // the 120 a thread needs for its keys and their state alone

@@ -686,7 +686,22 @@ struct ScatterArgs {
   double* S;
   int64_t lds;
   uint32_t* flags;
+  unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
 };
+
+#ifdef PLAIDHIP_DIAG
+#define PH_SC_STAMP(k)                                                                \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+    t_ph[k] += t_ - t_last;                                                            \
+    t_last = t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define PH_SC_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -699,24 +714,192 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* acc = reinterpret_cast<double*>(smem_raw);
   if (a.dense_cells != 0 && (int64_t)a.Xp[a.n] * 8 >= a.dense_cells) return;   // the gather kernel takes this input
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  for (int i = tid; i < a.ch; i += 1024) acc[i] = 0.0;
+  for (int i = tid; i < a.ch + kScatterTrash; i += 1024) acc[i] = 0.0;
   __syncthreads();
   const uint32_t* __restrict__ idw = reinterpret_cast<const uint32_t*>(a.ids);   // two u16 ids per lane and load
-#define PLAIDHIP_SCATTER2(id2, val)                                              \
-  {                                                                              \
-    const uint32_t lo_ = (id2) & 0xffffu, hi_ = (id2) >> 16;                      \
-    if (lo_ != 0xffffu) atomicAdd(&acc[lo_], (val));                              \
-    if (hi_ != 0xffffu) atomicAdd(&acc[hi_], (val));                              \
+  // one dword = two u16 accumulator ids per lane -> two ds_add_f64 wave-instructions.  No compare and no branch
+  // per lane: padded slots hold the id of a trash accumulator behind the chunk (geneset.cpp); a segment whose
+  // second instruction is empty carries 0xffff in every high half (tested once, on lane 0's dword, wave-uniform).
+  // The accumulators start at LDS address 0, so id << 3 IS the LDS address.  (Plain C on purpose: next to an inline-asm
+  // statement hipcc stops counting vmcnt and drains every load in flight, which would serialise the double buffer.)
+  typedef __attribute__((address_space(3))) double lds_f64;
+#define PLAIDHIP_SCATTER2(id2, val)                                                                              \
+  {                                                                                                              \
+    __hip_atomic_fetch_add(reinterpret_cast<lds_f64*>(static_cast<uintptr_t>(((id2) & 0xffffu) << 3)), (val),    \
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                      \
+    if (((uint32_t)__builtin_amdgcn_readfirstlane((int)(id2)) >> 16) != 0xffffu)                                 \
+      __hip_atomic_fetch_add(reinterpret_cast<lds_f64*>(static_cast<uintptr_t>(((id2) >> 16) << 3)), (val),      \
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                    \
+  }
+  // The id segments a wavefront has to apply are a flat work list: lane u holds stored value u of its 64 and the
+  // segment range [s0, s1) of that value's gene in the current chunk; "pass" p takes segment s0 + p of every lane
+  // that has one.  The list is walked UN segments at a time (wave-uniform bookkeeping in scalar registers), and
+  // the loads of the next group are in flight while the LDS atomics of the current one issue: the kernel was
+  // bound by the L2 latency of these loads, not by the atomics.
+  constexpr int UN = 8;
+#define PLAIDHIP_FETCH_GROUP(SEGV, VALV, CNT)                                                \
+  {                                                                                          \
+    CNT = 0;                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                          \
+      while (wmask == 0ull && more) {                                                        \
+        ++pass;                                                                              \
+        wmask = __ballot(ns > pass);                                                         \
+        more = wmask != 0ull;                                                                \
+      }                                                                                      \
+      if (wmask != 0ull) {                                                                   \
+        const int src = __builtin_ctzll(wmask);                                              \
+        wmask &= wmask - 1ull;                                                               \
+        SEGV[u] = __builtin_amdgcn_readlane(s0, src) + pass;                                 \
+        VALV[u] = readlane_f64(v, src);                                                      \
+        CNT = u + 1;                                                                         \
+      } else {                                                                               \
+        SEGV[u] = a.dummy_seg;                                                               \
+        VALV[u] = 0.0;                                                                       \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#define PLAIDHIP_LOAD_GROUP(IDV, SEGV) \
+  _Pragma("unroll") for (int u = 0; u < UN; ++u) IDV[u] = idw[(int64_t)SEGV[u] * 64 + lane];
+#define PLAIDHIP_APPLY_GROUP(IDV, VALV, CNT) \
+  _Pragma("unroll") for (int u = 0; u < UN; ++u) if (u < CNT) PLAIDHIP_SCATTER2(IDV[u], VALV[u])
+
+  // A wavefront applies its 64 stored values one after the other.  Per value the lanes need the value (the data of
+  // the atomic) and the first id segment of its gene in this chunk (the address of the id load): both are staged in
+  // LDS by the owning lane and read back with a wave-uniform address (one broadcast ds_read_b128) -- cross-lane
+  // broadcasts through v_readlane + SGPR bookkeeping made the kernel issue-bound (23 scalar + 12 vector instructions
+  // per segment, PMC) long before the LDS atomics were.  Segment 0 of every value goes through a static pipeline
+  // (8 loads in flight behind the 8 being applied); the few genes with more than 128 sets in the chunk walk their
+  // further segments afterwards (flattened work list, as before).
+  struct __attribute__((aligned(16))) StageEnt { int32_t s0, ns; double v; };
+  StageEnt* stg = reinterpret_cast<StageEnt*>(smem_raw + (size_t)(a.ch + kScatterTrash) * 8) + wave * 64;
+#define PLAIDHIP_WALK_SEGMENTS()                                                                       \
+  {                                                                                                    \
+    stg[lane] = StageEnt{ns > 0 ? s0 : a.dummy_seg, ns, v};                                            \
+    const uint32_t loff = (uint32_t)lane * 4u;                                                         \
+    const unsigned char* idb = reinterpret_cast<const unsigned char*>(idw);                            \
+    /* 48 id loads in flight per wavefront (three groups of 16 ahead of the group being applied): the loop was     \
+       bound by one L2 round trip per group of 8 values, not by the atomics; the values are re-read from the stage */  \
+    constexpr int HW = 16;                                                                             \
+    uint32_t idA[HW], idB[HW], idC[HW], idD[HW];                                                       \
+    const int nval = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(have)));            \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
+      idA[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[u].s0 * 256u + loff));          \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
+      idB[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[HW + u].s0 * 256u + loff));     \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
+      idC[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[2 * HW + u].s0 * 256u + loff)); \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idA[u], stg[u].v)                 \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
+      idD[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[3 * HW + u].s0 * 256u + loff)); \
+    if (nval > HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idB[u], stg[HW + u].v) }      \
+    if (nval > 2 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idC[u], stg[2 * HW + u].v) } \
+    if (nval > 3 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idD[u], stg[3 * HW + u].v) } \
+    /* genes in more than 128 sets of the chunk: their segments 1, 2, ... (flattened over the lanes) */ \
+    uint64_t wmask = __ballot(ns > 1);                                                                 \
+    if (wmask != 0ull) {                                                                               \
+      int pass = 1;                                                                                    \
+      bool more = true;                                                                                \
+      int sgX[UN], cntX;                                                                               \
+      double vX[UN];                                                                                   \
+      uint32_t idX[UN];                                                                                \
+      do {                                                                                             \
+        PLAIDHIP_FETCH_GROUP(sgX, vX, cntX)                                                            \
+        PLAIDHIP_LOAD_GROUP(idX, sgX)                                                                  \
+        PLAIDHIP_APPLY_GROUP(idX, vX, cntX)                                                            \
+      } while (cntX == UN);                                                                            \
+    }                                                                                                  \
+  }
+#define PLAIDHIP_CHUNK_EPILOGUE()                                                                  \
+  for (int i0 = tid; i0 < nj; i0 += 4 * 1024) {                                                     \
+    /* four sets per thread and step: the per-set scale factors are loaded before any is used */    \
+    double kj[4], wj[4], sum[4];                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+      const int i = i0 + u * 1024;                                                                  \
+      const int j = j0 + (i < nj ? i : nj - 1);                                                     \
+      kj[u] = a.k[j];                                                                               \
+      wj[u] = is_mean ? a.w[j] : 1.0;                                                               \
+    }                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+      const int i = i0 + u * 1024;                                                                  \
+      if (i < nj) { sum[u] = acc[i]; acc[i] = 0.0; }                                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+      const int i = i0 + u * 1024;                                                                  \
+      if (i < nj) {                                                                                 \
+        const double val = alpha * (sum[u] * wj[u]) + a.beta * (kj[u] * wj[u]);                     \
+        __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);                        \
+        f |= (val < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                              \
+        f |= (val == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                            \
+        f |= (val != val) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                             \
+      }                                                                                             \
+    }                                                                                               \
   }
 
-  for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
-    const int q0 = a.Xp[c], q1 = a.Xp[c + 1];
+  // Columns of at most 1,024 stored values (one value per thread: the usual single-cell column) run a pipelined
+  // schedule: a thread keeps its (gene, value) for all chunks, the segment range of the next chunk is loaded while
+  // the current one is applied, and the next column's (gene, value) arrive during the last chunk.  Longer columns
+  // take the plain loop below.
+#ifdef PLAIDHIP_DIAG
+  unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+  int c = blockIdx.x;
+  int q0n = 0, q1n = 0;
+  if (c < a.n) { q0n = a.Xp[c]; q1n = a.Xp[c + 1]; }
+  int gene_n = 0;
+  double v_n = 0.0;
+  bool have_n = false;
+  if (c < a.n && q1n - q0n <= 1024) {
+    have_n = q0n + tid < q1n;
+    gene_n = have_n ? a.Xi[q0n + tid] : 0;
+    v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+  }
+  for (; c < a.n; c += gridDim.x) {
+    const int q0 = q0n, q1 = q1n;
+    const int cn = c + gridDim.x;
+    if (cn < a.n) { q0n = a.Xp[cn]; q1n = a.Xp[cn + 1]; }
+    if (q1 - q0 <= 1024) {
+      const bool have = have_n;
+      const int gene = gene_n;
+      const double v = v_n;
+      int s0n = have ? a.seg[gene] : 0;
+      int s1n = have ? a.seg[gene + 1] : 0;
+      for (int chunk = 0; chunk < a.nch; ++chunk) {
+        const int j0 = chunk * a.ch;
+        const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
+        const int s0 = s0n;
+        const int ns = s1n - s0n;
+        if (chunk + 1 < a.nch) {                       // next chunk's segment range of the same genes
+          const int32_t* segn = a.seg + (int64_t)(chunk + 1) * a.g;
+          s0n = have ? segn[gene] : 0;
+          s1n = have ? segn[gene + 1] : 0;
+        } else if (cn < a.n && q1n - q0n <= 1024) {    // last chunk: the next column's stored values
+          have_n = q0n + tid < q1n;
+          gene_n = have_n ? a.Xi[q0n + tid] : 0;
+          v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+        }
+        PH_SC_STAMP(0);
+        PLAIDHIP_WALK_SEGMENTS()
+        PH_SC_STAMP(1);
+        __syncthreads();
+        PH_SC_STAMP(2);
+        PLAIDHIP_CHUNK_EPILOGUE()
+        PH_SC_STAMP(3);
+        __syncthreads();
+        PH_SC_STAMP(4);
+      }
+      continue;
+    }
     for (int chunk = 0; chunk < a.nch; ++chunk) {
       const int j0 = chunk * a.ch;
       const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
@@ -727,70 +910,30 @@ spmm_scatter_csc_f64(ScatterArgs a) {
         const int gene = have ? a.Xi[my] : 0;
         const double v = have ? a.Xx[my] : 0.0;
         const int s0 = have ? segc[gene] : 0;
-        const int s1 = have ? segc[gene + 1] : 0;
-        const int nb = (q1 - qb) < 64 ? (q1 - qb) : 64;
-        constexpr int UN = 8;   // stored values per step: 16 id segments (2 KiB) in flight per wavefront
-        for (int k = 0; k < nb; k += UN) {
-          int b0[UN], b1[UN];
-          double vv[UN];
-          uint32_t ia[UN], ib[UN];
-#pragma unroll
-          for (int u = 0; u < UN; ++u) {
-            const int kk = (k + u < nb) ? k + u : k;          // (a repeated value gets an empty range below)
-            b0[u] = __builtin_amdgcn_readlane(s0, kk);
-            b1[u] = (k + u < nb) ? __builtin_amdgcn_readlane(s1, kk) : b0[u];
-            vv[u] = readlane_f64(v, kk);
-            const int sa = b0[u] < b1[u] ? b0[u] : a.dummy_seg;
-            const int sb = b0[u] + 1 < b1[u] ? b0[u] + 1 : a.dummy_seg;
-            ia[u] = idw[(int64_t)sa * 64 + lane];
-            ib[u] = idw[(int64_t)sb * 64 + lane];
-          }
-#pragma unroll
-          for (int u = 0; u < UN; ++u) {
-            PLAIDHIP_SCATTER2(ia[u], vv[u])
-            PLAIDHIP_SCATTER2(ib[u], vv[u])
-          }
-#pragma unroll
-          for (int u = 0; u < UN; ++u)
-            for (int s = b0[u] + 2; s < b1[u]; ++s) {          // genes in more than 256 sets of the chunk
-              const uint32_t id2 = idw[(int64_t)s * 64 + lane];
-              PLAIDHIP_SCATTER2(id2, vv[u])
-            }
-        }
+        const int ns = have ? segc[gene + 1] - s0 : 0;
+        PLAIDHIP_WALK_SEGMENTS()
       }
       __syncthreads();
-      for (int i0 = tid; i0 < nj; i0 += 4 * 1024) {
-        // four sets per thread and step: the per-set scale factors are loaded before any is used
-        double kj[4], wj[4], sum[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * 1024;
-          const int j = j0 + (i < nj ? i : nj - 1);
-          kj[u] = a.k[j];
-          wj[u] = is_mean ? a.w[j] : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * 1024;
-          if (i < nj) { sum[u] = acc[i]; acc[i] = 0.0; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * 1024;
-          if (i < nj) {
-            const double val = alpha * (sum[u] * wj[u]) + a.beta * (kj[u] * wj[u]);
-            __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);
-            f |= (val < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;
-            f |= (val == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;
-            f |= (val != val) ? PLAIDHIP_FLAG_HAS_NAN : 0u;
-          }
-        }
-      }
+      PLAIDHIP_CHUNK_EPILOGUE()
       __syncthreads();
     }
+    if (cn < a.n && q1n - q0n <= 1024) {               // back to the pipelined schedule
+      have_n = q0n + tid < q1n;
+      gene_n = have_n ? a.Xi[q0n + tid] : 0;
+      v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+    }
   }
+#ifdef PLAIDHIP_DIAG
+  if (a.dbg != nullptr && (tid & 63) == 0)
+    for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * 16 + wave) * 8 + k] = t_ph[k];
+#endif
+#undef PLAIDHIP_WALK_SEGMENTS
+#undef PLAIDHIP_CHUNK_EPILOGUE
   publish_flags(f, a.flags);
 #undef PLAIDHIP_SCATTER2
+#undef PLAIDHIP_FETCH_GROUP
+#undef PLAIDHIP_LOAD_GROUP
+#undef PLAIDHIP_APPLY_GROUP
 }
 
 // how a sparse X is multiplied: plaidhip_set_option(PLAIDHIP_OPT_SPMM_SPARSE_KERNEL): 0 auto (scatter below
@@ -824,7 +967,10 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   a.S = S;
   a.lds = lds;
   a.flags = flags;
-  const size_t smem = (size_t)sp.ch * sizeof(double);
+#ifdef PLAIDHIP_DIAG
+  a.dbg = g_dbg;
+#endif
+  const size_t smem = (size_t)(sp.ch + kScatterTrash) * sizeof(double) + kScatterStage;
   PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64));
   int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
   if (per_cu > 2) per_cu = 2;
@@ -1280,7 +1426,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
+  if ((g_ablate == 0 || g_ablate == 100) && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
     // sparse-aware scatter or dense-work gather.  With nnz(X) from the caller the choice is made here (one
     // launch); without it (nnz < 0: only the device knows) both are enqueued and the one that does not apply
     // returns at once.

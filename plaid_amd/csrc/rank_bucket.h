@@ -56,7 +56,22 @@ struct RankBucketArgs {
   double* dense_scratch;     // g_dense doubles per workgroup
   int32_t* fb_count;         // device counter + list of columns left to the network kernel
   int32_t* fb_list;
+  unsigned long long* dbg;   // tools/ build only: per workgroup, cycles of wave 0 per phase (8 words)
 };
+
+#ifdef PLAIDHIP_DIAG
+#define PH_STAMP(k)                                                                   \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+    t_ph[k] += t_ - t_last;                                                            \
+    t_last = t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define PH_STAMP(k) do { } while (0)
+#endif
 
 // r^(q/4) for r > 0 by (correctly rounded) square roots and multiplications: a few ulp, ~6x cheaper than pow()
 __device__ __forceinline__ double pow_quarters(double r, int q) {
@@ -181,6 +196,10 @@ colranks_bucket_kernel(RankBucketArgs a) {
   uint32_t* mixed = reinterpret_cast<uint32_t*>(smem_raw + L::off_mixed);
   uint64_t* lkeys = reinterpret_cast<uint64_t*>(smem_raw + L::off_keys);
 
+#ifdef PLAIDHIP_DIAG
+  unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
     // an opaque copy of the thread id per column: nothing derived from it is hoisted out of the column loop
     // (LICM would keep dozens of per-thread addresses alive across all phases and spill)
@@ -282,6 +301,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
       kmin = o1 < kmin ? o1 : kmin;
       kmax = o2 > kmax ? o2 : kmax;
     }
+    PH_STAMP(0);   // load + convert + min / max
     const uint64_t lo = kmin;                                         // ~0 when the column has no real key at all
     const uint64_t range = kmax > kmin ? kmax - kmin : 0ull;
     const int rbits = range ? 64 - __clzll((long long)range) : 0;
@@ -309,6 +329,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
     }
     __syncthreads();
 
+    PH_STAMP(1);   // coarse histogram + scan
     // ---- 2b. fine bucket = CDF(coarse) + interpolation inside the coarse interval -----------------------
     uint32_t st[KPT];    // first: fine id | slot << 16; then the state word above
 #pragma unroll
@@ -351,6 +372,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
       if (tid == BLOCK - 1) c2[CAP] = ex;
     }
     __syncthreads();
+    PH_STAMP(2);   // fine histogram + scan
     uint64_t bigmask = 0;
     PH_FOR_ITEMS({
       const bool ok = (validmask >> j) & 1u;
@@ -401,6 +423,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
       continue;
     }
 
+    PH_STAMP(3);   // bucket state + tie test
     // ---- 3. keys of multi-key, not-all-equal buckets -> their bucket's slots in LDS; count inside ----------
     PH_FOR_ITEMS({
       if (st[j] >> 31) lkeys[(st[j] & 0x7fffu) + ((st[j] >> 15) & 0xffu)] = key[j];
@@ -409,23 +432,32 @@ colranks_bucket_kernel(RankBucketArgs a) {
     // the in-bucket counts first (the keys die here), then the output pass
     uint64_t zeromask = 0;
     PH_FOR_ITEMS({
+      // the first four slots of the bucket are probed with all four reads in flight (and the four items of a group
+      // interleave: nothing here branches); longer buckets -- rare unless the column has close clusters -- finish
+      // in a loop.  A settled key probes nothing (cs = 0).
+      const bool scan = st[j] >> 31;
       const uint32_t start = st[j] & 0x7fffu;
-      uint32_t lb = start, ub = start + ((st[j] >> 16) & 0x7fffu);
-      if (st[j] >> 31) {
-        const uint32_t count = ((st[j] >> 23) & 0xffu) + 1u;
-        const uint64_t k = key[j];
-        uint32_t less = 0, leq = 0;
-        for (uint32_t s = 0; s < count; ++s) {
+      const uint32_t cs = scan ? ((st[j] >> 23) & 0xffu) + 1u : 0u;
+      const uint64_t k = key[j];
+      uint32_t less = 0, leq = 0;
+      _Pragma("unroll") for (uint32_t s = 0; s < 4; ++s) {
+        const uint64_t o = lkeys[start + (s < cs ? s : 0u)];
+        less += (s < cs && o < k) ? 1u : 0u;
+        leq += (s < cs && o <= k) ? 1u : 0u;
+      }
+      if (cs > 4u) {
+        for (uint32_t s = 4; s < cs; ++s) {
           const uint64_t o = lkeys[start + s];
           less += (o < k) ? 1u : 0u;
           leq += (o <= k) ? 1u : 0u;
         }
-        lb = start + less;
-        ub = start + leq;
       }
+      const uint32_t lb = start + less;
+      const uint32_t ub = scan ? start + leq : start + ((st[j] >> 16) & 0x7fffu);
       st[j] = lb | (ub << 16);
-      zeromask |= (key[j] == 0x8000000000000000ull) ? (1ull << j) : 0u;
+      zeromask |= (k == 0x8000000000000000ull) ? (1ull << j) : 0u;
     })
+    PH_STAMP(4);   // scatter + in-bucket counts
     double vmax = (a.Xp != nullptr && a.Xi_dense == nullptr) ? 0.0 : -INFINITY;   // sparse ranks: the implicit zeros
     const bool generic_pow = a.pow_q4 == 0 && a.power != 1.0;   // uniform
     if (generic_pow) __syncthreads();                           // every in-bucket count is done: the LDS is free again
@@ -470,9 +502,14 @@ colranks_bucket_kernel(RankBucketArgs a) {
       }
     }
     __syncthreads();
+    PH_STAMP(5);   // ranks -> power -> store (+ column maximum)
 #undef PH_GROUP
 #undef PH_FOR_ITEMS
   }
+#ifdef PLAIDHIP_DIAG
+  if (a.dbg != nullptr && threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 8 + k] = t_ph[k];
+#endif
 }
 
 }  // namespace plaidhip

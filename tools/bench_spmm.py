@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--ties", default="average")
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"])
     ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
-    ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..3 (wrong results by design)")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..7 (wrong results by design; needs PLAIDHIP_LIB=<the make diag library>)")
+    ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the scatter kernel (diag library)")
+    ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
+    ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -29,12 +32,14 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = plaid_amd.Context(0, stream.cuda_stream)
     ctx.set_precision(a.precision)
+    ctx.set_option("spmm_dense_kernel", a.dense_kernel)
+    ctx.set_option("spmm_sparse_kernel", a.sparse_kernel)
     dbg = None
-    if a.ablate:
+    if a.ablate or a.stamps:
         import ctypes
         dbg = torch.zeros(4096 * 16 * 4, dtype=torch.int64, device=dev)
         ctx.lib.plaidhip_debug_set_ablation.argtypes = [ctypes.c_int, ctypes.c_void_p]
-        ctx.lib.plaidhip_debug_set_ablation(a.ablate, dbg.data_ptr())
+        ctx.lib.plaidhip_debug_set_ablation(a.ablate if a.ablate else 100, dbg.data_ptr())
     g, n, m = a.genes, a.samples, a.sets
     t0 = time.perf_counter()
     Gp, Gi = synth.geneset_csc(g, m, sort_by_size=not a.unsorted)
@@ -62,7 +67,8 @@ def main():
             dXi = torch.from_numpy(Xi).to(dev)
             dXx = torch.from_numpy(Xx).to(dev)
             dRx = torch.empty_like(dXx)
-            print(f"sparse X: nnz {len(Xx)} ({len(Xx)/n:.0f} per cell)")
+            max_nnz = int(np.diff(Xp).max())
+            print(f"sparse X: nnz {len(Xx)} ({len(Xx)/n:.0f} per cell, longest {max_nnz})")
         else:
             X = torch.randn((n, g), dtype=torch.float64, device=dev) * 2 + 8
             R = torch.empty_like(X)
@@ -71,14 +77,14 @@ def main():
                 flags.zero_()
                 e0 = ev()
                 if a.kernel == "c3":
-                    ctx.dev_colranks_csc(dXp.data_ptr(), dXx.data_ptr(), n, dRx.data_ptr(), "average", False, 1.25, colmax.data_ptr())
+                    ctx.dev_colranks_csc(dXp.data_ptr(), dXx.data_ptr(), n, max_nnz, dRx.data_ptr(), "average", False, 1.25, colmax.data_ptr())
                 else:
                     ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, "average", False, 1.25, colmax.data_ptr())
                 ctx.dev_max(colmax.data_ptr(), n, red.data_ptr() + 16)
                 e1 = ev()
                 if a.kernel == "c3":
                     ctx.dev_spmm_csc(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
-                                     flags.data_ptr(), red.data_ptr() + 16)
+                                     flags.data_ptr(), red.data_ptr() + 16, nnz=len(Xx))
                 else:
                     ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
                                        red.data_ptr() + 16)
@@ -88,6 +94,13 @@ def main():
                 ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
                 e3 = ev()
             torch.cuda.synchronize()
+            if dbg is not None and a.kernel == "c3" and it == a.iters - 1:
+                d = dbg.cpu().numpy()[: 256 * 16 * 8].reshape(256, 16, 8).astype(float)
+                tot = d[:, :, :5].sum(axis=2).mean()
+                names = ["between", "walk", "barrier1", "epilogue", "barrier2"]
+                print("  scatter stamps (cycles per launch, mean over workgroups x waves): " +
+                      "  ".join(f"{nm} {d[:, :, k].mean():.0f} ({100 * d[:, :, k].mean() / tot:.0f}%)" for k, nm in enumerate(names)))
+                print("  walk cycles by wave, WG 0:", d[0, :, 1].astype(int).tolist())
             print(f"{a.kernel} ({g}x{n}x{m}): rank {e0.elapsed_time(e1):.3f} ms  spmm {e1.elapsed_time(e2):.3f} ms  "
                   f"normalize {e2.elapsed_time(e3):.3f} ms  total {e0.elapsed_time(e3):.3f} ms -> "
                   f"{m*n/e0.elapsed_time(e3)/1e-3:.3e} scores/s")
@@ -130,7 +143,7 @@ def main():
     print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
     if a.kernel == "medians":
         print("  flags words (3 = bracket misses over all launches):", flags.cpu().tolist())
-    if a.ablate == 4 or (a.ablate in (2, 5, 6, 7) and os.environ.get('PLAIDHIP_SPMM_KERNEL') == 'pair'):
+    if a.ablate == 4 or (a.ablate in (2, 5, 6, 7) and True):
         waves = info["waves"]
         nwg = min(n, 256)
         d = dbg.cpu().numpy()[: nwg * waves * 4].reshape(nwg, waves, 4).astype(float)
