@@ -211,6 +211,26 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
                         int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                         double alpha, double* S_out);
 
+/* ---- several GPUs of one node from ONE host process (the R session): multi.cpp ----------------------
+ * The sample columns are cut into ndev contiguous shards (plaidhip_shard_bounds); a host thread per device
+ * moves its shard over its own PCIe link (pipelined through pinned staging), runs the same kernels, and the
+ * three scalars that couple the samples -- max(rX) (R/plaid.R:251), min(x) == 0 (:556-557), mean(medx) (:572)
+ * -- are combined on the host between the phases.  Nothing else crosses between devices (no RCCL).
+ * `devices`: ndev distinct device ordinals, or NULL for 0 .. ndev-1.  X: dense g x n (Xp == NULL, X_or_x are
+ * the doubles) or a dgCMatrix (Xp, Xi, X_or_x = @x).  The contexts are created on first use and kept by the
+ * library until plaidhip_multi_finalize().  Results equal the single-device entry points bit for bit
+ * (shards only change which device computes a column).                                                    */
+int plaidhip_shard_bounds(int64_t n, int ndev, int k, int64_t* lo, int64_t* hi);   /* columns [lo, hi) of shard k */
+int plaidhip_plaid_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                         int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat,
+                         int normalize, double* S_out);
+int plaidhip_sing_multi(const int* devices, int ndev, const double* X, int32_t g, int32_t n, const int32_t* Gp,
+                        const int32_t* Gi, int32_t m, double* S_out);
+int plaidhip_ssgsea_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                          int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
+                          double* S_out);
+int plaidhip_multi_finalize(void);
+
 /* ---- "next" rows of the scope table: thin callers of the same two kernels --------------- */
 
 /* replaid.ucell(X, matG, rmax), R/plaid.R:276-282: rX = colranks(X, "average");

@@ -8,7 +8,8 @@ from ._lib import PlaidHipError, device_count
 from .api import (aligned_pattern, chunked_crossprod, colranks, normalize_medians, plaid, plaid_test, replaid_gsva,
                   replaid_aucell, replaid_scse, replaid_sing, replaid_ssgsea, replaid_ucell,
                   sparse_colranks)
-from .engine import Context, Geneset, default_context
+from .engine import (Context, Geneset, default_context, multi_finalize, plaid_multi, shard_bounds, sing_multi,
+                     ssgsea_multi)
 from .gmt import GmtList, gmt2mat, mat2gmt, read_gmt, write_gmt
 from .matrix import NamedMatrix, as_named
 
@@ -17,5 +18,6 @@ __all__ = [
     "as_named", "GmtList", "read_gmt", "write_gmt", "gmt2mat", "mat2gmt", "plaid",
     "chunked_crossprod", "normalize_medians", "colranks", "sparse_colranks", "replaid_sing",
     "replaid_ssgsea", "replaid_ucell", "replaid_aucell", "replaid_scse", "aligned_pattern", "plaid_test", "replaid_gsva",
+    "plaid_multi", "sing_multi", "ssgsea_multi", "shard_bounds", "multi_finalize",
 ]
-__version__ = "0.1.0"
+__version__ = "0.2.0"

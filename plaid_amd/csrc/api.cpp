@@ -22,6 +22,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+const char* last_error_cstr() { return g_err; }
+
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
   return (e == hipErrorOutOfMemory) ? PLAIDHIP_ENOMEM : PLAIDHIP_EHIP;
@@ -47,6 +49,23 @@ int32_t host_max_col_nnz(const int32_t* Xp, int32_t n) {
   return mx;
 }
 
+int ctx_buffer(plaidhip_ctx* ctx, int k, size_t bytes, void** out) {
+  if (bytes < 256) bytes = 256;
+  if (ctx->hbuf_bytes[k] < bytes) {
+    if (ctx->hbuf[k]) {
+      PH_HIP(hipStreamSynchronize(ctx->stream));
+      PH_HIP(hipFree(ctx->hbuf[k]));
+      ctx->hbuf[k] = nullptr;
+      ctx->hbuf_bytes[k] = 0;
+    }
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    PH_HIP(hipMalloc(&ctx->hbuf[k], want));
+    ctx->hbuf_bytes[k] = want;
+  }
+  *out = ctx->hbuf[k];
+  return PLAIDHIP_OK;
+}
+
 int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask) {
   const uint32_t bit = 1u << (ctx->device & 31);
   if (*done_mask & bit) return PLAIDHIP_OK;
@@ -69,19 +88,15 @@ using namespace plaidhip;
     if (rc_ != PLAIDHIP_OK) return rc_;   \
   } while (0)
 
-namespace {
+namespace plaidhip {
+int DevBuf::alloc(size_t bytes) {
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+  return PLAIDHIP_OK;
+}
+}  // namespace plaidhip
 
-// RAII for the device buffers of one host-level call
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  int alloc(size_t bytes) {
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
-    return PLAIDHIP_OK;
-  }
-  template <typename T> T* as() { return static_cast<T*>(p); }
-};
+namespace {
 
 // The host-level entry points prepare the gene-set collection themselves.  An R session calls them again and
 // again with the same matG, so the last few prepared collections stay in the context (keyed by sizes and a hash
@@ -100,6 +115,8 @@ void hash_words(const int32_t* w, size_t count, uint64_t& h1, uint64_t& h2) {
   }
 }
 
+}  // namespace
+namespace plaidhip {
 int acquire_geneset(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, plaidhip_geneset** out) {
   *out = nullptr;
   uint64_t h = 1469598103934665603ull, h2 = 0x243f6a8885a308d3ull;
@@ -128,6 +145,8 @@ int acquire_geneset(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp, 
   *out = gs;
   return PLAIDHIP_OK;
 }
+}  // namespace plaidhip
+namespace {
 
 int h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -159,6 +178,8 @@ int normalize_on_device(plaidhip_ctx* ctx, double* dS, int32_t m, int32_t n, int
   return PLAIDHIP_OK;
 }
 
+}  // namespace
+namespace plaidhip {
 // dgCMatrix slots handed over by a host language: @p non-decreasing from 0, @i inside [0, g)
 int check_host_csc(const int32_t* Xp, const int32_t* Xi, int32_t g, int32_t n) {
   PH_REQUIRE(Xp != nullptr, "null Xp");
@@ -178,6 +199,8 @@ int check_host_common(const void* G_p, int32_t g, int32_t n, int32_t m) {
   PH_REQUIRE(G_p != nullptr, "null Gp");
   return PLAIDHIP_OK;
 }
+}  // namespace plaidhip
+namespace {
 
 }  // namespace
 
@@ -288,6 +311,13 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   for (plaidhip_ctx::cached_geneset& e : ctx->gs_cache) plaidhip_geneset_destroy(e.gs);
   ctx->gs_cache.clear();
   if (ctx->ws) hipFree(ctx->ws);
+  for (int k = 0; k < plaidhip_ctx::kHostBufs; ++k)
+    if (ctx->hbuf[k]) hipFree(ctx->hbuf[k]);
+  for (int t = 0; t < plaidhip_ctx::kFeeders; ++t) {
+    for (int b = 0; b < 2; ++b)
+      if (ctx->pin[t][b]) hipHostFree(ctx->pin[t][b]);
+    if (ctx->copy_stream[t]) hipStreamDestroy(ctx->copy_stream[t]);
+  }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return PLAIDHIP_OK;
@@ -444,60 +474,19 @@ int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t 
                          const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize,
                          double* S_out) {
   PH_CTX(ctx);
-  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_dense: bad stat %d", stat);
   PH_REQUIRE(n == 0 || (X && S_out), "plaid_dense: null X/S_out");
-  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
-  GenesetHolder gh;
-  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
-  DevBuf dX, dS, dsmall;
-  const int64_t ldg = even_ld(g);
-  PH_TRY(dX.alloc((size_t)ldg * n * 8));
-  PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
-  uint32_t* d_flags = dsmall.as<uint32_t>();
-  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
-  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
-  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
-  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dX.as<double>(), ldg, n, stat, 1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
-  if (normalize)
-    PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
-  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return PLAIDHIP_OK;
+  // one shard on this context: pipelined upload, crossprod per column panel, normalize_medians, download (multi.cpp)
+  return run_sharded(&ctx, 1, 0, nullptr, nullptr, X, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
 }
 
 int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                        int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                        int stat, int normalize, double* S_out) {
   PH_CTX(ctx);
-  PH_TRY(check_host_common(Gp, g, n, m));
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_csc: bad stat %d", stat);
   PH_REQUIRE(Xp != nullptr && (n == 0 || S_out), "plaid_csc: null Xp/S_out");
-  PH_TRY(check_host_csc(Xp, Xi, g, n));
-  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
-  const int64_t zx = Xp[n];
-  GenesetHolder gh;
-  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
-  DevBuf dXp, dXi, dXx, dS, dsmall;
-  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
-  PH_TRY(dXi.alloc((size_t)zx * 4));
-  PH_TRY(dXx.alloc((size_t)zx * 8));
-  PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
-  uint32_t* d_flags = dsmall.as<uint32_t>();
-  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
-  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
-  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
-  PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
-  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
-  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), n, zx, stat,
-                             1.0, nullptr, 0.0, dS.as<double>(), m, d_flags));
-  if (normalize)
-    PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
-  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return PLAIDHIP_OK;
+  return run_sharded(&ctx, 1, 0, Xp, Xi, Xx, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
 }
 
 int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,
@@ -587,99 +576,26 @@ int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int3
 int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                         const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
   PH_CTX(ctx);
-  PH_TRY(check_host_common(Gp, g, n, m));
-  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
-  PH_REQUIRE(X && S_out, "sing_dense: null X/S_out");
-  GenesetHolder gh;
-  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
-  DevBuf dX, dR, dS;
-  const int64_t ldg = even_ld(g);
-  PH_TRY(dX.alloc((size_t)ldg * n * 8));
-  PH_TRY(dR.alloc((size_t)ldg * n * 8));
-  PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
-  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_MIN, 0, 1.0, dR.as<double>(), ldg, nullptr));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,
-                               dS.as<double>(), m, nullptr, /*x_exact_in_f32=*/true));   // integer ranks
-  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return PLAIDHIP_OK;
+  return run_sharded(&ctx, 1, 1, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
 }
 
 int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                           const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
                           double* S_out) {
   PH_CTX(ctx);
-  PH_TRY(check_host_common(Gp, g, n, m));
-  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
-  PH_REQUIRE(X && S_out, "ssgsea_dense: null X/S_out");
-  GenesetHolder gh;
-  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
-  DevBuf dX, dR, dS, dsmall;
-  const int64_t ldg = even_ld(g);
-  PH_TRY(dX.alloc((size_t)ldg * n * 8));
-  PH_TRY(dR.alloc((size_t)ldg * n * 8));
-  PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
-  uint32_t* d_flags = dsmall.as<uint32_t>();
-  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
-  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
-  double* d_colmax = d_med + n;
-  PH_TRY(h2d_cols(ctx, dX.p, ldg, X, g, n));
   // rX = colranks(X, ties="average")^(1+alpha) ; rX/max(rX) - 0.5 ; plaid(mean, normalize=TRUE)  (R/plaid.R:245-253)
-  PH_TRY(launch_colranks_dense_f64(ctx, dX.as<double>(), ldg, g, n, PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha,
-                                   dR.as<double>(), ldg, d_colmax));
-  double* d_gmax = d_red + 2;   // max(rX), stays on the device
-  PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
-  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5,
-                               dS.as<double>(), m, d_flags, /*x_exact_in_f32=*/alpha == 0.0));   // plain average ranks
-  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
-  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return PLAIDHIP_OK;
+  return run_sharded(&ctx, 1, 2, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 1, alpha, S_out);
 }
 
 int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                         int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                         double alpha, double* S_out) {
   PH_CTX(ctx);
-  PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(Xp != nullptr, "ssgsea_csc: null Xp");
-  PH_TRY(check_host_csc(Xp, Xi, g, n));
-  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
-  PH_REQUIRE(S_out != nullptr, "ssgsea_csc: null S_out");
-  const int64_t zx = Xp[n];
-  GenesetHolder gh;
-  PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
-  DevBuf dXp, dXi, dXx, dRx, dS, dsmall;
-  PH_TRY(dXp.alloc((size_t)(n + 1) * 4));
-  PH_TRY(dXi.alloc((size_t)zx * 4));
-  PH_TRY(dXx.alloc((size_t)zx * 8));
-  PH_TRY(dRx.alloc((size_t)zx * 8));
-  PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(dsmall.alloc(64 + (size_t)n * 16));
-  uint32_t* d_flags = dsmall.as<uint32_t>();
-  double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
-  double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
-  double* d_colmax = d_med + n;
-  PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
-  PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
-  PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
-  // sparse branch: ranks of the non-zeros only, zeros stay 0 (R/plaid.R:600-601, 631-650); the
-  // "- 0.5" of R/plaid.R:251 applies to the zeros too, which the (alpha, beta) epilogue covers.
-  PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dXx.as<double>(), n, host_max_col_nnz(Xp, n),
-                                 PLAIDHIP_TIES_AVERAGE, 0, 1.0 + alpha, dRx.as<double>(), d_colmax));
-  double* d_gmax = d_red + 2;   // max(rX), stays on the device
-  PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
-  PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_csc_f64(ctx, gh.gs, dXp.as<int32_t>(), dXi.as<int32_t>(), dRx.as<double>(), n, zx,
-                             PLAIDHIP_STAT_MEAN, 1.0, d_gmax, -0.5, dS.as<double>(), m, d_flags));
-  PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
-  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PH_HIP(hipStreamSynchronize(ctx->stream));
-  return PLAIDHIP_OK;
+  // sparse branch: ranks of the non-zeros only, zeros stay 0 (R/plaid.R:600-601, 631-650); the "- 0.5" of
+  // R/plaid.R:251 applies to the zeros too, which the (alpha, beta) epilogue covers
+  return run_sharded(&ctx, 1, 2, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 1, alpha, S_out);
 }
 
 }  // extern "C"

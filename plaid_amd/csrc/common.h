@@ -65,6 +65,16 @@ struct plaidhip_ctx {
   int opt_nt_store = -1;       // -1 auto | 0 | 1
   int opt_ranks_f32 = 1;       // rank inputs take the fp32-staged crossprod
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
+  // pinned staging of the pipelined host uploads (multi.cpp): kFeeders feeder threads x 2 buffers, their streams
+  static constexpr int kFeeders = 4;
+  void* pin[kFeeders][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  size_t pin_bytes = 0;
+  hipStream_t copy_stream[kFeeders] = {nullptr, nullptr, nullptr, nullptr};
+  // device buffers of the host-level pipelines, kept between calls (an R session scores matrix after matrix of the
+  // same shape; hipMalloc + hipFree of gigabytes per call cost milliseconds and a device synchronisation)
+  static constexpr int kHostBufs = 6;
+  void* hbuf[kHostBufs] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t hbuf_bytes[kHostBufs] = {0, 0, 0, 0, 0, 0};
 };
 
 // Prepared membership (built by geneset.cpp, see the header comment there).
@@ -151,6 +161,28 @@ struct plaidhip_geneset {
 namespace plaidhip {
 
 int ensure_workspace(plaidhip_ctx* ctx, size_t bytes);
+// RAII for the device buffers of one host-level call
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) hipFree(p); }
+  int alloc(size_t bytes);
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+// slot `k` of the context's persistent host-pipeline buffers, grown to at least `bytes` (contents undefined)
+int ctx_buffer(plaidhip_ctx* ctx, int k, size_t bytes, void** out);
+// host-level helpers shared by api.cpp and multi.cpp
+int acquire_geneset(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, plaidhip_geneset** out);
+int check_host_csc(const int32_t* Xp, const int32_t* Xi, int32_t g, int32_t n);
+int check_host_common(const void* G_p, int32_t g, int32_t n, int32_t m);
+const char* last_error_cstr();
+// the sample-sharded host pipeline behind plaid / replaid.sing / replaid.ssgsea (multi.cpp): ndev contexts, one per
+// device; X dense (Xp == nullptr) or CSC; method 0 plaid, 1 sing, 2 ssgsea
+int run_sharded(plaidhip_ctx* const* ctxs, int ndev, int method, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
+                int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double alpha,
+                double* S_out);
 // opt a kernel into the full 160 KiB of dynamic LDS, once per (kernel, device)
 int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask);
 #define PH_FULL_LDS(ctx, kernel)                                                          \

@@ -17,6 +17,7 @@
 //      chunks (8 u16 gene ids per lane), so the kernel's index prefetch never restarts.
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -26,7 +27,7 @@
 using namespace plaidhip;
 
 // measured on MI355X (tools/bench_spmm.py --ablate 4), see wave_weights()
-static const double kAgeShare16[4] = {1.6, 1.2, 0.8, 0.4};          // two-column fp64 kernel (pair plan): 0.988 -> 0.970 ms vs 1.3/1.1/0.9/0.7
+// (the pair plan interpolates its shares by tile count, build_pair_plan)
 static const double kAgeShare16Single[4] = {1.6, 1.2, 0.8, 0.4};    // one-column plan: tuned on its main user, the mixed-precision pair kernel
 
 namespace {
@@ -439,7 +440,18 @@ void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
   for (int si = 0; si < S; ++si)
     for (int32_t t = 0; t < tiles; ++t) tot[t] += plans[si][t].steps;
   std::vector<std::vector<int32_t>> mine;
-  assign_tiles(tot, waves, mine, kAgeShare16);
+  // The share an age class can take depends on how long its stream is: with ~5 tiles per wavefront (C2: 5,000 sets)
+  // the youngest four lag most and get 0.46 of an equal share, with ~50 (50,000 sets) 0.57 (in-kernel stamps per
+  // wavefront, tools/bench_spmm.py --ablate 4: with the C2 shares the youngest class of a 50k-set plan sat 40 % of
+  // the gather phase at the end-of-slice barrier).  Interpolated in log(tiles) between the two measured plans.
+  double share[4];
+  {
+    static const double lo[4] = {1.53, 1.20, 0.81, 0.46}, hi[4] = {1.40, 1.16, 0.87, 0.57};
+    double t = (std::log((double)std::max(tiles, 1)) - std::log(80.0)) / (std::log(800.0) - std::log(80.0));
+    t = std::min(1.0, std::max(0.0, t));
+    for (int q = 0; q < 4; ++q) share[q] = lo[q] + t * (hi[q] - lo[q]);
+  }
+  assign_tiles(tot, waves, mine, share);
   pp.wave_tile_off.assign(waves + 1, 0);
   std::vector<int32_t> ktile;   // wave-stream order -> tile
   for (int w = 0; w < waves; ++w) {

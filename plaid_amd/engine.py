@@ -341,3 +341,60 @@ def default_context() -> Context:
         import os
         _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _default_ctx
+
+
+# ---- several GPUs from one host process (plaidhip_*_multi: a host thread per device, no RCCL) ------------------
+def shard_bounds(n: int, ndev: int, k: int):
+    """columns [lo, hi) of shard k of n sample columns over ndev devices (needs no device)"""
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    check(_lib.load().plaidhip_shard_bounds(int(n), int(ndev), int(k), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def _devices_arg(devices):
+    if devices is None:
+        raise ValueError("devices: a list of device ordinals or an int (the first ndev devices)")
+    if isinstance(devices, int):
+        return None, int(devices), None
+    d = np.ascontiguousarray(devices, dtype=np.int32)
+    return _np_ptr(d), len(d), d
+
+
+def plaid_multi(X, Gp, Gi, stat="mean", normalize=True, devices=1) -> np.ndarray:
+    """plaid() with the sample columns sharded over `devices` (an int: devices 0 .. n-1, or a list of ordinals)"""
+    lib = _lib.load()
+    xp, xi, xv, g, n, keep = _x_args(X)
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    dp, nd, dkeep = _devices_arg(devices)
+    check(lib.plaidhip_plaid_multi(dp, nd, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m, STAT[stat], int(bool(normalize)),
+                                   _np_ptr(S)))
+    return S
+
+
+def sing_multi(X, Gp, Gi, devices=1) -> np.ndarray:
+    lib = _lib.load()
+    X = _as_f64_fortran(X)
+    g, n = X.shape
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    dp, nd, dkeep = _devices_arg(devices)
+    check(lib.plaidhip_sing_multi(dp, nd, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m, _np_ptr(S)))
+    return S
+
+
+def ssgsea_multi(X, Gp, Gi, alpha=0.0, devices=1) -> np.ndarray:
+    lib = _lib.load()
+    xp, xi, xv, g, n, keep = _x_args(X)
+    Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+    m = len(Gp) - 1
+    S = np.empty((m, n), dtype=np.float64, order="F")
+    dp, nd, dkeep = _devices_arg(devices)
+    check(lib.plaidhip_ssgsea_multi(dp, nd, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m, float(alpha), _np_ptr(S)))
+    return S
+
+
+def multi_finalize():
+    check(_lib.load().plaidhip_multi_finalize())

@@ -709,7 +709,7 @@ def test_c3_step_is_capturable_in_a_hip_graph():
     gs = ctx.geneset(g, Gp, Gi)
     Xp, Xi, Xx = sy.sparse_columns(g, 0, n, density=0.06)
     zx = int(Xp[-1])
-    cap = zx + 64                                              # fixed-size buffers: the graph is shape-static
+    cap = zx + zx // 4                                        # fixed-size buffers: the graph is shape-static
     dXp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
     dXi = torch.zeros(cap, dtype=torch.int32, device=dev)
     dXx = torch.zeros(cap, dtype=torch.float64, device=dev)
@@ -756,3 +756,45 @@ def test_c3_step_is_capturable_in_a_hip_graph():
     close(S.cpu().numpy().T, _oracle().replaid_ssgsea(Xs2, rn, G, rn, alpha=0.25))
     gs.close()
     ctx.close()
+
+
+# ---------------------------------------------------------------- host entry points: pipelined uploads, multi-device form
+def test_multi_device_entry_with_one_device_equals_the_context_entry(hip_ctx):
+    """plaidhip_*_multi with ndev = 1 (all a 1-GPU box can run) is the same sharded engine as the context entry points:
+    bit-identical scores for plaid / sing / ssgsea, dense and dgCMatrix X; and a device list with a repeat is refused"""
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, n, m = 9000, 37, 210
+    Gp, Gi = sy.geneset_csc(g, m, kmin=3, kmax=300, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    Xz = np.where(np.random.default_rng(2).random(X.shape) < 0.9, 0.0, X)
+    Xs = sp.csc_matrix(Xz)
+    assert np.array_equal(plaid_amd.plaid_multi(X, Gp, Gi, "mean", True, devices=1), hip_ctx.plaid_dense(X, Gp, Gi, "mean", True))
+    assert np.array_equal(plaid_amd.plaid_multi(X, Gp, Gi, "sum", False, devices=[0]), hip_ctx.plaid_dense(X, Gp, Gi, "sum", False))
+    a = plaid_amd.plaid_multi(Xs, Gp, Gi, "mean", True, devices=1)
+    close(a, hip_ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True))      # LDS atomics: last bits vary
+    assert np.array_equal(plaid_amd.sing_multi(X, Gp, Gi, devices=1), hip_ctx.sing_dense(X, Gp, Gi))
+    assert np.array_equal(plaid_amd.ssgsea_multi(X, Gp, Gi, 0.25, devices=1), hip_ctx.ssgsea_dense(X, Gp, Gi, 0.25))
+    close(plaid_amd.ssgsea_multi(Xs, Gp, Gi, 0.25, devices=1), hip_ctx.ssgsea_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, 0.25))
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(plaid_amd.ssgsea_multi(Xs, Gp, Gi, 0.25, devices=1), _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
+    with pytest.raises(plaid_amd.PlaidHipError):
+        plaid_amd.plaid_multi(X, Gp, Gi, devices=[0, 0])
+    plaid_amd.multi_finalize()
+
+
+def test_pipelined_host_upload_many_panels(hip_ctx):
+    """a matrix larger than the pinned staging (several 48 MB panels per feeder thread, odd gene count so that the
+    device leading dimension differs from nrow): the crossprod per landed panel gives the oracle's scores"""
+    from oracle import c_oracle
+    from plaid_amd import synth as sy
+    g, n, m = 19999, 1500, 64                                  # 240 MB of X: ~6 panels
+    Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
+    X = sy.dense_columns(g, 0, n)
+    close(hip_ctx.plaid_dense(X, Gp, Gi, "mean", True), c_oracle.plaid_dense(X, Gp, Gi, "mean", True))
+    cols = [0, 299, 300, 301, 1499]
+    Ssing = hip_ctx.sing_dense(X, Gp, Gi)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    close(Ssing[:, cols], _oracle().replaid_sing(X[:, cols], rn, G, rn))

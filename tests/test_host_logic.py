@@ -283,3 +283,19 @@ def test_int32_slots_refuse_values_that_do_not_fit():
     assert _as_i32(np.array([0, 5, 2**31 - 1], dtype=np.int64)).dtype == np.int32
     with pytest.raises(_lib.PlaidHipError):
         _as_i32(np.array([0, 2**31], dtype=np.int64))
+
+
+def test_c_abi_shard_bounds_match_the_python_side():
+    """plaidhip_shard_bounds (the multi-device host entry's shard rule) needs no device; it is the same rule as
+    sharded.shard_bounds (the RCCL path): contiguous blocks of ceil(n / ndev) columns, trailing shards short or empty"""
+    for n in (0, 1, 7, 8, 9, 1000, 100000):
+        for ndev in (1, 2, 3, 8):
+            cover = []
+            for k in range(ndev):
+                lo, hi = plaid_amd.shard_bounds(n, ndev, k)
+                assert (lo, hi) == shard_bounds(n, ndev, k)
+                cover += list(range(lo, hi)) if n <= 1000 else []
+            if n <= 1000:
+                assert cover == list(range(n))
+    with pytest.raises(_lib.PlaidHipError):
+        plaid_amd.shard_bounds(5, 0, 0)
