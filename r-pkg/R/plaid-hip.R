@@ -4,6 +4,23 @@
 ## A maintainer of the reference would add `useDynLib(plaidhip, .registration = TRUE)` to
 ## NAMESPACE and replace the bodies of the functions below (see INTEGRATION.md).
 
+## Session options (set with options(); read on every call):
+##   plaidhip.device     integer, the GPU ordinal the session context lives on (default 0; read when the
+##                       context is first created)
+##   plaidhip.devices    integer vector of GPU ordinals: with more than one, plaid() / replaid.sing() /
+##                       replaid.ssgsea() shard the sample columns over them (a host thread per device inside
+##                       the library, no process per GPU); default: the session device alone
+##   plaidhip.precision  "f64" (default: scores equal to the last bits) or "mixed" (dense crossprod stages the
+##                       sample columns as fp32, sums fp64; ~1e-7 relative, inside the 1e-5 bar; ~1.5x faster)
+.device <- function() as.integer(getOption("plaidhip.device", 0L))
+.devices <- function() as.integer(getOption("plaidhip.devices", .device()))
+.session <- function() {
+  prec <- match(getOption("plaidhip.precision", "f64"), c("f64", "mixed"))
+  if (is.na(prec)) stop("options(plaidhip.precision) must be \"f64\" or \"mixed\"")
+  .Call("R_plaidhip_session", .device(), prec - 1L, PACKAGE = "plaidhip")
+  invisible(NULL)
+}
+
 .stat_code <- function(stats) match(stats[1], c("mean", "sum")) - 1L
 .ties_code <- function(ties.method) {
   code <- match(ties.method, c("average", "min", "max"))
@@ -34,11 +51,17 @@ plaid <- function(X, matG, stats = c("mean", "sum"), chunk = NULL, normalize = T
     message("[plaid] ERROR. No overlapping features.")
     return(NULL)
   }
-  if (inherits(X, "CsparseMatrix")) {
+  .session()
+  dev <- .devices()
+  if (length(dev) > 1L) {                                  # sample shards over several GPUs of the node
+    xa <- .x_args(X)
+    S <- .Call("R_plaidhip_plaid_multi", dev, xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
+               .stat_code(stats), normalize, PACKAGE = "plaidhip")
+  } else if (inherits(X, "CsparseMatrix")) {
     S <- .Call("R_plaidhip_plaid_csc", X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi,
                .stat_code(stats), normalize, PACKAGE = "plaidhip")
   } else {
-    storage.mode(X) <- "double"
+    X <- as.matrix(X); storage.mode(X) <- "double"
     S <- .Call("R_plaidhip_plaid_dense", X, pat$Gp, pat$Gi, .stat_code(stats), normalize,
                PACKAGE = "plaidhip")
   }
@@ -46,7 +69,51 @@ plaid <- function(X, matG, stats = c("mean", "sum"), chunk = NULL, normalize = T
   S
 }
 
+## chunked_crossprod(x, y, chunk), R/plaid.R:100-123: t(x) %*% y for the membership matrix plaid() builds
+## (0/1, optionally scaled per column, R/plaid.R:73-77) -- internal in the reference too.  The column scale is
+## read off x and applied to the device's unscaled sums; the chunk loop and its message are the reference's
+## (the device has no 2^31 limit, the loop only bounds the size of one transfer).  An x with different values
+## inside a column is not a membership matrix: Matrix::crossprod keeps that case.
+chunked_crossprod <- function(x, y, chunk = NULL) {
+  x <- methods::as(methods::as(x, "CsparseMatrix"), "generalMatrix")
+  if (nrow(x) != nrow(y)) stop("non-conformable arguments")
+  col <- rep.int(seq_len(ncol(x)), diff(x@p))
+  nz <- x@x != 0
+  lo <- tapply(x@x[nz], factor(col[nz], levels = seq_len(ncol(x))), min)
+  hi <- tapply(x@x[nz], factor(col[nz], levels = seq_len(ncol(x))), max)
+  if (any(lo != hi, na.rm = TRUE)) return(Matrix::crossprod(x, y))
+  scale <- ifelse(is.na(lo), 1, lo)
+  Gp <- c(0L, cumsum(tabulate(col[nz], nbins = ncol(x))))
+  Gi <- x@i[nz]
+  if (is.null(chunk) || chunk < 0) chunk <- round(0.8 * 2147483647 / ncol(x))     # R/plaid.R:103-104
+  .session()
+  block <- function(jj) {
+    yy <- y[, jj, drop = FALSE]
+    if (inherits(yy, "CsparseMatrix")) {
+      .Call("R_plaidhip_plaid_csc", yy@p, yy@i, as.double(yy@x), nrow(yy), Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
+    } else {
+      yy <- as.matrix(yy); storage.mode(yy) <- "double"
+      .Call("R_plaidhip_plaid_dense", yy, Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
+    }
+  }
+  if (ncol(y) < chunk) {
+    gsetX <- block(seq_len(ncol(y)))
+  } else {
+    message("[chunked_crossprod] chunked compute: chunk = ", chunk)                # R/plaid.R:109
+    gsetX <- matrix(NA_real_, ncol(x), ncol(y))
+    k <- ceiling(ncol(y) / chunk)
+    for (i in seq_len(k)) {
+      jj <- ((i - 1) * chunk + 1):min(ncol(y), i * chunk)
+      gsetX[, jj] <- block(jj)
+    }
+  }
+  gsetX <- gsetX * scale
+  dimnames(gsetX) <- list(colnames(x), colnames(y))
+  gsetX
+}
+
 normalize_medians <- function(x, ignore.zero = NULL) {
+  .session()
   x <- as.matrix(x); storage.mode(x) <- "double"
   iz <- if (is.null(ignore.zero)) NA else as.logical(ignore.zero)
   out <- .Call("R_plaidhip_normalize_medians", x, iz, PACKAGE = "plaidhip")
@@ -55,6 +122,7 @@ normalize_medians <- function(x, ignore.zero = NULL) {
 }
 
 sparse_colranks <- function(X, signed = FALSE, ties.method = "average") {
+  .session()
   X <- methods::as(X, "CsparseMatrix")
   rX <- X
   rX@x <- .Call("R_plaidhip_colranks_csc", X@p, as.double(X@x), .ties_code(ties.method), signed,
@@ -65,8 +133,16 @@ sparse_colranks <- function(X, signed = FALSE, ties.method = "average") {
 colranks <- function(X, sparse = NULL, signed = FALSE, keep.zero = FALSE, ties.method = "average") {
   if (is.null(sparse)) sparse <- inherits(X, "CsparseMatrix")
   if (sparse && keep.zero) return(sparse_colranks(X, signed = signed, ties.method = ties.method))
-  D <- as.matrix(X); storage.mode(D) <- "double"
-  rX <- .Call("R_plaidhip_colranks_dense", D, .ties_code(ties.method), signed, PACKAGE = "plaidhip")
+  .session()
+  if (inherits(X, "CsparseMatrix")) {
+    ## zeros are ranked and the result is dense (sparseMatrixStats::colRanks, R/plaid.R:602-609), but the
+    ## matrix goes to the device as its three CSC slots: no as.matrix(X) on the host
+    rX <- .Call("R_plaidhip_colranks_csc_dense", X@p, X@i, as.double(X@x), nrow(X), .ties_code(ties.method),
+                signed, PACKAGE = "plaidhip")
+  } else {
+    D <- as.matrix(X); storage.mode(D) <- "double"
+    rX <- .Call("R_plaidhip_colranks_dense", D, .ties_code(ties.method), signed, PACKAGE = "plaidhip")
+  }
   dimnames(rX) <- dimnames(X)
   rX
 }
@@ -74,8 +150,11 @@ colranks <- function(X, sparse = NULL, signed = FALSE, keep.zero = FALSE, ties.m
 replaid.sing <- function(X, matG) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  .session()
   D <- as.matrix(X); storage.mode(D) <- "double"
-  S <- .Call("R_plaidhip_sing_dense", D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+  dev <- .devices()
+  S <- if (length(dev) > 1L) .Call("R_plaidhip_sing_multi", dev, D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+       else .Call("R_plaidhip_sing_dense", D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }
@@ -83,7 +162,13 @@ replaid.sing <- function(X, matG) {
 replaid.ssgsea <- function(X, matG, alpha = 0) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
-  if (inherits(X, "CsparseMatrix")) {
+  .session()
+  dev <- .devices()
+  if (length(dev) > 1L) {
+    xa <- .x_args(X)
+    S <- .Call("R_plaidhip_ssgsea_multi", dev, xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
+               as.double(alpha), PACKAGE = "plaidhip")
+  } else if (inherits(X, "CsparseMatrix")) {
     S <- .Call("R_plaidhip_ssgsea_csc", X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi,
                as.double(alpha), PACKAGE = "plaidhip")
   } else {
@@ -103,6 +188,7 @@ replaid.ssgsea <- function(X, matG, alpha = 0) {
 replaid.ucell <- function(X, matG, rmax = 1500) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  .session()
   xa <- .x_args(X)
   S <- .Call("R_plaidhip_ucell", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
              as.double(Matrix::colSums(matG != 0)), as.double(rmax), PACKAGE = "plaidhip")
@@ -113,6 +199,7 @@ replaid.ucell <- function(X, matG, rmax = 1500) {
 replaid.aucell <- function(X, matG, aucMaxRank = ceiling(0.05 * nrow(X))) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  .session()
   xa <- .x_args(X)
   S <- .Call("R_plaidhip_aucell", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
              as.double(aucMaxRank), PACKAGE = "plaidhip")
@@ -123,6 +210,7 @@ replaid.aucell <- function(X, matG, aucMaxRank = ceiling(0.05 * nrow(X))) {
 replaid.scse <- function(X, matG, removeLog2 = NULL, scoreMean = FALSE) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
+  .session()
   xa <- .x_args(X)
   S <- .Call("R_plaidhip_scse", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
              if (is.null(removeLog2)) NA else as.logical(removeLog2), as.logical(scoreMean),
@@ -160,11 +248,13 @@ plaid.test <- function(X, y, G, gsetX = NULL, tests = c("one", "two", "lm"),
   }
   if (!metap.method %in% c("fisher", "sumlog", "stouffer", "sumz")) stop("Invalid method: ", metap.method)
   gg <- intersect(rownames(G), rownames(X))
-  X <- as.matrix(X[gg, , drop = FALSE])
-  G <- methods::as(G[gg, , drop = FALSE] != 0, "dgCMatrix")
-  if (!is.null(gsetX)) gsetX <- as.matrix(gsetX[colnames(G), , drop = FALSE])
+  X <- as.matrix(X[gg, , drop = FALSE]); storage.mode(X) <- "double"
+  G <- G[gg, , drop = FALSE]
+  pat <- .aligned_pattern(X, G)                           # stored zeros of G are dropped: set sizes count members only
+  if (!is.null(gsetX)) { gsetX <- as.matrix(gsetX[colnames(G), , drop = FALSE]); storage.mode(gsetX) <- "double" }
   bits <- sum(c(one = 1L, two = 2L, lm = 4L)[intersect(tests, c("one", "two", "lm"))])
-  r <- .Call("R_plaidhip_plaid_test", X, as.integer(y), G@p, G@i, gsetX, bits,
+  .session()
+  r <- .Call("R_plaidhip_plaid_test", X, as.integer(y), pat$Gp, pat$Gi, gsetX, bits,
              as.integer(metap.method %in% c("stouffer", "sumz")), PACKAGE = "plaidhip")
   keep <- c(TRUE, "one" %in% tests, "two" %in% tests, "lm" %in% tests, TRUE, TRUE)
   res <- r[, keep, drop = FALSE]
@@ -181,7 +271,9 @@ replaid.gsva <- function(X, matG, tau = 0, rowtf = c("z", "ecdf")[1]) {
   if (!rowtf %in% c("z", "ecdf")) stop("Error: unknown row transform", rowtf)
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
-  S <- .Call("R_plaidhip_gsva", as.matrix(X), pat$Gp, pat$Gi, as.numeric(tau), as.integer(rowtf == "ecdf"), PACKAGE = "plaidhip")
+  .session()
+  D <- as.matrix(X); storage.mode(D) <- "double"
+  S <- .Call("R_plaidhip_gsva", D, pat$Gp, pat$Gi, as.numeric(tau), as.integer(rowtf == "ecdf"), PACKAGE = "plaidhip")
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }

@@ -15,10 +15,11 @@
 #include "plaidhip.h"
 
 static plaidhip_ctx* g_ctx = NULL;
+static int g_device = 0;
 
 static plaidhip_ctx* ctx(void) {
   if (g_ctx == NULL) {
-    int rc = plaidhip_init(0, NULL, &g_ctx);
+    int rc = plaidhip_init(g_device, NULL, &g_ctx);
     if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
   }
   return g_ctx;
@@ -26,6 +27,16 @@ static plaidhip_ctx* ctx(void) {
 
 static void check(int rc) {
   if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
+}
+
+/* options(plaidhip.device, plaidhip.precision): called by every R wrapper before its .Call.  A changed device
+ * closes the session context (the next call opens one on the new device). */
+SEXP R_plaidhip_session(SEXP device, SEXP precision) {
+  const int d = Rf_asInteger(device);
+  if (d != g_device && g_ctx != NULL) { plaidhip_finalize(g_ctx); g_ctx = NULL; }
+  g_device = d;
+  check(plaidhip_set_precision(ctx(), Rf_asInteger(precision)));
+  return R_NilValue;
 }
 
 /* plaid(): X numeric matrix g x n; Gp/Gi integer vectors = aligned membership pattern in
@@ -76,6 +87,16 @@ SEXP R_plaidhip_colranks_csc(SEXP Xp, SEXP Xx, SEXP ties, SEXP is_signed) {
   return R;
 }
 
+/* colranks(sparse X, keep.zero = FALSE): dense g x n ranks from the CSC slots (R/plaid.R:602-609) */
+SEXP R_plaidhip_colranks_csc_dense(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP ties, SEXP is_signed) {
+  const int n = LENGTH(Xp) - 1, gg = Rf_asInteger(g);
+  SEXP R = PROTECT(Rf_allocMatrix(REALSXP, gg, n));
+  check(plaidhip_colranks_csc_dense(ctx(), INTEGER(Xp), INTEGER(Xi), REAL(Xx), gg, n, Rf_asInteger(ties),
+                                    Rf_asLogical(is_signed), REAL(R)));
+  UNPROTECT(1);
+  return R;
+}
+
 SEXP R_plaidhip_sing_dense(SEXP X, SEXP Gp, SEXP Gi) {
   const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
   SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
@@ -103,6 +124,35 @@ SEXP R_plaidhip_ssgsea_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi, 
 
 /* X: numeric matrix or NULL; for a dgCMatrix pass Xp/Xi/Xx (else R_NilValue) */
 static const int* int_or_null(SEXP x) { return Rf_isNull(x) ? NULL : INTEGER(x); }
+
+/* several GPUs from the one R process: `devices` integer vector of ordinals (plaidhip_*_multi, a host thread per
+ * device inside the library) */
+SEXP R_plaidhip_plaid_multi(SEXP devices, SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP stat,
+                            SEXP normalize) {
+  const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  check(plaidhip_plaid_multi(INTEGER(devices), LENGTH(devices), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g),
+                             nn, INTEGER(Gp), INTEGER(Gi), m, Rf_asInteger(stat), Rf_asLogical(normalize), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_sing_multi(SEXP devices, SEXP X, SEXP Gp, SEXP Gi) {
+  const int g = Rf_nrows(X), n = Rf_ncols(X), m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_sing_multi(INTEGER(devices), LENGTH(devices), REAL(X), g, n, INTEGER(Gp), INTEGER(Gi), m, REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_ssgsea_multi(SEXP devices, SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP alpha) {
+  const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  check(plaidhip_ssgsea_multi(INTEGER(devices), LENGTH(devices), int_or_null(Xp), int_or_null(Xi), REAL(Xv),
+                              Rf_asInteger(g), nn, INTEGER(Gp), INTEGER(Gi), m, Rf_asReal(alpha), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
 
 SEXP R_plaidhip_ucell(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi, SEXP kfull, SEXP rmax) {
   const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
@@ -158,26 +208,36 @@ SEXP R_plaidhip_gmt2mat_file(SEXP path, SEXP add_source, SEXP nrows, SEXP max_ge
   const int rc = plaidhip_gmt2mat(gmt, (int64_t)Rf_asReal(max_genes), (int64_t)Rf_asReal(ntop), bgp, nbg, &mat);
   plaidhip_gmt_destroy(gmt);
   if (rc != PLAIDHIP_OK) Rf_error("plaidhip: %s", plaidhip_last_error_string());
-  int64_t dims[3], nb = 0;
+  /* everything R needs is copied into R_alloc() memory (released by R itself, also on error) and `mat` is freed
+   * BEFORE the first R allocation that could longjmp: an allocation failure cannot leak the native object */
+  int64_t dims[3], nb_r = 0, nb_c = 0;
   plaidhip_gmtmat_dims(mat, dims);
+  int* cp = (int*)R_alloc((size_t)dims[1] + 1, sizeof(int));
+  int* ci = (int*)R_alloc((size_t)(dims[2] > 0 ? dims[2] : 1), sizeof(int));
+  memcpy(cp, plaidhip_gmtmat_p(mat), sizeof(int) * (size_t)(dims[1] + 1));
+  if (dims[2]) memcpy(ci, plaidhip_gmtmat_i(mat), sizeof(int) * (size_t)dims[2]);
+  const char* rn0 = plaidhip_gmtmat_names(mat, 0, &nb_r);
+  char* rn = (char*)R_alloc((size_t)nb_r + 1, 1);
+  memcpy(rn, rn0, (size_t)nb_r);
+  const char* cn0 = plaidhip_gmtmat_names(mat, 1, &nb_c);
+  char* cn = (char*)R_alloc((size_t)nb_c + 1, 1);
+  memcpy(cn, cn0, (size_t)nb_c);
+  plaidhip_gmtmat_destroy(mat);
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
   SEXP p = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t)dims[1] + 1));
   SEXP i = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t)dims[2]));
-  memcpy(INTEGER(p), plaidhip_gmtmat_p(mat), sizeof(int) * (size_t)(dims[1] + 1));
-  if (dims[2]) memcpy(INTEGER(i), plaidhip_gmtmat_i(mat), sizeof(int) * (size_t)dims[2]);
+  memcpy(INTEGER(p), cp, sizeof(int) * (size_t)(dims[1] + 1));
+  if (dims[2]) memcpy(INTEGER(i), ci, sizeof(int) * (size_t)dims[2]);
   SEXP dim = PROTECT(Rf_allocVector(INTSXP, 2));
   INTEGER(dim)[0] = (int)dims[0];
   INTEGER(dim)[1] = (int)dims[1];
-  const char* rn = plaidhip_gmtmat_names(mat, 0, &nb);
-  SEXP rnames = PROTECT(split_lines(rn, nb, dims[0]));
-  const char* cn = plaidhip_gmtmat_names(mat, 1, &nb);
-  SEXP cnames = PROTECT(split_lines(cn, nb, dims[1]));
+  SEXP rnames = PROTECT(split_lines(rn, nb_r, dims[0]));
+  SEXP cnames = PROTECT(split_lines(cn, nb_c, dims[1]));
   SET_VECTOR_ELT(out, 0, p);
   SET_VECTOR_ELT(out, 1, i);
   SET_VECTOR_ELT(out, 2, dim);
   SET_VECTOR_ELT(out, 3, rnames);
   SET_VECTOR_ELT(out, 4, cnames);
-  plaidhip_gmtmat_destroy(mat);
   UNPROTECT(6);
   return out;
 }
@@ -205,11 +265,16 @@ SEXP R_plaidhip_gsva(SEXP X, SEXP Gp, SEXP Gi, SEXP tau, SEXP rowtf) {
 }
 
 static const R_CallMethodDef call_methods[] = {
+    {"R_plaidhip_session", (DL_FUNC)&R_plaidhip_session, 2},
     {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
     {"R_plaidhip_normalize_medians", (DL_FUNC)&R_plaidhip_normalize_medians, 2},
     {"R_plaidhip_colranks_dense", (DL_FUNC)&R_plaidhip_colranks_dense, 3},
     {"R_plaidhip_colranks_csc", (DL_FUNC)&R_plaidhip_colranks_csc, 4},
+    {"R_plaidhip_colranks_csc_dense", (DL_FUNC)&R_plaidhip_colranks_csc_dense, 6},
+    {"R_plaidhip_plaid_multi", (DL_FUNC)&R_plaidhip_plaid_multi, 10},
+    {"R_plaidhip_sing_multi", (DL_FUNC)&R_plaidhip_sing_multi, 4},
+    {"R_plaidhip_ssgsea_multi", (DL_FUNC)&R_plaidhip_ssgsea_multi, 9},
     {"R_plaidhip_sing_dense", (DL_FUNC)&R_plaidhip_sing_dense, 3},
     {"R_plaidhip_ssgsea_dense", (DL_FUNC)&R_plaidhip_ssgsea_dense, 4},
     {"R_plaidhip_ssgsea_csc", (DL_FUNC)&R_plaidhip_ssgsea_csc, 7},
@@ -229,4 +294,5 @@ void R_init_plaidhip(DllInfo* dll) {
 void R_unload_plaidhip(DllInfo* dll) {
   (void)dll;
   if (g_ctx) { plaidhip_finalize(g_ctx); g_ctx = NULL; }
+  plaidhip_multi_finalize();
 }

@@ -299,3 +299,104 @@ def test_c_abi_shard_bounds_match_the_python_side():
                 assert cover == list(range(n))
     with pytest.raises(_lib.PlaidHipError):
         plaid_amd.shard_bounds(5, 0, 0)
+
+
+def _split_top_level(argstr):
+    out, depth, cur, quote = [], 0, "", None
+    for ch in argstr:
+        if quote:
+            cur += ch
+            if ch == quote:
+                quote = None
+            continue
+        if ch in "\"'":
+            quote = ch
+            cur += ch
+        elif ch in "([{":
+            depth += 1
+            cur += ch
+        elif ch in ")]}":
+            depth -= 1
+            cur += ch
+        elif ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _call_sites(text, opener):
+    """argument strings of every `opener(` ... matching `)` in text"""
+    i = 0
+    while True:
+        i = text.find(opener + "(", i)
+        if i < 0:
+            return
+        j = i + len(opener) + 1
+        depth, k, quote = 1, j, None
+        while depth:
+            ch = text[k]
+            if quote:
+                quote = None if ch == quote else quote
+            elif ch in "\"'":
+                quote = ch
+            elif ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            k += 1
+        yield text[j:k - 1]
+        i = k
+
+
+def test_r_shim_is_consistent_without_r():
+    """R is not installed here, so the .Call shim is never compiled: check statically that every .Call in
+    r-pkg/R/plaid-hip.R names a routine registered in r-pkg/src/plaidhip_R.c with that many arguments, that every
+    registered routine is defined with that many SEXP parameters, that every C-ABI function the shim calls is declared
+    in include/plaidhip.h with the number of arguments the shim passes, and that NAMESPACE exports functions that exist"""
+    rsrc = open(os.path.join(ROOT, "r-pkg", "R", "plaid-hip.R")).read()
+    rsrc = "\n".join(line.split("##")[0] if line.lstrip().startswith("##") else line for line in rsrc.splitlines())
+    csrc = open(os.path.join(ROOT, "r-pkg", "src", "plaidhip_R.c")).read()
+    header = open(os.path.join(ROOT, "include", "plaidhip.h")).read()
+    registered = {m.group(1): int(m.group(2))
+                  for m in re.finditer(r'\{"(R_plaidhip_\w+)",\s*\(DL_FUNC\)&\1,\s*(\d+)\}', csrc)}
+    assert len(registered) >= 18
+    defined = {}
+    for m in re.finditer(r"^SEXP (R_plaidhip_\w+)\(([^)]*)\)\s*\{", csrc, re.M | re.S):
+        defined[m.group(1)] = len([a for a in m.group(2).split(",") if a.strip().startswith("SEXP")])
+    assert registered == defined, "registration table and definitions disagree"
+    calls = 0
+    for args in _call_sites(rsrc, ".Call"):
+        parts = _split_top_level(args)
+        name = parts[0].strip("\"")
+        nargs = len([a for a in parts[1:] if not a.startswith("PACKAGE")])
+        assert name in registered, f".Call of an unregistered routine {name}"
+        assert registered[name] == nargs, f".Call({name}) passes {nargs} arguments, {registered[name]} registered"
+        calls += 1
+    assert calls >= 20
+    # C-ABI calls of the shim against the header
+    code = re.sub(r"/\*.*?\*/", "", csrc, flags=re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    proto = {}
+    for m in re.finditer(r"\b(?:int|const char\*|const int32_t\*|int64_t)\s+(plaidhip_\w+)\s*\(([^;]*?)\)\s*;", hdr, re.S):
+        a = m.group(2).strip()
+        proto[m.group(1)] = 0 if a in ("", "void") else len(_split_top_level(a))
+    used = set()
+    for m in re.finditer(r"\b(plaidhip_\w+)\s*\(", code):
+        name = m.group(1)
+        if name in ("plaidhip_ctx", "plaidhip_gmt", "plaidhip_gmtmat"):
+            continue
+        assert name in proto, f"the shim calls {name}, which include/plaidhip.h does not declare"
+        args = next(_call_sites(code[m.start():], name))
+        n = 0 if args.strip() == "" else len(_split_top_level(args))
+        assert n == proto[name], f"{name}: the shim passes {n} arguments, the header declares {proto[name]}"
+        used.add(name)
+    assert {"plaidhip_plaid_dense", "plaidhip_colranks_csc_dense", "plaidhip_plaid_multi", "plaidhip_ssgsea_multi",
+            "plaidhip_set_precision"} <= used
+    ns = open(os.path.join(ROOT, "r-pkg", "NAMESPACE")).read()
+    exported = re.findall(r"[\w.]+", ns.split("export(")[1].split(")")[0])
+    for fn in exported:
+        assert re.search(r"^" + re.escape(fn) + r"\s*<-\s*function", rsrc, re.M), f"NAMESPACE exports {fn}, not defined"
