@@ -550,6 +550,41 @@ def run_c4(a, env):
                                   f"{2.0 * g * n * m:.2e} flop (x3 issues as a bf16 split) against {2.0 * z * n:.2e} for this "
                                   "crossprod: see DESIGN.md (C4 row) for the measured MFMA rate beside this time"},
     }
+    # the same crossprod as the dense contraction config 4 names, on the matrix cores (opt-in backend): timed on a
+    # sample panel, next to the SpMM kernel's time for the same panel
+    try:
+        npan = min(n, 4096)
+        ctx.set_option("spmm_dense_kernel", "mfma")
+        tt = {}
+        for name in ("mfma", "auto"):
+            ctx.set_option("spmm_dense_kernel", name)
+            with torch.cuda.stream(stream):
+                ctx.dev_spmm_dense(gs, R.data_ptr(), g, npan, S.data_ptr(), m, "mean", 1.0, -0.5, None, gmax.data_ptr())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(stream):
+                e0.record(stream)
+                for _ in range(3):
+                    ctx.dev_spmm_dense(gs, R.data_ptr(), g, npan, S.data_ptr(), m, "mean", 1.0, -0.5, None, gmax.data_ptr())
+                e1.record(stream)
+            torch.cuda.synchronize()
+            tt[name] = e0.elapsed_time(e1) / 3
+            if name == "mfma":
+                Sm = S[:64].cpu().numpy().copy()
+        err = float(np.max(np.abs(Sm - S[:64].cpu().numpy())))
+        flop = 3.0 * 2.0 * g * float(npan) * m
+        tf = flop / (tt["mfma"] * 1e-3) / 1e12
+        out["mfma_backend"] = {
+            "kernel": "crossprod_mfma_bf16x3_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "samples": npan, "ms": round(tt["mfma"], 3),
+            "spmm_ms_same_panel": round(tt["auto"], 3), "slowdown_vs_spmm": round(tt["mfma"] / tt["auto"], 2),
+            "flop": flop, "max_abs_diff_vs_spmm": err,
+            "note": "dense 0/1 G (bf16) x bf16x3 split of the rank weights, fp32 accumulate: 3 x 2 g n m flop against "
+                    "2 z n for the SpMM (z/(g m) = 0.7 % dense); includes the split of the panel into three bf16 planes"}
+    except Exception as exc:  # pragma: no cover
+        out["mfma_backend"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+    finally:
+        ctx.set_option("spmm_dense_kernel", "auto")
     if a.cpu_sample > 0:
         from oracle import c_oracle
         nc = min(512, n)

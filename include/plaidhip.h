@@ -85,7 +85,9 @@ int plaidhip_set_stream(plaidhip_ctx* ctx, void* stream);
 /* Kernel-selection knobs of one context (tests and tools use them to pin a path; the defaults choose
  * by shape).  Unknown option or value: PLAIDHIP_EINVAL.                                              */
 enum plaidhip_option {
-  PLAIDHIP_OPT_SPMM_DENSE_KERNEL = 1,  /* 0 auto (default) | 1 one-column kernel | 2 pair kernel wherever it applies */
+  PLAIDHIP_OPT_SPMM_DENSE_KERNEL = 1,  /* 0 auto (default) | 1 one-column kernel | 2 pair kernel wherever it applies |
+                                          3 dense 0/1 G x bf16x3 split of X on MFMA (BASELINE config 4's "GEMM" form:
+                                          ~145x the flops of the SpMM, ~1e-7 relative; measured beside it, never default) */
   PLAIDHIP_OPT_SPMM_SPARSE_KERNEL = 2, /* 0 auto: by nnz(X) (default) | 1 scatter | 2 gather                        */
   PLAIDHIP_OPT_NT_STORE = 3,           /* -1 auto (default) | 0 plain stores of S | 1 streaming stores              */
   PLAIDHIP_OPT_RANKS_F32 = 4,          /* 1 (default): rank inputs take the fp32-staged crossprod (exact) | 0: fp64 */

@@ -17,7 +17,7 @@ TIES = {"average": 0, "min": 1, "max": 2}
 FLAG_HAS_NEG, FLAG_HAS_ZERO, FLAG_HAS_NAN = 1, 2, 4
 # enum plaidhip_option and its values (include/plaidhip.h)
 OPTIONS = {
-    "spmm_dense_kernel": (1, {"auto": 0, "single": 1, "pair": 2}),
+    "spmm_dense_kernel": (1, {"auto": 0, "single": 1, "pair": 2, "mfma": 3}),
     "spmm_sparse_kernel": (2, {"auto": 0, "scatter": 1, "gather": 2}),
     "nt_store": (3, {"auto": -1, "off": 0, "on": 1}),
     "ranks_f32": (4, {"off": 0, "on": 1}),

@@ -228,7 +228,7 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
   PH_CTX(ctx);
   switch (option) {
     case PLAIDHIP_OPT_SPMM_DENSE_KERNEL:
-      PH_REQUIRE(value >= 0 && value <= 2, "set_option: dense kernel %d (0 auto, 1 one-column, 2 pair)", value);
+      PH_REQUIRE(value >= 0 && value <= 3, "set_option: dense kernel %d (0 auto, 1 one-column, 2 pair, 3 mfma)", value);
       ctx->opt_dense_kernel = value;
       break;
     case PLAIDHIP_OPT_SPMM_SPARSE_KERNEL:

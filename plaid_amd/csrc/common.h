@@ -60,7 +60,7 @@ struct plaidhip_ctx {
   std::vector<cached_geneset> gs_cache;
   int precision = 0;   // PLAIDHIP_PRECISION_*: 0 fp64 throughout (default), 1 fp32 operand staging in the dense SpMM
   // plaidhip_set_option (include/plaidhip.h: enum plaidhip_option)
-  int opt_dense_kernel = 0;    // 0 auto | 1 one-column | 2 pair wherever it applies
+  int opt_dense_kernel = 0;    // 0 auto | 1 one-column | 2 pair wherever it applies | 3 dense bf16x3 GEMM on MFMA
   int opt_sparse_kernel = 0;   // 0 auto | 1 scatter | 2 gather
   int opt_nt_store = -1;       // -1 auto | 0 | 1
   int opt_ranks_f32 = 1;       // rank inputs take the fp32-staged crossprod
@@ -156,6 +156,11 @@ struct plaidhip_geneset {
   plaidhip_pair_plan pair;              // dense-X kernel: two columns per pass
   plaidhip_scatter_plan scatter;        // sparse-X kernel: nonzeros are scattered into per-set LDS accumulators
   bool rows_in_order = false;           // the sets came sorted by decreasing size: a tile's lanes are neighbouring rows of S
+  // MFMA backend (opt-in, kernels_mfma.hip): the pattern is kept on the host and the dense bf16 sets x genes matrix
+  // is built on first use
+  std::vector<int32_t> h_Gp, h_Gi;
+  void* d_dense_g = nullptr;
+  int32_t dense_gk = 0;
 };
 
 namespace plaidhip {
@@ -215,6 +220,8 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags,
                           bool x_exact_in_f32 = false);   // X holds (half-)integer ranks: fp32 staging loses nothing
+int launch_spmm_mfma_f64(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n, int stat,
+                         double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,

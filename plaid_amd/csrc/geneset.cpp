@@ -549,6 +549,8 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
   gs->g = g;
   gs->m = m;
   gs->z = z;
+  gs->h_Gp.assign(Gp, Gp + m + 1);
+  gs->h_Gi.assign(Gi, Gi + z);
   gs->tiles = (m + 63) / 64;
 
   int rc = PLAIDHIP_OK;
@@ -753,6 +755,7 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   hipFree(gs->pair.d_meta_j);
   hipFree(gs->pair.d_meta_w);
   hipFree(gs->pair.d_meta_k);
+  hipFree(gs->d_dense_g);
   hipFree(gs->scatter.d_seg);
   hipFree(gs->scatter.d_ids);
   hipFree(gs->scatter.d_w);

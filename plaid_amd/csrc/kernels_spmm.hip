@@ -1395,6 +1395,8 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags, bool x_exact_in_f32) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
+  if (ctx->opt_dense_kernel == 3)   // opt-in: the dense contraction on the matrix cores (kernels_mfma.hip)
+    return launch_spmm_mfma_f64(ctx, const_cast<plaidhip_geneset*>(gs), X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags);
   // fp32 staging: opt-in, or free of any rounding when X holds ranks (integers / half-integers <= 20,448 are
   // exact in fp32, and so are the four-term fp32 partial sums of the kernel: < 2^17 with one fractional bit)
   if (!ctx->opt_ranks_f32) x_exact_in_f32 = false;   // PLAIDHIP_OPT_RANKS_F32 = 0: rank inputs stay on the fp64 kernels (tests compare the two)

@@ -798,3 +798,27 @@ def test_pipelined_host_upload_many_panels(hip_ctx):
     rn = [str(k) for k in range(g)]
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
     close(Ssing[:, cols], _oracle().replaid_sing(X[:, cols], rn, G, rn))
+
+
+# ---------------------------------------------------------------- the dense "GEMM" form of config 4 on the matrix cores
+@pytest.mark.parametrize("g,n,m", [(20000, 200, 700), (5000, 131, 257), (333, 5, 40)])
+def test_mfma_backend_matches_the_spmm_route(pinned_ctx, g, n, m):
+    """opt-in alternate backend (PLAIDHIP_OPT_SPMM_DENSE_KERNEL = mfma): dense 0/1 G (bf16, exact) x the bf16 x 3 split
+    of the rank weights, fp32 accumulation -- within the 1e-5 bar of the fp64 SpMM route and of the oracle, for plaid(),
+    replaid.ssgsea(alpha = 0.25) (the config-4 pipeline) and the sum statistic; tile edges in both dimensions"""
+    from plaid_amd import synth as sy
+    Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(g, 400), sort_by_size=False)
+    X = sy.dense_columns(g, 0, n)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    ref = {"plaid": pinned_ctx().plaid_dense(X, Gp, Gi, "mean", False),
+           "sum": pinned_ctx().plaid_dense(X, Gp, Gi, "sum", True),
+           "ssgsea": pinned_ctx().ssgsea_dense(X, Gp, Gi, 0.25)}
+    ctx = pinned_ctx(spmm_dense_kernel="mfma")
+    got = {"plaid": ctx.plaid_dense(X, Gp, Gi, "mean", False), "sum": ctx.plaid_dense(X, Gp, Gi, "sum", True),
+           "ssgsea": ctx.ssgsea_dense(X, Gp, Gi, 0.25)}
+    np.testing.assert_allclose(got["plaid"], ref["plaid"], rtol=1e-5, atol=0)
+    assert 0 < np.max(np.abs(got["plaid"] - ref["plaid"]) / np.abs(ref["plaid"])) < 3e-6      # really the bf16 x 3 / fp32 path
+    np.testing.assert_allclose(got["sum"], ref["sum"], rtol=1e-5, atol=1e-3)                    # sums ~ 1e3, medians removed
+    np.testing.assert_allclose(got["ssgsea"], ref["ssgsea"], rtol=1e-5, atol=1e-6)              # centred scores
+    np.testing.assert_allclose(got["ssgsea"], _oracle().replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-5, atol=1e-6)
