@@ -785,6 +785,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #define PLAIDHIP_WALK_SEGMENTS()                                                                       \
   {                                                                                                    \
     stg[lane] = StageEnt{ns > 0 ? s0 : a.dummy_seg, ns, v};                                            \
+    PLAIDHIP_AFTER_STAGE()                                                                             \
     const uint32_t loff = (uint32_t)lane * 4u;                                                         \
     const unsigned char* idb = reinterpret_cast<const unsigned char*>(idw);                            \
     /* 48 id loads in flight per wavefront (three groups of 16 ahead of the group being applied): the loop was     \
@@ -846,9 +847,13 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   }
 
   // Columns of at most 1,024 stored values (one value per thread: the usual single-cell column) run a pipelined
-  // schedule: a thread keeps its (gene, value) for all chunks, the segment range of the next chunk is loaded while
-  // the current one is applied, and the next column's (gene, value) arrive during the last chunk.  Longer columns
-  // take the plain loop below.
+  // schedule: a thread keeps its (gene, value) for all chunks; the segment range of the next chunk (and, during the
+  // last chunk, the next column's gene / value and then its first segment range) is loaded while the current chunk is
+  // applied.  The loads are branch-free (clamped index instead of an exec-masked branch) and their results are pinned
+  // by an empty asm at the END of the walk: left to itself hipcc put an s_waitcnt vmcnt(0) in front of the next chunk
+  // -- a full L2 round trip for the loads just issued plus the acknowledgement of the chunk's S stores, 24 % of the
+  // kernel by in-kernel stamps.  Longer columns take the plain loop below.
+#define PLAIDHIP_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
 #ifdef PLAIDHIP_DIAG
   unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -856,40 +861,54 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   int c = blockIdx.x;
   int q0n = 0, q1n = 0;
   if (c < a.n) { q0n = a.Xp[c]; q1n = a.Xp[c + 1]; }
-  int gene_n = 0;
+  int gene_n = 0, s0n = 0, s1n = 0;
   double v_n = 0.0;
   bool have_n = false;
-  if (c < a.n && q1n - q0n <= 1024) {
+  if (c < a.n && q1n - q0n <= 1024 && q1n > q0n) {
     have_n = q0n + tid < q1n;
-    gene_n = have_n ? a.Xi[q0n + tid] : 0;
-    v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+    const int qi = have_n ? q0n + tid : q0n;
+    gene_n = a.Xi[qi];
+    v_n = have_n ? a.Xx[qi] : 0.0;
+    s0n = a.seg[gene_n];
+    s1n = have_n ? a.seg[gene_n + 1] : s0n;
   }
   for (; c < a.n; c += gridDim.x) {
     const int q0 = q0n, q1 = q1n;
     const int cn = c + gridDim.x;
     if (cn < a.n) { q0n = a.Xp[cn]; q1n = a.Xp[cn + 1]; }
     if (q1 - q0 <= 1024) {
-      const bool have = have_n;
-      const int gene = gene_n;
-      const double v = v_n;
-      int s0n = have ? a.seg[gene] : 0;
-      int s1n = have ? a.seg[gene + 1] : 0;
+      const bool have = have_n && q1 > q0;
+      const int gene = (q1 > q0) ? gene_n : 0;
+      const double v = have ? v_n : 0.0;
+      const bool next_fast = cn < a.n && q1n - q0n <= 1024 && q1n > q0n;
       for (int chunk = 0; chunk < a.nch; ++chunk) {
         const int j0 = chunk * a.ch;
         const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
         const int s0 = s0n;
-        const int ns = s1n - s0n;
-        if (chunk + 1 < a.nch) {                       // next chunk's segment range of the same genes
-          const int32_t* segn = a.seg + (int64_t)(chunk + 1) * a.g;
-          s0n = have ? segn[gene] : 0;
-          s1n = have ? segn[gene + 1] : 0;
-        } else if (cn < a.n && q1n - q0n <= 1024) {    // last chunk: the next column's stored values
-          have_n = q0n + tid < q1n;
-          gene_n = have_n ? a.Xi[q0n + tid] : 0;
-          v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+        const int ns = have ? s1n - s0n : 0;
+        const bool last = chunk + 1 == a.nch;
+        // (issued right after this chunk's segment range has been staged: hipcc waits with vmcnt(0) in front of
+        // the first use of s0 / ns, which must not include these loads)
+#define PLAIDHIP_AFTER_STAGE()                                                                         \
+        if (!last) {                                  /* next chunk's segment range of the same genes */ \
+          const int32_t* segn = a.seg + (int64_t)(chunk + 1) * a.g;                                    \
+          s0n = segn[gene];                                                                            \
+          s1n = segn[gene + 1];                                                                        \
+        } else if (next_fast) {                       /* last chunk: the next column's stored values */ \
+          have_n = q0n + tid < q1n;                                                                    \
+          const int qi = have_n ? q0n + tid : q0n;                                                     \
+          gene_n = a.Xi[qi];                                                                           \
+          v_n = a.Xx[qi];                                                                              \
         }
         PH_SC_STAMP(0);
         PLAIDHIP_WALK_SEGMENTS()
+#undef PLAIDHIP_AFTER_STAGE
+        if (!last) {
+          PLAIDHIP_PIN2(s0n, s1n);
+        } else if (next_fast) {                       // ... and its first segment range, on its way during the epilogue
+          s0n = a.seg[gene_n];
+          s1n = a.seg[gene_n + 1];
+        }
         PH_SC_STAMP(1);
         __syncthreads();
         PH_SC_STAMP(2);
@@ -898,6 +917,8 @@ spmm_scatter_csc_f64(ScatterArgs a) {
         __syncthreads();
         PH_SC_STAMP(4);
       }
+      if (next_fast) PLAIDHIP_PIN2(s0n, s1n);
+      else have_n = false;
       continue;
     }
     for (int chunk = 0; chunk < a.nch; ++chunk) {
@@ -911,18 +932,25 @@ spmm_scatter_csc_f64(ScatterArgs a) {
         const double v = have ? a.Xx[my] : 0.0;
         const int s0 = have ? segc[gene] : 0;
         const int ns = have ? segc[gene + 1] - s0 : 0;
+#define PLAIDHIP_AFTER_STAGE()
         PLAIDHIP_WALK_SEGMENTS()
+#undef PLAIDHIP_AFTER_STAGE
       }
       __syncthreads();
       PLAIDHIP_CHUNK_EPILOGUE()
       __syncthreads();
     }
-    if (cn < a.n && q1n - q0n <= 1024) {               // back to the pipelined schedule
+    have_n = false;
+    if (cn < a.n && q1n - q0n <= 1024 && q1n > q0n) {   // back to the pipelined schedule
       have_n = q0n + tid < q1n;
-      gene_n = have_n ? a.Xi[q0n + tid] : 0;
-      v_n = have_n ? a.Xx[q0n + tid] : 0.0;
+      const int qi = have_n ? q0n + tid : q0n;
+      gene_n = a.Xi[qi];
+      v_n = a.Xx[qi];
+      s0n = a.seg[gene_n];
+      s1n = a.seg[gene_n + 1];
     }
   }
+#undef PLAIDHIP_PIN2
 #ifdef PLAIDHIP_DIAG
   if (a.dbg != nullptr && (tid & 63) == 0)
     for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * 16 + wave) * 8 + k] = t_ph[k];
