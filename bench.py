@@ -59,10 +59,15 @@ def parse():
     return ap.parse_args()
 
 
-def _traffic(kernel, shape):
+def _traffic(kernel, shape, columns=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json): per launch for the headline shape,
+    per column x the columns of this launch for the kernels measured on a smaller panel of the same shape"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(path)).get(f"{kernel}/{shape}", {}).get("hbm_bytes_per_launch")
+        e = json.load(open(path)).get(f"{kernel}/{shape}", {})
+        if columns is not None and "hbm_bytes_per_column" in e:
+            return int(e["hbm_bytes_per_column"] * columns)
+        return e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -440,11 +445,13 @@ def run_sparse_ssgsea(a, env, n, label, collective):
         "rank_keys_per_s": round(nnz / (rank_ms * 1e-3), 1),
         "geneset_plan_s": round(t_plan, 2),
         "kernels": {
-            "sparse_colranks": _roof("colranks_bucket_kernel<256,8>" if max_nnz <= 2048 else "colranks_bucket_kernel", 16.0 * nnz, rank_ms),
+            "sparse_colranks": _roof("colranks_bucket_kernel<256,8>" if max_nnz <= 2048 else "colranks_bucket_kernel", 16.0 * nnz, rank_ms,
+                                     _traffic("colranks_bucket_kernel<256,8>", "csc", n) if max_nnz <= 2048 else None),
             "crossprod": _roof("spmm_scatter_csc_f64" if scatter else "spmm_colpair_f64<csc>", spmm_alg, spmm_ms,
+                               _traffic("spmm_scatter_csc_f64", f"{g}xNx{m}", n) if scatter else None,
                                extra={"lds_atomic_adds_per_s": round(nnz * (z / g) / (spmm_ms * 1e-3), 1)} if scatter else None),
-            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms),
-            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),
+            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
     }
     if not collective and rank == 0 and a.cpu_sample > 0:
@@ -541,10 +548,12 @@ def run_c4(a, env):
                       "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
         "rank_keys_per_s": round(float(g) * n / (rank_ms * 1e-3), 1),
         "kernels": {
-            "colranks": _roof("colranks_bucket_kernel<512,40>", 16.0 * g * n, rank_ms),
-            "crossprod": _roof("spmm_colpair_f64", spmm_alg, spmm_ms, lds_bytes=float(info["padded_slots"]) * 8.0 * n),
-            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms),
-            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+            "colranks": _roof("colranks_bucket_kernel<512,40>", 16.0 * g * n, rank_ms,
+                              _traffic("colranks_bucket_kernel<512,40>", f"{g}xN", n)),
+            "crossprod": _roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
+                               lds_bytes=float(info["padded_slots"]) * 8.0 * n),
+            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),
+            "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
         "dense_gemm_equivalent": {"flop": 2.0 * g * n * m, "note": "the dense contraction config 4 names would be "
                                   f"{2.0 * g * n * m:.2e} flop (x3 issues as a bf16 split) against {2.0 * z * n:.2e} for this "
