@@ -37,6 +37,12 @@ static unsigned long long* g_dbg = nullptr;
 static constexpr int g_ablate = 0;
 #endif
 
+// Plan arrays are read-only for the lifetime of a launch: wave-uniform reads of them go through the
+// constant address space, i.e. the scalar cache (s_load), not through a vector load + readfirstlane,
+// whose result would have to be awaited with a vmcnt that drains the index ring.
+typedef __attribute__((address_space(4))) const int32_t* cptr_i32;
+typedef __attribute__((address_space(4))) const plaidhip_pair_slice_dev* cptr_pair_slice;
+
 struct SpmmArgs {
   const double* X;
   int64_t ldx;
@@ -127,9 +133,9 @@ spmm_colgather_f64(SpmmArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
 
-  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
-  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
-  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+  const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
+  const int ch_end = ((cptr_i32)a.wave_chunk_off)[wave + 1];
+  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
 
   const int g2 = a.g >> 1;
   const uint32_t lane_off16 = (uint32_t)tid * 16u;
@@ -227,7 +233,7 @@ spmm_colgather_f64(SpmmArgs a) {
       }                                                                                        \
     }                                                                                          \
     ++k;                                                                                       \
-    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
+    next_end = ((cptr_i32)a.wtile_end)[k];                                 \
     /* metadata of the next tile: issued now, consumed a whole tile later */                   \
     mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
     mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
@@ -243,7 +249,7 @@ spmm_colgather_f64(SpmmArgs a) {
       uint4 qc = PLAIDHIP_LOADQ(2);
       uint4 qd = PLAIDHIP_LOADQ(3);
       int k = tk_begin;
-      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
+      int next_end = ((cptr_i32)a.wtile_end)[k];
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       const uint32_t moff4 = (uint32_t)lane * 4u, moff8 = (uint32_t)lane * 8u;
       int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
@@ -418,7 +424,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
-  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
   const int ns = a.nslices;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
   f64x2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;   // next slice: p0..p4 column A, p5..p9 column B
@@ -436,8 +442,8 @@ spmm_colpair_f64(SpmmPairArgs a) {
   do {                                                                                              \
     uint32_t lane_off16 = (uint32_t)tid * 16u;                                                      \
     asm volatile("" : "+v"(lane_off16)); /* keep address math out of the enclosing loops */         \
-    const int g0_ = a.slices[si_].g0;                                                               \
-    const int g2_ = a.slices[si_].gs >> 1;                                                          \
+    const int g0_ = ((cptr_pair_slice)a.slices)[si_].g0;                                            \
+    const int g2_ = ((cptr_pair_slice)a.slices)[si_].gs >> 1;                                                       \
     const int ca_ = 2 * (pp_);                                                                      \
     const int cb_ = (ca_ + 1 < a.n) ? ca_ + 1 : ca_;                                                \
     const char* xa_ = reinterpret_cast<const char*>(a.X + (int64_t)ca_ * a.ldx + g0_);              \
@@ -465,8 +471,8 @@ spmm_colpair_f64(SpmmPairArgs a) {
     const bool hasB = cA + 1 < a.n;
     const int cB = hasB ? cA + 1 : cA;
     for (int si = 0; si < ns; ++si) {
-      const plaidhip_pair_slice_dev* sl = a.slices + si;
-      const int gs_ = __builtin_amdgcn_readfirstlane(sl->gs);
+      const cptr_pair_slice sl = (cptr_pair_slice)(a.slices + si);
+      const int gs_ = sl->gs;
       const int g2 = gs_ >> 1;
       unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
       if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
@@ -508,13 +514,13 @@ spmm_colpair_f64(SpmmPairArgs a) {
       if (nsi == ns) { nsi = 0; np = p + gridDim.x; }
       const bool want_pf = !CSC_X && np < a.npairs;
       const bool first = si == 0, last = si == ns - 1;
-      const gptr_i32 wco = (gptr_i32)sl->wave_chunk_off;
-      const int ch_begin = __builtin_amdgcn_readfirstlane(wco[wave]);
-      const int ch_end = __builtin_amdgcn_readfirstlane(wco[wave + 1]);
+      const cptr_i32 wco = (cptr_i32)sl->wave_chunk_off;
+      const int ch_begin = wco[wave];
+      const int ch_end = wco[wave + 1];
 
       if (ch_begin < ch_end) {
         // pointers read from memory are generic to the compiler: say "global" or it emits flat loads
-        const gptr_i32 wtile_end = (gptr_i32)sl->wtile_end;
+        const cptr_i32 wtile_end = (cptr_i32)sl->wtile_end;
         gptr_u8 ibase = (gptr_u8)sl->tile_idx + (int64_t)ch_begin * 1024;  // uniform
         const gptr_u8 ibase0 = ibase;
         uint32_t lane_o = (uint32_t)lane;
@@ -555,7 +561,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
       if (hasB) PLAIDHIP_EPI(sumB, cB)                                                         \
     }                                                                                          \
     ++k;                                                                                       \
-    next_end = __builtin_amdgcn_readfirstlane(wtile_end[k]);                                   \
+    next_end = wtile_end[k];                                   \
     if (last && ABL != 7) {                                                                    \
       mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
       mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
@@ -574,7 +580,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
         u32x4 qg = PLAIDHIP_LOADQ(6);
         u32x4 qh = PLAIDHIP_LOADQ(7);
         int k = tk_begin;
-        int next_end = __builtin_amdgcn_readfirstlane(wtile_end[k]);
+        int next_end = wtile_end[k];
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         const uint32_t moff4 = lane_o * 4u, moff8 = lane_o * 8u;
         int mj = -1;
@@ -1046,9 +1052,9 @@ spmm_colpair_mixed(SpmmArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
-  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
-  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
+  const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
+  const int ch_end = ((cptr_i32)a.wave_chunk_off)[wave + 1];
+  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
   const int g2 = a.g >> 1;
   const int npairs = (a.n + 1) >> 1;
   // next pair, as loaded: 10 x 16 bytes of column A and of column B per thread
@@ -1143,7 +1149,7 @@ spmm_colpair_mixed(SpmmArgs a) {
       if (hasB) PLAIDHIP_EPI(dB0 + dB1, cB)                                                    \
     }                                                                                          \
     ++k;                                                                                       \
-    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
+    next_end = ((cptr_i32)a.wtile_end)[k];                                 \
     mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
     mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
     mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
@@ -1154,7 +1160,7 @@ spmm_colpair_mixed(SpmmArgs a) {
       uint4 qc = PLAIDHIP_LOADQ(2);
       uint4 qd = PLAIDHIP_LOADQ(3);
       int k = tk_begin;
-      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
+      int next_end = ((cptr_i32)a.wtile_end)[k];
       double dA0 = 0.0, dA1 = 0.0, dB0 = 0.0, dB1 = 0.0;
       int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
       double mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);
