@@ -144,6 +144,7 @@ struct plaidhip_scatter_plan {
   uint16_t* d_ids = nullptr;
   double* d_w = nullptr;   // per set 1/(1e-8 + size)
   double* d_k = nullptr;   // per set size
+  double* d_kw = nullptr;  // {size, 1/(1e-8 + size)} interleaved: one 16-byte load per set in the scatter kernel's epilogue
 };
 
 struct plaidhip_geneset {

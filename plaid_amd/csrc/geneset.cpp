@@ -731,6 +731,11 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     if ((rc = upload(ctx, ids, &sp.d_ids)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, w, &sp.d_w)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, k, &sp.d_k)) != PLAIDHIP_OK) goto fail;
+    {
+      std::vector<double> kw((size_t)2 * m);
+      for (int32_t j = 0; j < m; ++j) { kw[2 * (size_t)j] = k[j]; kw[2 * (size_t)j + 1] = w[j]; }
+      if ((rc = upload(ctx, kw, &sp.d_kw)) != PLAIDHIP_OK) goto fail;
+    }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
   *out = gs;
@@ -760,6 +765,7 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   hipFree(gs->scatter.d_ids);
   hipFree(gs->scatter.d_w);
   hipFree(gs->scatter.d_k);
+  hipFree(gs->scatter.d_kw);
   hipFree(gs->pair.d_slices);
   hipFree(gs->pair.d_partial);
   for (plaidhip_pair_slice& d : gs->pair.slices) {
