@@ -716,7 +716,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
 spmm_scatter_csc_f64(ScatterArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* acc = reinterpret_cast<double*>(smem_raw);
@@ -844,6 +844,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   }
 #define PLAIDHIP_CHUNK_EPILOGUE()                                                                  \
   {                                                                                                 \
+    /* all factors are awaited before the first store: one whose use is skipped (i >= nj) would stay "pending" in */ \
+    /* hipcc's bookkeeping, and the next write to its register would wait with vmcnt(0) -- for the stores' acks */   \
+    _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) asm volatile("" : "+v"(kwv[u]));          \
     int tid_e = tid;                                                                                \
     asm volatile("" : "+v"(tid_e));                                                                 \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
@@ -861,113 +864,140 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     }                                                                                               \
   }
 
-  // Columns of at most 1,024 stored values (one value per thread: the usual single-cell column) run a pipelined
-  // schedule: a thread keeps its (gene, value) for all chunks; the segment range of the next chunk (and, during the
-  // last chunk, the next column's gene / value and then its first segment range) is loaded while the current chunk is
-  // applied.  The loads are branch-free (clamped index instead of an exec-masked branch) and their results are pinned
-  // by an empty asm at the END of the walk: left to itself hipcc put an s_waitcnt vmcnt(0) in front of the next chunk
-  // -- a full L2 round trip for the loads just issued plus the acknowledgement of the chunk's S stores, 24 % of the
-  // kernel by in-kernel stamps.  Longer columns take the plain loop below.
-#define PLAIDHIP_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+  // The work of a workgroup is a sequence of ITEMS (column, chunk of sets, round): round r of a column is its stored
+  // values [1024 r, 1024 (r + 1)), one per thread; all rounds of a (column, chunk) add into the same accumulators, then
+  // the chunk's epilogue runs.  What an item needs from memory -- the thread's (gene, value) and the segment range of
+  // that gene in the item's chunk, the second depending on the first -- is requested TWO and ONE items ahead, while an
+  // earlier item is being applied, across chunk and column boundaries alike; any number of stored values per column
+  // runs the same pipeline.  (Round 2 of the build had a pipelined path for columns of <= 1,024 values and a plain
+  // loop for longer ones: with ~1,000 +- 30 values per cell a fifth of the columns took the plain loop and a quarter
+  // of the kernel's time.)
+  // These prefetches are issued through inline asm into v120..v125 -- registers outside the compiler's range
+  // (amdgpu_num_vgpr on the kernel) -- and fetched with plain moves behind a wait placed by hand at the end of the
+  // walk, where every load has been consumed anyway.  As ordinary loads they cost stalls in every item: hipcc copied
+  // loop-carried results right behind the load instruction (a full L2 round trip before the walk had started), and
+  // at the top of the next item it waited with vmcnt(0) -- it cannot count the conditional S stores issued since --
+  // i.e. for the acknowledgement of a whole chunk's stores.
+#define PLAIDHIP_ASM_LOAD_SEG(ptr_)   /* {seg[gene], seg[gene + 1]} -> v[120:121] */                    \
+  asm volatile("global_load_dwordx2 v[120:121], %0, off" : : "v"(ptr_) : "memory", "v120", "v121")
+#define PLAIDHIP_ASM_LOAD_CELL(pi_, px_)   /* Xi[q] -> v122, Xx[q] -> v[124:125] */                     \
+  asm volatile("global_load_dword v122, %0, off\n\tglobal_load_dwordx2 v[124:125], %1, off"            \
+               : : "v"(pi_), "v"(px_) : "memory", "v122", "v124", "v125")
+#define PLAIDHIP_ASM_TAKE(s0_, s1_, g_, xlo_, xhi_)                                                     \
+  asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v122\n\t" \
+               "v_mov_b32 %3, v124\n\tv_mov_b32 %4, v125"                                               \
+               : "=v"(s0_), "=v"(s1_), "=v"(g_), "=v"(xlo_), "=v"(xhi_) : : "memory")
+// item iterator (wave-uniform): next round of the column, else next chunk, else next column of this workgroup.
+// A column of nnz stored values takes nr = ceil(nnz / 1024) rounds of per = ceil(nnz / nr) values (balanced rounds:
+// 1,100 values are 2 x 550, not 1,024 + 76); inside a round the values are dealt to the wavefronts in groups of 16
+// (group i of the round goes to wavefront i mod 16), so every wavefront applies the same number of groups +- 1.
+#define PLAIDHIP_ITEM_ROUNDS(q0_, q1_) (((q1_) - (q0_) + 1023) >> 10 > 1 ? ((q1_) - (q0_) + 1023) >> 10 : 1)
+#define PLAIDHIP_ITEM_NEXT(c_, ch_, r_, q0_, q1_)                                                       \
+  if (c_ < a.n) {                                                                                       \
+    if (r_ + 1 < PLAIDHIP_ITEM_ROUNDS(q0_, q1_)) {                                                      \
+      ++r_;                                                                                             \
+    } else {                                                                                            \
+      r_ = 0;                                                                                           \
+      if (ch_ + 1 < a.nch) {                                                                            \
+        ++ch_;                                                                                          \
+      } else {                                                                                          \
+        ch_ = 0;                                                                                        \
+        c_ += gridDim.x;                                                                                \
+        if (c_ < a.n) { q0_ = ((cptr_i32)a.Xp)[c_]; q1_ = ((cptr_i32)a.Xp)[c_ + 1]; }                   \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+// the thread's stored value in round r_ of column [q0_, q1_): index (clamped into the column) and whether it exists
+#define PLAIDHIP_ITEM_MINE(r_, q0_, q1_, qi_, have_)                                                    \
+  {                                                                                                     \
+    const int nnz_ = (q1_) - (q0_);                                                                     \
+    const int nr_ = PLAIDHIP_ITEM_ROUNDS(q0_, q1_);                                                     \
+    const int per_ = nr_ == 1 ? nnz_ : (nnz_ + nr_ - 1) / nr_;                                          \
+    const int lo_ = (r_) * per_;                                                                        \
+    const int cnt_ = nnz_ - lo_ < per_ ? nnz_ - lo_ : per_;                                             \
+    const int i_ = ((((lane >> 4) << 4) + wave) << 4) + (lane & 15);                                    \
+    have_ = i_ < cnt_;                                                                                  \
+    qi_ = (q0_) + (have_ ? lo_ + i_ : 0);                                                               \
+  }
 #ifdef PLAIDHIP_DIAG
   unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
-  int c = blockIdx.x;
-  int q0n = 0, q1n = 0;
-  if (c < a.n) { q0n = a.Xp[c]; q1n = a.Xp[c + 1]; }
-  int gene_n = 0, s0n = 0, s1n = 0;
-  double v_n = 0.0;
-  bool have_n = false;
-  if (c < a.n && q1n - q0n <= 1024 && q1n > q0n) {
-    have_n = q0n + tid < q1n;
-    const int qi = have_n ? q0n + tid : q0n;
-    gene_n = a.Xi[qi];
-    v_n = have_n ? a.Xx[qi] : 0.0;
-    s0n = a.seg[gene_n];
-    s1n = have_n ? a.seg[gene_n + 1] : s0n;
+  // current item, the next one (n1: gene / value here, segment range on its way during the current walk) and the one
+  // after (n2: gene / value on their way)
+  int c = blockIdx.x, chunk = 0, rr = 0, q0 = 0, q1 = 0;
+  if (c < a.n) { q0 = ((cptr_i32)a.Xp)[c]; q1 = ((cptr_i32)a.Xp)[c + 1]; }
+  int c1 = c, chunk1 = chunk, r1 = rr, q01 = q0, q11 = q1;
+  PLAIDHIP_ITEM_NEXT(c1, chunk1, r1, q01, q11)
+  int c2 = c1, chunk2 = chunk1, r2 = r1, q02 = q01, q12 = q11;
+  PLAIDHIP_ITEM_NEXT(c2, chunk2, r2, q02, q12)
+  int gene = 0, s0 = 0, s1 = 0, gene1 = 0;
+  double v = 0.0, v1 = 0.0;
+  if (c < a.n && q1 > q0) {
+    int qi; bool hv;
+    PLAIDHIP_ITEM_MINE(rr, q0, q1, qi, hv)
+    gene = a.Xi[qi];
+    v = a.Xx[qi];
+    s0 = a.seg[gene];
+    s1 = a.seg[gene + 1];
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(gene), "+v"(v));   // (awaited here, once)
   }
-  for (; c < a.n; c += gridDim.x) {
-    const int q0 = q0n, q1 = q1n;
-    const int cn = c + gridDim.x;
-    if (cn < a.n) { q0n = a.Xp[cn]; q1n = a.Xp[cn + 1]; }
-    if (q1 - q0 <= 1024) {
-      const bool have = have_n && q1 > q0;
-      const int gene = (q1 > q0) ? gene_n : 0;
-      const double v = have ? v_n : 0.0;
-      const bool next_fast = cn < a.n && q1n - q0n <= 1024 && q1n > q0n;
-      for (int chunk = 0; chunk < a.nch; ++chunk) {
-        const int j0 = chunk * a.ch;
-        const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
-        const int s0 = s0n;
-        const int ns = have ? s1n - s0n : 0;
-        const bool last = chunk + 1 == a.nch;
-        // (issued right after this chunk's segment range has been staged: hipcc waits with vmcnt(0) in front of
-        // the first use of s0 / ns, which must not include these loads)
-#define PLAIDHIP_AFTER_STAGE()                                                                         \
-        if (!last) {                                  /* next chunk's segment range of the same genes */ \
-          const int32_t* segn = a.seg + (int64_t)(chunk + 1) * a.g;                                    \
-          s0n = segn[gene];                                                                            \
-          s1n = segn[gene + 1];                                                                        \
-        } else if (next_fast) {                       /* last chunk: the next column's stored values */ \
-          have_n = q0n + tid < q1n;                                                                    \
-          const int qi = have_n ? q0n + tid : q0n;                                                     \
-          gene_n = a.Xi[qi];                                                                           \
-          v_n = a.Xx[qi];                                                                              \
-        }
-        PH_SC_STAMP(0);
-        PLAIDHIP_WALK_SEGMENTS()
-#undef PLAIDHIP_AFTER_STAGE
-        if (!last) {
-          PLAIDHIP_PIN2(s0n, s1n);
-        } else if (next_fast) {                       // ... and its first segment range, on its way during the epilogue
-          s0n = a.seg[gene_n];
-          s1n = a.seg[gene_n + 1];
-        }
-        PLAIDHIP_EPI_PREFETCH()
-        PH_SC_STAMP(1);
-        __syncthreads();
-        PH_SC_STAMP(2);
-        PLAIDHIP_CHUNK_EPILOGUE()
-        PH_SC_STAMP(3);
-        __syncthreads();
-        PH_SC_STAMP(4);
-      }
-      if (next_fast) PLAIDHIP_PIN2(s0n, s1n);
-      else have_n = false;
-      continue;
+  if (c1 < a.n && q11 > q01) {
+    int qi; bool hv;
+    PLAIDHIP_ITEM_MINE(r1, q01, q11, qi, hv)
+    gene1 = a.Xi[qi];
+    v1 = a.Xx[qi];
+    asm volatile("" : "+v"(gene1), "+v"(v1));
+  }
+  while (c < a.n) {
+    bool have; int qi_cur;
+    PLAIDHIP_ITEM_MINE(rr, q0, q1, qi_cur, have)
+    const int ns = have ? s1 - s0 : 0;
+    if (!have) v = 0.0;
+    const bool n1_loads = c1 < a.n, n2_loads = c2 < a.n && q12 > q02;
+    // requests for the items behind this one (before the walk's own loads: vmcnt retires in order)
+    if (n1_loads) PLAIDHIP_ASM_LOAD_SEG(a.seg + (int64_t)chunk1 * a.g + gene1);
+    if (n2_loads) {
+      int qi; bool hv;
+      PLAIDHIP_ITEM_MINE(r2, q02, q12, qi, hv)
+      PLAIDHIP_ASM_LOAD_CELL(a.Xi + qi, a.Xx + qi);
     }
-    for (int chunk = 0; chunk < a.nch; ++chunk) {
+#define PLAIDHIP_AFTER_STAGE()
+    PH_SC_STAMP(0);
+    if (__ballot(have) != 0ull) {   // (a wavefront without a value in this round has nothing to apply)
+      PLAIDHIP_WALK_SEGMENTS()
+    }
+#undef PLAIDHIP_AFTER_STAGE
+    int s0_1, s1_1, gene2, xlo, xhi;
+    PLAIDHIP_ASM_TAKE(s0_1, s1_1, gene2, xlo, xhi);   // (the walk has consumed every load of its own: nothing else to wait for)
+    PH_SC_STAMP(1);
+    if (rr + 1 >= PLAIDHIP_ITEM_ROUNDS(q0, q1)) {   // last round of this (column, chunk): scale and write the chunk's scores
       const int j0 = chunk * a.ch;
       const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
-      const int32_t* segc = a.seg + (int64_t)chunk * a.g;
-      for (int qb = q0 + wave * 64; qb < q1; qb += 16 * 64) {
-        const int my = qb + lane;
-        const bool have = my < q1;
-        const int gene = have ? a.Xi[my] : 0;
-        const double v = have ? a.Xx[my] : 0.0;
-        const int s0 = have ? segc[gene] : 0;
-        const int ns = have ? segc[gene + 1] - s0 : 0;
-#define PLAIDHIP_AFTER_STAGE()
-        PLAIDHIP_WALK_SEGMENTS()
-#undef PLAIDHIP_AFTER_STAGE
-      }
       PLAIDHIP_EPI_PREFETCH()
       __syncthreads();
+      PH_SC_STAMP(2);
       PLAIDHIP_CHUNK_EPILOGUE()
+      PH_SC_STAMP(3);
       __syncthreads();
+      PH_SC_STAMP(4);
     }
-    have_n = false;
-    if (cn < a.n && q1n - q0n <= 1024 && q1n > q0n) {   // back to the pipelined schedule
-      have_n = q0n + tid < q1n;
-      const int qi = have_n ? q0n + tid : q0n;
-      gene_n = a.Xi[qi];
-      v_n = a.Xx[qi];
-      s0n = a.seg[gene_n];
-      s1n = a.seg[gene_n + 1];
-    }
+    // (otherwise the next round stages into the same per-wave slots: the LDS operations of a wavefront are in order
+    // and only the wavefront itself reads its slots)
+    // rotate the pipeline
+    c = c1; chunk = chunk1; rr = r1; q0 = q01; q1 = q11;
+    gene = gene1; v = v1; s0 = n1_loads ? s0_1 : 0; s1 = n1_loads ? s1_1 : 0;
+    c1 = c2; chunk1 = chunk2; r1 = r2; q01 = q02; q11 = q12;
+    gene1 = n2_loads ? gene2 : 0;
+    v1 = n2_loads ? __hiloint2double(xhi, xlo) : 0.0;
+    PLAIDHIP_ITEM_NEXT(c2, chunk2, r2, q02, q12)
   }
-#undef PLAIDHIP_PIN2
+#undef PLAIDHIP_ITEM_NEXT
+#undef PLAIDHIP_ITEM_MINE
+#undef PLAIDHIP_ITEM_ROUNDS
+#undef PLAIDHIP_ASM_TAKE
+#undef PLAIDHIP_ASM_LOAD_SEG
+#undef PLAIDHIP_ASM_LOAD_CELL
 #ifdef PLAIDHIP_DIAG
   if (a.dbg != nullptr && (tid & 63) == 0)
     for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * 16 + wave) * 8 + k] = t_ph[k];

@@ -101,6 +101,8 @@ def main():
                 print("  scatter stamps (cycles per launch, mean over workgroups x waves): " +
                       "  ".join(f"{nm} {d[:, :, k].mean():.0f} ({100 * d[:, :, k].mean() / tot:.0f}%)" for k, nm in enumerate(names)))
                 print("  walk cycles by wave, WG 0:", d[0, :, 1].astype(int).tolist())
+                for k, nm in enumerate(names):
+                    print(f"  {nm} by wave, WG 5:", d[5, :, k].astype(int).tolist())
             print(f"{a.kernel} ({g}x{n}x{m}): rank {e0.elapsed_time(e1):.3f} ms  spmm {e1.elapsed_time(e2):.3f} ms  "
                   f"normalize {e2.elapsed_time(e3):.3f} ms  total {e0.elapsed_time(e3):.3f} ms -> "
                   f"{m*n/e0.elapsed_time(e3)/1e-3:.3e} scores/s")
