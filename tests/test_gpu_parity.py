@@ -646,6 +646,34 @@ def test_c3_shape_ssgsea_csc_50k_sets(pinned_ctx, g50k, mode):
     close(ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
 
 
+@pytest.mark.parametrize("sets", [700, 24000])
+def test_scatter_kernel_any_number_of_stored_values_per_column(pinned_ctx, sets):
+    """the scatter kernel's item pipeline (column, chunk, round): columns of 0 ... 6,000 stored values next to each
+    other -- empty, one value, one group of 16 +- 1, one round of 1,024 +- 1, two and three rounds +- 1, six rounds --
+    with one and two chunks of sets, against the oracle"""
+    from plaid_amd import synth as sy
+    g = 9000
+    Gp, Gi = sy.geneset_csc(g, sets, kmax=300)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, sets))
+    rn = [str(k) for k in range(g)]
+    counts = [0, 1, 15, 16, 17, 0, 1023, 1024, 1025, 2047, 2048, 2049, 3071, 3073, 6000, 0, 5, 1000, 1100, 0]
+    rng = np.random.default_rng(11)
+    Xp = np.zeros(len(counts) + 1, dtype=np.int32)
+    Xi, Xx = [], []
+    for j, k in enumerate(counts):
+        rows = np.sort(rng.choice(g, size=k, replace=False)).astype(np.int32)
+        Xi.append(rows)
+        Xx.append(rng.normal(3.0, 2.0, size=k))
+        Xp[j + 1] = Xp[j] + k
+    Xi = np.concatenate(Xi).astype(np.int32)
+    Xx = np.concatenate(Xx)
+    Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, len(counts)))
+    ctx = pinned_ctx(spmm_sparse_kernel="scatter")
+    for stat in ("mean", "sum"):
+        close(ctx.plaid_csc(Xp, Xi, Xx, g, Gp, Gi, stat, False), _oracle().plaid(Xs, rn, G, rn, stats=stat, normalize=False))
+    close(ctx.plaid_csc(Xp, Xi, Xx, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
+
+
 @pytest.mark.parametrize("rank_kernel", ["bucket", "network"])
 def test_c4_shape_ssgsea_and_sing_dense_fp64_50k_sets(pinned_ctx, g50k, rank_kernel):
     """config 4 per sample in the default fp64 mode: dense 20k-gene columns (the register-blocked network / the
