@@ -1252,9 +1252,9 @@ int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
 int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,
                          const double* med, double add, const double* red) {
   if (n == 0 || m == 0) return PLAIDHIP_OK;
-  int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);   // workgroups per column: one trip of 2,048 values each, up to 32
+  int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);   // workgroups per column: one trip of 2,048 values each, up to 16
   if (bx < 1) bx = 1;
-  if (bx > 32) bx = 32;
+  if (bx > 16) bx = 16;                         // (32 measured equal on 8k columns x 50k sets and 7 % slower on 100k)
   int by = n < 32768 ? n : 32768;
   hipLaunchKernelGGL(shift_columns_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, S, lds, m, n, med, add, red);
   PH_HIP(hipGetLastError());

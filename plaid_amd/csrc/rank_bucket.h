@@ -222,8 +222,11 @@ colranks_bucket_kernel(RankBucketArgs a) {
       xc = dcol;
       rc = a.R + (int64_t)c * a.ldr;
     } else if (a.Xp != nullptr) {
-      const int p0 = a.Xp[c];
-      cnt = (uint32_t)(a.Xp[c + 1] - p0);
+      // (wave-uniform and read-only: through the scalar cache -- as a vector load + readfirstlane the column bounds are
+      // one more dependent L2 round trip in front of every column's value loads)
+      typedef __attribute__((address_space(4))) const int32_t* cptr_i32_;
+      const int p0 = ((cptr_i32_)a.Xp)[c];
+      cnt = (uint32_t)(((cptr_i32_)a.Xp)[c + 1] - p0);
       xc = a.Xv + p0;
       rc = a.R + p0;
     } else {
