@@ -726,18 +726,13 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   PH_TRY(dcol.alloc(64 + (size_t)n * 8));
   double* d_mm = dcol.as<double>();
   double* d_colsum = reinterpret_cast<double*>(dcol.as<char>() + 64);
-  if (remove_log2 < 0) {                                        // R/plaid.R:160-161
+  if (remove_log2 < 0) {                                        // R/plaid.R:160-161: decided and applied on the device
     PH_TRY(launch_minmax(ctx, dX.as<double>(), nvals, d_mm));
-    double mm[2];
-    PH_HIP(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
-    if (sparse && nvals < (int64_t)g * n) {                     // implicit zeros take part in min / max
-      mm[0] = mm[0] < 0.0 ? mm[0] : 0.0;
-      mm[1] = mm[1] > 0.0 ? mm[1] : 0.0;
-    }
-    remove_log2 = (mm[0] == 0.0 && mm[1] < 20.0) ? 1 : 0;
+    const bool implicit_zeros = sparse && nvals < (int64_t)g * n;   // they take part in min / max
+    PH_TRY(launch_map(ctx, dX.as<double>(), nvals, sparse ? 5 : 4, implicit_zeros ? 1.0 : 0.0, d_mm));   // :163-171
+  } else if (remove_log2) {
+    PH_TRY(launch_map(ctx, dX.as<double>(), nvals, sparse ? 3 : 2, 0.0, nullptr));                       // :163-171
   }
-  if (remove_log2) PH_TRY(launch_map(ctx, dX.as<double>(), nvals, sparse ? 3 : 2, 0.0, nullptr));   // :163-171
   PH_TRY(launch_col_abs_sums(ctx, dX.as<double>(), g, g, sparse ? dXp.as<int32_t>() : nullptr, n, d_colsum));
   PH_TRY(dS.alloc((size_t)m * n * 8));
   const int stat = score_mean ? PLAIDHIP_STAT_MEAN : PLAIDHIP_STAT_SUM;

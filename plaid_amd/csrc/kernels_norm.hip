@@ -539,6 +539,15 @@ shift_columns_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
 // (replaid.ucell R/plaid.R:276-282, replaid.aucell :304-309, replaid.scse :155-190)
 __global__ void __launch_bounds__(256)
 map_kernel(double* __restrict__ v, int64_t count, int op, double p0, const double* __restrict__ scalar) {
+  if (op >= 4) {
+    // replaid.scse's automatic removeLog2 (R/plaid.R:160-161), decided on the device from {min, max} at `scalar`
+    // (p0 != 0: a sparse X whose implicit zeros take part): the transform runs iff min == 0 and max < 20
+    double mn = scalar[0], mx = scalar[1];
+    if (p0 != 0.0) { mn = mn < 0.0 ? mn : 0.0; mx = mx > 0.0 ? mx : 0.0; }
+    if (!(mn == 0.0 && mx < 20.0)) return;
+    op -= 2;
+    scalar = nullptr;
+  }
   const double sc = scalar != nullptr ? *scalar : 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
