@@ -133,9 +133,9 @@ spmm_colgather_f64(SpmmArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
 
-  const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
-  const int ch_end = ((cptr_i32)a.wave_chunk_off)[wave + 1];
-  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
+  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
+  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
+  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
 
   const int g2 = a.g >> 1;
   const uint32_t lane_off16 = (uint32_t)tid * 16u;
@@ -233,7 +233,7 @@ spmm_colgather_f64(SpmmArgs a) {
       }                                                                                        \
     }                                                                                          \
     ++k;                                                                                       \
-    next_end = ((cptr_i32)a.wtile_end)[k];                                 \
+    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
     /* metadata of the next tile: issued now, consumed a whole tile later */                   \
     mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
     mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
@@ -249,7 +249,7 @@ spmm_colgather_f64(SpmmArgs a) {
       uint4 qc = PLAIDHIP_LOADQ(2);
       uint4 qd = PLAIDHIP_LOADQ(3);
       int k = tk_begin;
-      int next_end = ((cptr_i32)a.wtile_end)[k];
+      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       const uint32_t moff4 = (uint32_t)lane * 4u, moff8 = (uint32_t)lane * 8u;
       int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
@@ -1095,9 +1095,9 @@ spmm_colpair_mixed(SpmmArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
-  const int ch_end = ((cptr_i32)a.wave_chunk_off)[wave + 1];
-  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
+  const int ch_begin = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave]);
+  const int ch_end = __builtin_amdgcn_readfirstlane(a.wave_chunk_off[wave + 1]);
+  const int tk_begin = __builtin_amdgcn_readfirstlane(a.wave_tile_off[wave]);
   const int g2 = a.g >> 1;
   const int npairs = (a.n + 1) >> 1;
   // next pair, as loaded: 10 x 16 bytes of column A and of column B per thread
@@ -1192,7 +1192,7 @@ spmm_colpair_mixed(SpmmArgs a) {
       if (hasB) PLAIDHIP_EPI(dB0 + dB1, cB)                                                    \
     }                                                                                          \
     ++k;                                                                                       \
-    next_end = ((cptr_i32)a.wtile_end)[k];                                 \
+    next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);                                 \
     mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
     mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
     mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
@@ -1203,7 +1203,7 @@ spmm_colpair_mixed(SpmmArgs a) {
       uint4 qc = PLAIDHIP_LOADQ(2);
       uint4 qd = PLAIDHIP_LOADQ(3);
       int k = tk_begin;
-      int next_end = ((cptr_i32)a.wtile_end)[k];
+      int next_end = __builtin_amdgcn_readfirstlane(a.wtile_end[k]);
       double dA0 = 0.0, dA1 = 0.0, dB0 = 0.0, dB1 = 0.0;
       int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
       double mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);

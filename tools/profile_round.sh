@@ -22,6 +22,9 @@ run_pmc c4 --kernel c4 --samples 4096 --sets 50000 --iters 3
 python3 tools/bench_spmm.py --kernel c3 --samples 4096 --sets 50000 --iters 3 > $out/c3_4096.log 2>&1
 python3 tools/bench_spmm.py --kernel c4 --samples 2048 --sets 50000 --iters 3 > $out/c4_2048.log 2>&1
 python3 tools/bench_rank.py > $out/rank.log 2>&1
+python3 tools/bench_shift.py > $out/shift.log 2>&1
+python3 tools/bench_spmm.py --kernel medians --samples 8192 --sets 50000 --iters 10 > $out/medians_50k.log 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_cost.hip -o /tmp/valu_cost 2>/dev/null && UBENCH_ONLY_PAIR=1 /tmp/valu_cost > $out/ubench_pair_loops.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/ubench/lds_atomics.hip -o /tmp/lds_atomics 2>/dev/null && /tmp/lds_atomics > $out/ubench_lds_atomics.txt 2>&1
 hipcc -O2 tools/ubench/pcie.cpp -o /tmp/pcie -lpthread 2>/dev/null && /tmp/pcie > $out/ubench_pcie.txt 2>&1
 python3 - "$out" <<'PY'
