@@ -957,6 +957,8 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
     const double* sc = S + (int64_t)c * lds;
     uint32_t cnt = 0, k_lo = 0, k_hi = 0, k = 0, count = 0;
     uint32_t ncand = 0;          // keys of the sample interval written to `cand` by the sampled start (0: none / overflow)
+    uint64_t hi_cap = ~0ull;     // sampled start: its counts cover the keys <= qb only (the histogram interval is padded
+                                 // to a power of two and may reach beyond qb) -- every later sweep applies the same cap
     uint64_t lo = 0;
     int B = 0;
     bool seeded = false;
@@ -1064,6 +1066,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
             lo = qa + ((uint64_t)dsel << rt.shift);
             B = rt.shift;
             seeded = true;
+            hi_cap = qb;
           }
         }
         if (!seeded) ncand = 0;
@@ -1112,7 +1115,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         rt.nbins = 1u << (B - rt.shift);
         sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
           const uint32_t b = rt.bin(key);
-          if (b != 0xffffffffu) atomicAdd(&hist[b], 1u);
+          if (b != 0xffffffffu && ((((uint64_t)key.hi << 32) | key.lo) <= hi_cap)) atomicAdd(&hist[b], 1u);
         });
         wave_lds_sync();
         const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
@@ -1149,7 +1152,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         rt.nbins = 1u << (B - rt.shift);
         uint32_t base = 0;
         auto collect = [&](const Key32& key) {
-          const bool in = rt.bin(key) != 0xffffffffu;
+          const bool in = rt.bin(key) != 0xffffffffu && ((((uint64_t)key.hi << 32) | key.lo) <= hi_cap);
           const unsigned long long bal = __ballot(in);
           if (in) {
             const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));

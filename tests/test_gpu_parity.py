@@ -279,6 +279,19 @@ def test_medians_large_m_select_path(hip_ctx):
     close(hip_ctx.normalize_medians(S, False)[0], exp)
 
 
+def test_streaming_medians_many_columns_per_wavefront(hip_ctx):
+    """more columns than the streaming kernel has wavefronts in flight (8 workgroups x 4 per CU): every wavefront
+    walks several columns and REUSES its candidate list in global memory -- each column must read back its own keys,
+    not what an earlier column of the same wavefront left in a cache; medians differ from column to column"""
+    rng = np.random.default_rng(5)
+    m, n = 6400, 20480
+    S = rng.normal(size=(m, n)) + np.linspace(-3.0, 3.0, n)[None, :]
+    S[:, 1::7] = np.round(S[:, 1::7], 1)                         # heavy ties in some columns
+    med = np.median(S, axis=0)
+    exp = S - med[None, :] + med.mean()
+    close(hip_ctx.normalize_medians(S, False)[0], exp)
+
+
 def test_empty_inputs(hip_ctx):
     Gp = np.zeros(1, dtype=np.int32)
     Gi = np.zeros(0, dtype=np.int32)
