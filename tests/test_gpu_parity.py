@@ -687,6 +687,30 @@ def test_scatter_kernel_any_number_of_stored_values_per_column(pinned_ctx, sets)
     close(ctx.plaid_csc(Xp, Xi, Xx, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
 
 
+def test_scatter_kernel_many_columns_per_workgroup(pinned_ctx):
+    """more columns than workgroups: the item pipeline of a workgroup runs across column boundaries (the next
+    column's values and segment ranges are requested during the current column's last chunks) -- 1,500 columns of
+    0 ... 2,500 stored values, every one against the oracle; also an X without a single stored value"""
+    from plaid_amd import synth as sy
+    g, sets, n = 3000, 300, 1500
+    Gp, Gi = sy.geneset_csc(g, sets, kmax=200)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, sets))
+    rn = [str(k) for k in range(g)]
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 2500, size=n)
+    counts[::17] = 0
+    Xp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    Xi = np.concatenate([np.sort(rng.choice(g, size=int(k), replace=False)) for k in counts]).astype(np.int32)
+    Xx = rng.normal(1.0, 2.0, size=int(Xp[-1]))
+    Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, n))
+    ctx = pinned_ctx(spmm_sparse_kernel="scatter")
+    close(ctx.plaid_csc(Xp, Xi, Xx, g, Gp, Gi, "mean", False), _oracle().plaid(Xs, rn, G, rn, normalize=False))
+    close(ctx.ssgsea_csc(Xp, Xi, Xx, g, Gp, Gi, 0.25), _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
+    Xe = sp.csc_matrix((g, 40))
+    got = ctx.plaid_csc(Xe.indptr, Xe.indices, Xe.data, g, Gp, Gi, "sum", False)
+    assert got.shape == (sets, 40) and not got.any()
+
+
 @pytest.mark.parametrize("rank_kernel", ["bucket", "network"])
 def test_c4_shape_ssgsea_and_sing_dense_fp64_50k_sets(pinned_ctx, g50k, rank_kernel):
     """config 4 per sample in the default fp64 mode: dense 20k-gene columns (the register-blocked network / the
