@@ -1290,8 +1290,10 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 4096) launch_radix<256, 16>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 5120) launch_radix<256, 20>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 6144) launch_radix<256, 24>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    // (beyond 16 keys per thread the 256-thread kernel drops to 4 waves per SIMD: 512 threads x 10 / 12 keys measured
+    //  5 % / 9 % faster at m = 5,000 / 6,000, and 20-60 % slower than 256 threads below 4,096)
+    else if (m <= 5120) launch_radix<512, 10>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 6144) launch_radix<512, 12>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_radix<512, 32>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (want_sample) {
     // workgroup-per-column sample-bracket selection (superseded by the streaming kernel's sampled start): BLOCK 512 up to 16k sets, 1024 beyond; the sample grows with m so
