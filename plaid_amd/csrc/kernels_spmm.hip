@@ -879,10 +879,10 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   // at the top of the next item it waited with vmcnt(0) -- it cannot count the conditional S stores issued since --
   // i.e. for the acknowledgement of a whole chunk's stores.
 #define PLAIDHIP_ASM_LOAD_SEG(ptr_)   /* {seg[gene], seg[gene + 1]} -> v[120:121] */                    \
-  asm volatile("global_load_dwordx2 v[120:121], %0, off" : : "v"(ptr_) : "memory", "v120", "v121")
+  asm volatile("global_load_dwordx2 v[120:121], %0, off" : : "v"(ptr_) : "memory")
 #define PLAIDHIP_ASM_LOAD_CELL(pi_, px_)   /* Xi[q] -> v122, Xx[q] -> v[124:125] */                     \
   asm volatile("global_load_dword v122, %0, off\n\tglobal_load_dwordx2 v[124:125], %1, off"            \
-               : : "v"(pi_), "v"(px_) : "memory", "v122", "v124", "v125")
+               : : "v"(pi_), "v"(px_) : "memory")
 #define PLAIDHIP_ASM_TAKE(s0_, s1_, g_, xlo_, xhi_)                                                     \
   asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v122\n\t" \
                "v_mov_b32 %3, v124\n\tv_mov_b32 %4, v125"                                               \
@@ -925,6 +925,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #endif
   // current item, the next one (n1: gene / value here, segment range on its way during the current walk) and the one
   // after (n2: gene / value on their way)
+  asm volatile("" : : : "v125");   // (the one clobber that makes the kernel's register count cover v120..v125)
   int c = blockIdx.x, chunk = 0, rr = 0, q0 = 0, q1 = 0;
   if (c < a.n) { q0 = ((cptr_i32)a.Xp)[c]; q1 = ((cptr_i32)a.Xp)[c + 1]; }
   int c1 = c, chunk1 = chunk, r1 = rr, q01 = q0, q11 = q1;
