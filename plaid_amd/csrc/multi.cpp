@@ -17,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -72,7 +73,16 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
   PH_TRY(ensure_pinned(ctx));
   constexpr int T = plaidhip_ctx::kFeeders;
   const int64_t pcols = std::max<int64_t>(1, (int64_t)(kPanelBytes / ldd_bytes));
-  const int64_t npan = (cols + pcols - 1) / pcols;
+  // panel boundaries: the first round of panels (one per feeder) is an eighth of the size, the second a half -- the
+  // bus starts after a fraction of a millisecond of staging instead of after a whole 48 MB memcpy (measured: 3.3 ms
+  // of fill in front of the first DMA with equal panels)
+  std::vector<int64_t> pb{0};
+  for (int64_t r = 0; pb.back() < cols; ++r) {
+    int64_t w = r < T ? pcols / 8 : (r < 2 * T ? pcols / 2 : pcols);
+    w = std::max<int64_t>(2, w & ~(int64_t)1);   // even: the pair kernel takes two columns per pass
+    pb.push_back(std::min(cols, pb.back() + w));
+  }
+  const int64_t npan = (int64_t)pb.size() - 1;
   std::vector<hipEvent_t> done((size_t)npan, nullptr);
   for (auto& e : done) PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   std::vector<std::atomic<int>> ready((size_t)npan);
@@ -84,7 +94,7 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
     hipEvent_t freeb[2] = {nullptr, nullptr};
     for (int64_t p = t, it = 0; p < npan; p += T, ++it) {
       const int b = (int)(it & 1);
-      const int64_t c0 = p * pcols, c1 = std::min(cols, c0 + pcols);
+      const int64_t c0 = pb[(size_t)p], c1 = pb[(size_t)p + 1];
       bool ok = failed.load() == 0;
       if (ok && freeb[b] != nullptr) ok = hipEventSynchronize(freeb[b]) == hipSuccess;   // the DMA that last read this buffer
       if (ok) {
@@ -115,7 +125,7 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
     while (ready[(size_t)p].load(std::memory_order_acquire) == 0) std::this_thread::yield();
     if (failed.load() != 0 || rc != PLAIDHIP_OK) continue;
     if (hipStreamWaitEvent(ctx->stream, done[(size_t)p], 0) != hipSuccess) { failed.store(1); continue; }
-    if (on_panel) rc = on_panel(p * pcols, std::min(cols, (p + 1) * pcols));
+    if (on_panel) rc = on_panel(pb[(size_t)p], pb[(size_t)p + 1]);
   }
   for (auto& t : th) t.join();
   for (auto& e : done) hipEventDestroy(e);
@@ -186,8 +196,22 @@ struct CtxBuf {
 };
 
 // one device's part of a sharded call.  Returns a status; `sh` carries the cross-shard scalars.
+#ifdef PLAIDHIP_DIAG
+#define PH_TRACE(tag)                                                                                              \
+  do {                                                                                                             \
+    if (getenv("PLAIDHIP_TRACE"))                                                                                  \
+      fprintf(stderr, "[trace] %-22s %8.2f ms\n", tag,                                                             \
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace0).count());     \
+  } while (0)
+#else
+#define PH_TRACE(tag) do { } while (0)
+#endif
+
 int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) {
   int rc = PLAIDHIP_OK;
+#ifdef PLAIDHIP_DIAG
+  const auto t_trace0 = std::chrono::steady_clock::now();
+#endif
   // every `step` is skipped once this shard or any other has failed; the rendezvous points are always reached
   auto live = [&] { return rc == PLAIDHIP_OK && sh.abort.load() == 0; };
   auto step = [&](const std::function<int()>& fn) {
@@ -216,6 +240,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
   step([&]() -> int {
     PH_HIP(hipSetDevice(ctx->device));
     PH_TRY(acquire_geneset(ctx, g, m, c.Gp, c.Gi, &gs));
+    PH_TRACE("geneset acquired");
     PH_TRY(dsmall.alloc(64 + (size_t)std::max(nloc, 1) * 16));
     d_flags = dsmall.as<uint32_t>();
     d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
@@ -251,8 +276,10 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
                                          c.method == 2 ? 1.0 + c.alpha : 1.0, dR.as<double>() + c0 * ldg, ldg,
                                          c.method == 2 ? d_colmax + c0 : nullptr);
       };
+      PH_TRACE("buffers ready");
       PH_TRY(upload_pipelined(ctx, dX.as<char>(), (size_t)ldg * 8, reinterpret_cast<const char*>(Xh), (size_t)g * 8, nloc,
                               on_panel));
+      PH_TRACE("upload enqueued");
     } else {
       z0 = c.Xp[lo];
       zx = (int64_t)c.Xp[lo + nloc] - z0;
@@ -322,6 +349,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       if (nloc == 0) return PLAIDHIP_OK;
       PH_HIP(hipMemcpyAsync(fl, d_flags, 16, hipMemcpyDeviceToHost, ctx->stream));
       PH_HIP(hipStreamSynchronize(ctx->stream));
+      PH_TRACE("crossprod done (flags)");
       return PLAIDHIP_OK;
     });
     {
@@ -354,10 +382,12 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
 
   // ---- the score shard goes home (pageable destination: the runtime's own staging runs at ~53 GB/s) ---------------------
   for (auto& t : prefault) t.join();
+  PH_TRACE("normalise enqueued");
   step([&]() -> int {
     if (nloc > 0)
       PH_HIP(hipMemcpyAsync(c.S_out + (int64_t)lo * m, dS.p, (size_t)m * nloc * 8, hipMemcpyDeviceToHost, ctx->stream));
     PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_TRACE("scores home");
     return PLAIDHIP_OK;
   });
   if (rc == PLAIDHIP_OK && sh.abort.load() != 0) {
