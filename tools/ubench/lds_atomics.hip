@@ -61,6 +61,44 @@ __global__ void __launch_bounds__(1024) k(const unsigned short* ids, int nid, in
   if (out) out[blockIdx.x * 1024 + threadIdx.x] = acc[threadIdx.x];
 }
 
+// ids held in registers (32 per lane, applied round and round): no id load between the atomics, so the LDS unit is the
+// only bound (the kernel above loads a u16 per lane and instruction and saturates the vector-memory issue at ~14 cycles)
+template <typename T>
+__global__ void __launch_bounds__(1024) kreg(const unsigned short* ids, int nid, int iters, unsigned long long* cyc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* acc = reinterpret_cast<T*>(smem);
+  for (int i = threadIdx.x; i < 20480; i += 1024) acc[i] = (T)0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned short* my = ids + (size_t)wave * nid * 64 + lane;
+  unsigned id[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) id[q] = my[(size_t)q * 64];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  T v = (T)1;
+  for (int it = 0; it < iters * (nid / 32); ++it) {
+#pragma unroll
+    for (int q = 0; q < 32; ++q) lds_add<T>(&acc[id[q]], v);
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <typename T>
+static void run_reg(const char* name, const unsigned short* d_ids, int nid, int iters) {
+  unsigned long long* d_cyc;
+  hipMalloc(&d_cyc, 256 * 8);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&kreg<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  kreg<T><<<256, 1024, 160 * 1024>>>(d_ids, nid, 1, d_cyc);
+  kreg<T><<<256, 1024, 160 * 1024>>>(d_ids, nid, iters, d_cyc);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> c(256);
+  hipMemcpy(c.data(), d_cyc, 256 * 8, hipMemcpyDeviceToHost);
+  double cyc = 0; for (auto x : c) cyc += (double)x; cyc /= 256;
+  printf("%-56s %7.2f shader cycles per wave-instruction per CU (ids in registers)\n", name, cyc / (16.0 * nid * iters));
+  hipFree(d_cyc);
+}
+
 template <typename T, int MODE>
 static double run(const char* name, const unsigned short* d_ids, int nid, int iters) {
   unsigned long long* d_cyc;
@@ -101,6 +139,38 @@ int main() {
   unsigned short* d_ids;
   hipMalloc(&d_ids, ids.size() * 2);
   hipMemcpy(d_ids, ids.data(), ids.size() * 2, hipMemcpyHostToDevice);
+  {
+    // banks distinct inside every 16-lane group (what the scatter plan achieves where the counts allow), rows random
+    std::vector<unsigned short> ids2(ids.size());
+    for (size_t i = 0; i < ids2.size(); i += 16) {
+      int perm[16];
+      for (int r = 0; r < 16; ++r) perm[r] = r;
+      for (int r = 15; r > 0; --r) { const int j = rand() % (r + 1); const int t = perm[r]; perm[r] = perm[j]; perm[j] = t; }
+      for (int l = 0; l < 16; ++l) ids2[i + l] = (unsigned short)(16 * (rand() % 1280) + perm[l]);
+    }
+    unsigned short* d_ids2;
+    hipMalloc(&d_ids2, ids2.size() * 2);
+    hipMemcpy(d_ids2, ids2.data(), ids2.size() * 2, hipMemcpyHostToDevice);
+    run_reg<double>("ds_add_f64 banks distinct per 16 lanes, random rows", d_ids2, nid, iters);
+    run_reg<unsigned long long>("ds_add_u64 banks distinct per 16 lanes, random rows", d_ids2, nid, iters);
+    run_reg<double>("ds_add_f64 64 distinct random slots", d_ids, nid, iters);
+    run_reg<unsigned long long>("ds_add_u64 64 distinct random slots", d_ids, nid, iters);
+    // the same with fewer distinct 128-byte rows per 16-lane group: 1 (16 consecutive slots at a random base), 2, 4, 8
+    for (int nrows : {1, 2, 4, 8}) {
+      for (size_t i = 0; i < ids2.size(); i += 16) {
+        int perm[16], rows[8];
+        for (int r = 0; r < 16; ++r) perm[r] = r;
+        for (int r = 15; r > 0; --r) { const int j = rand() % (r + 1); const int t = perm[r]; perm[r] = perm[j]; perm[j] = t; }
+        for (int r = 0; r < nrows; ++r) rows[r] = rand() % 1280;
+        for (int l = 0; l < 16; ++l) ids2[i + l] = (unsigned short)(16 * rows[l % nrows] + perm[l]);
+      }
+      hipMemcpy(d_ids2, ids2.data(), ids2.size() * 2, hipMemcpyHostToDevice);
+      char nm[96];
+      snprintf(nm, sizeof nm, "ds_add_f64 banks distinct, %d rows per 16 lanes", nrows);
+      run_reg<double>(nm, d_ids2, nid, iters);
+    }
+    hipFree(d_ids2);
+  }
   run<double, 0>("ds_add_f64 random", d_ids, nid, iters);
   run<double, 1>("ds_add_f64 conflict-free", d_ids, nid, iters);
   run<unsigned long long, 0>("ds_add_u64 random", d_ids, nid, iters);
