@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the scatter kernel (diag library)")
     ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
+    ap.add_argument("--nt-store", default="auto", choices=["auto", "off", "on"], help="non-temporal stores of the scores")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -34,6 +35,7 @@ def main():
     ctx.set_precision(a.precision)
     ctx.set_option("spmm_dense_kernel", a.dense_kernel)
     ctx.set_option("spmm_sparse_kernel", a.sparse_kernel)
+    ctx.set_option("nt_store", a.nt_store)
     dbg = None
     if a.ablate or a.stamps:
         import ctypes
