@@ -135,6 +135,47 @@ def _rel_err(a, b):
         return float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-9)))
 
 
+
+# ----------------------------------------------------------------------------------------- parity of the TIMED launches
+def _snapshot(torch, S, med, red, flags, n, m, more=None):
+    """probe columns (first / around element offset 2^31 / last, oracle.fullsize.probe_columns) of the result the LAST
+    TIMED step left in S, plus the device's per-column vectors and scalars, copied to the host before anything else
+    touches the buffers"""
+    from oracle import fullsize
+    cols, crosses = fullsize.probe_columns(n, m)
+    idx = torch.as_tensor(cols, device=S.device)
+    torch.cuda.synchronize()
+    snap = {"cols": cols, "idx": idx, "crosses": crosses, "S": np_f(S.index_select(0, idx)),
+            "med": med.cpu().numpy().copy(), "red": red.cpu().numpy().copy(), "flags": flags.cpu().numpy().copy()}
+    for k, v in (more or {}).items():
+        snap[k] = v.cpu().numpy().copy()
+    return snap
+
+
+def np_f(t):
+    """(k, m) row-major device tensor -> (m, k) Fortran-ordered host array (R layout)"""
+    import numpy as np
+    return np.asfortranarray(t.cpu().numpy().T)
+
+
+def _parity_report(res, snap, n, m, extra=None):
+    from oracle import fullsize
+    out = {"launch": "full", "checked": "the S the last timed step produced",
+           "columns": int(len(snap["cols"])),
+           "column_runs": [list(r) for r in fullsize.contiguous_runs(snap["cols"])],
+           "offsets_past_2^31_checked": bool(snap["crosses"]),
+           "last_element_offset": int(m) * int(n) - 1}
+    out.update({k: (float(v) if isinstance(v, float) else v) for k, v in res.items()})
+    if extra:
+        out.update(extra)
+    return out
+
+
+def _full_minmax(torch, Sraw):
+    """independent device reduction over a FULL un-normalised result: (min, any zero) -- what R/plaid.R:556-557 tests"""
+    return float(Sraw.min().item()), bool((Sraw == 0).any().item())
+
+
 # ----------------------------------------------------------------------------------------- C2 (headline)
 def run_c2(a, env):
     import numpy as np
@@ -180,6 +221,7 @@ def run_c2(a, env):
             ev.rec(k, 3)
 
     elapsed = _timed(torch, dist, use_dist, dev, a.steps, a.warmup, step)
+    snap = _snapshot(torch, S, med, red[0:2], flags, n, m) if (rank == 0 and world == 1 and a.cpu_sample > 0) else None
     ms_step = 1e3 * elapsed / a.steps
     spmm_ms, med_ms, shift_ms = ev.phase_ms(0), ev.phase_ms(1), ev.phase_ms(2)
     scores = float(world) * n * m
@@ -267,12 +309,22 @@ def run_c2(a, env):
                "all_cores": {"value": round(m * nc / (t5 - t4), 1), "cores": nt,
                              "note": "same code, OpenMP over sample columns (not what the single-threaded reference does)"},
                "cpu_count": os.cpu_count()}
-        with torch.cuda.stream(stream):
-            ctx.dev_spmm_dense(gs, X.data_ptr(), g, nc, S.data_ptr(), m, "mean", 1.0, 0.0, None)
-        torch.cuda.synchronize()
-        Sg = S[:nc].cpu().numpy().T
-        parity = {"max_rel_err_vs_oracle": float(np.max(np.abs(Sg - Sraw) / np.maximum(np.abs(Sraw), 1e-300))),
-                  "columns": nc}
+        # parity of the launch that was timed: probe columns of ITS result against the oracle, column by column
+        from oracle import fullsize
+        try:
+            Xc = np_f(X.index_select(0, snap["idx"]))
+            raw_o = c_oracle.crossprod_dense(Xc, Gp, Gi, "mean", nt)
+            with torch.cuda.stream(stream):     # one more full-size launch, un-normalised: for the independent flag check
+                ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, None)
+            torch.cuda.synchronize()
+            res = fullsize.check_normalised(raw_o, snap["S"], snap["med"], snap["cols"], snap["red"], snap["flags"],
+                                            _full_minmax(torch, S))
+            raw_g = np_f(S.index_select(0, snap["idx"]))
+            res["raw_max_rel_err_vs_oracle"] = float(np.max(np.abs(raw_g - raw_o) / np.maximum(np.abs(raw_o), 1e-300)))
+            np.testing.assert_allclose(raw_g, raw_o, rtol=fullsize.RTOL, atol=fullsize.ATOL)
+            parity = _parity_report(res, snap, n, m)
+        except AssertionError as exc:
+            parity = {"launch": "full", "ok": False, "error": str(exc)[:400]}
         if mixed is not None and "error" not in mixed:
             ctx.set_precision("mixed")
             with torch.cuda.stream(stream):
@@ -325,32 +377,6 @@ def run_c2(a, env):
 
 
 # ----------------------------------------------------------------------------------------- sparse X generator
-def device_sparse_cells(torch, dev, g, n, seed, density=0.05, levels=50):
-    """n cells of the sparse workload generated ON the device (~5 % stored values per cell, values
-    log1p(count / size factor) with ~50 levels per cell), as CSC tensors.  Returns (p int32[n+1], i int32, x float64,
-    nnz, longest column)."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    ps, idx, val = [torch.zeros(1, dtype=torch.int64, device=dev)], [], []
-    B = 4096
-    for j0 in range(0, n, B):
-        b = min(B, n - j0)
-        mask = torch.rand((b, g), device=dev, generator=gen) < density
-        cnt = mask.sum(dim=1)
-        nz = mask.nonzero(as_tuple=False)                  # sorted by cell, then gene
-        k = torch.empty(nz.shape[0], device=dev, dtype=torch.float64).geometric_(0.12, generator=gen).clamp_(max=levels)
-        sf = 0.5 + torch.rand(b, device=dev, dtype=torch.float64, generator=gen)
-        val.append(torch.log1p(k / sf[nz[:, 0]]))
-        idx.append(nz[:, 1].to(torch.int32))
-        ps.append(cnt)
-        del mask, nz, k
-    cnt = torch.cat(ps)
-    p = torch.cumsum(cnt, 0)
-    nnz = int(p[-1].item())
-    assert nnz < 2**31 - 1, "more than 2^31-1 stored values: 32-bit dgCMatrix slots"
-    return p.to(torch.int32), torch.cat(idx), torch.cat(val), nnz, int(cnt.max().item())
-
-
 def ssgsea_csc_oracle(c_oracle, np, Xp, Xi, Xx, g, Gp, Gi, alpha, threads):
     """replaid.ssgsea on a dgCMatrix, phase by phase, on the C oracle (R/plaid.R:244-255)"""
     t = [time.perf_counter()]
@@ -395,7 +421,7 @@ def run_sparse_ssgsea(a, env, n, label, collective):
     gs = ctx.geneset(g, Gp, Gi)
     t_plan = time.perf_counter() - t0
     with torch.cuda.stream(stream):
-        Xp, Xi, Xx, nnz, max_nnz = device_sparse_cells(torch, dev, g, n, 20250615 + 7919 * rank)
+        Xp, Xi, Xx, nnz, max_nnz = synth.device_sparse_cells(torch, dev, g, n, 20250615 + 7919 * rank)
         Rx = torch.empty_like(Xx)
         S = torch.empty((n, m), dtype=torch.float64, device=dev)
         colmax = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -431,6 +457,9 @@ def run_sparse_ssgsea(a, env, n, label, collective):
             ev.rec(k, 4)
 
     elapsed = _timed(torch, dist, collective, dev, steps, 1, step)
+    snap = None
+    if not collective and rank == 0 and a.cpu_sample > 0:
+        snap = _snapshot(torch, S, med, red, flags, n, m, {"colmax": colmax, "gmax": gmax})
     rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
     scatter = nnz * 8 < g * n
     spmm_alg = 12.0 * nnz + 4.0 * (n + 1) + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
@@ -468,21 +497,38 @@ def run_sparse_ssgsea(a, env, n, label, collective):
             "sample": f"first {nc} of {n} cells x {m} sets, plain-C oracle: sparse_colranks+pow {t1[0]:.2f} s, crossprod "
                       f"(Gustavson order) {t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
             "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
-        # checker: the GPU pipeline on exactly that sample (the three global scalars couple all cells)
-        with torch.cuda.stream(stream):
-            flags.zero_()
-            ctx.dev_colranks_csc(Xp.data_ptr(), Xx.data_ptr(), nc, max_nnz, Rx.data_ptr(), "average", False, 1.0 + alpha,
-                                 colmax.data_ptr())
-            ctx.dev_max(colmax.data_ptr(), nc, gmax.data_ptr())
-            ctx.dev_spmm_csc(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), nc, S.data_ptr(), m, "mean", 1.0, -0.5,
-                             flags.data_ptr(), gmax.data_ptr(), nnz=zc)
-            ctx.dev_col_medians(S.data_ptr(), m, m, nc, None, med.data_ptr(), flags.data_ptr())
-            ctx.dev_sum(med.data_ptr(), nc, red.data_ptr())
-            ctx.dev_shift_columns(S.data_ptr(), m, m, nc, med.data_ptr(), 0.0, red.data_ptr())
-        torch.cuda.synchronize()
-        Sg = S[:nc].cpu().numpy().T
-        out["parity"] = {"max_abs_err_vs_oracle": float(np.max(np.abs(Sg - S1))), "max_rel_err_vs_oracle": _rel_err(Sg, S1),
-                         "columns": nc, "note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"}
+        # checker: probe cells of the launch that was timed (first / around element offset 2^31 / last), phase by phase
+        from oracle import fullsize
+        try:
+            cols, runs = snap["cols"], fullsize.contiguous_runs(snap["cols"])
+            ph_all = Xp.cpu().numpy()
+            parts, rparts = [], []
+            for lo, hi in runs:
+                q0, q1 = int(ph_all[lo]), int(ph_all[hi])
+                parts.append((ph_all[lo:hi + 1], Xi[q0:q1].cpu().numpy(), Xx[q0:q1].cpu().numpy()))
+                rparts.append(Rx[q0:q1].cpu().numpy())
+            sp_, si_, sx_ = fullsize.sub_csc(parts)
+            rx_gpu = np.concatenate(rparts)
+            gmax_dev = float(snap["gmax"][0])
+            assert gmax_dev == float(snap["colmax"].max()), "max(rX) on the device != max of the device's colmax[]"
+            r_o, raw_o = fullsize.ssgsea_csc_raw(sp_, si_, sx_, g, Gp, Gi, alpha, gmax_dev)
+            ranks_exact = bool(np.array_equal(fullsize.ranks_from_powered(rx_gpu, 1.0 + alpha), r_o))
+            assert ranks_exact, "sparse_colranks of the probe cells differ from the oracle"
+            cm = np.array([rx_gpu[sp_[j]:sp_[j + 1]].max() if sp_[j + 1] > sp_[j] else 0.0 for j in range(len(cols))])
+            assert np.array_equal(cm, snap["colmax"][cols]), "colmax[] of the probe cells != max of their powered ranks"
+            with torch.cuda.stream(stream):     # one more full-size launch, un-normalised: for the independent flag check
+                S2 = torch.empty_like(S)
+                ctx.dev_spmm_csc(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), n, S2.data_ptr(), m, "mean", 1.0, -0.5,
+                                 None, gmax.data_ptr(), nnz=nnz)
+            torch.cuda.synchronize()
+            res = fullsize.check_normalised(raw_o, snap["S"], snap["med"], cols, snap["red"], snap["flags"],
+                                            _full_minmax(torch, S2))
+            del S2
+            res["ranks_bit_exact"] = ranks_exact
+            res["gmax_equals_max_of_colmax"] = True
+            out["parity"] = _parity_report(res, snap, n, m, {"note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"})
+        except AssertionError as exc:
+            out["parity"] = {"launch": "full", "ok": False, "error": str(exc)[:400]}
     gs.close()
     del Xp, Xi, Xx, Rx, S
     torch.cuda.empty_cache()
@@ -536,6 +582,10 @@ def run_c4(a, env):
             pipeline(n, k)
 
     elapsed = _timed(torch, dist, False, dev, steps, 1, step)
+    snap = None
+    if a.cpu_sample > 0:
+        snap = _snapshot(torch, S, med, red, flags, n, m, {"colmax": colmax, "gmax": gmax})
+        snap["R"] = R.index_select(0, snap["idx"]).cpu().numpy()          # (k, g): powered ranks of the probe samples
     rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
     spmm_alg = 8.0 * g * n + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
     out = {
@@ -606,12 +656,27 @@ def run_c4(a, env):
             "sample": f"first {nc} of {n} samples x {m} sets, plain-C oracle: colranks+pow {t1[0]:.2f} s, crossprod "
                       f"{t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
             "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
-        with torch.cuda.stream(stream):
-            pipeline(nc)
-        torch.cuda.synchronize()
-        Sg = S[:nc].cpu().numpy().T
-        out["parity"] = {"max_abs_err_vs_oracle": float(np.max(np.abs(Sg - S1))), "max_rel_err_vs_oracle": _rel_err(Sg, S1),
-                         "columns": nc, "note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"}
+        # checker: probe samples of the launch that was timed (first / around element offset 2^31 / last), phase by phase
+        from oracle import fullsize
+        try:
+            cols = snap["cols"]
+            gmax_dev = float(snap["gmax"][0])
+            assert gmax_dev == float(snap["colmax"].max()), "max(rX) on the device != max of the device's colmax[]"
+            Xc = np_f(X.index_select(0, snap["idx"]))
+            r_o, raw_o = fullsize.ssgsea_dense_raw(Xc, Gp, Gi, alpha, gmax_dev)
+            ranks_exact = bool(np.array_equal(fullsize.ranks_from_powered(snap["R"].T, 1.0 + alpha), r_o))
+            assert ranks_exact, "colranks of the probe samples differ from the oracle"
+            assert np.array_equal(snap["R"].max(axis=1), snap["colmax"][cols]), "colmax[] != max of the powered ranks"
+            with torch.cuda.stream(stream):     # one more full-size launch, un-normalised: for the independent flag check
+                ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, None, gmax.data_ptr())
+            torch.cuda.synchronize()
+            res = fullsize.check_normalised(raw_o, snap["S"], snap["med"], cols, snap["red"], snap["flags"],
+                                            _full_minmax(torch, S))
+            res["ranks_bit_exact"] = ranks_exact
+            res["gmax_equals_max_of_colmax"] = True
+            out["parity"] = _parity_report(res, snap, n, m, {"note": "scores are centred (|s| <~ 0.5): abs error is the meaningful one"})
+        except AssertionError as exc:
+            out["parity"] = {"launch": "full", "ok": False, "error": str(exc)[:400]}
     gs.close()
     del X, R, S
     torch.cuda.empty_cache()

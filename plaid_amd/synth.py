@@ -80,3 +80,29 @@ def sparse_columns(g: int, j0: int, j1: int, seed: int = SEED_X + 1, density: fl
     Xi = np.concatenate(idx) if idx else np.zeros(0, np.int32)
     Xx = np.concatenate(val) if val else np.zeros(0, np.float64)
     return np.asarray(ps, dtype=np.int64), Xi, Xx
+
+
+def device_sparse_cells(torch, dev, g, n, seed, density=0.05, levels=50):
+    """n cells of the sparse workload generated ON the device (~5 % stored values per cell, values
+    log1p(count / size factor) with ~50 levels per cell), as CSC tensors.  Returns (p int32[n+1], i int32, x float64,
+    nnz, longest column)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    ps, idx, val = [torch.zeros(1, dtype=torch.int64, device=dev)], [], []
+    B = 4096
+    for j0 in range(0, n, B):
+        b = min(B, n - j0)
+        mask = torch.rand((b, g), device=dev, generator=gen) < density
+        cnt = mask.sum(dim=1)
+        nz = mask.nonzero(as_tuple=False)                  # sorted by cell, then gene
+        k = torch.empty(nz.shape[0], device=dev, dtype=torch.float64).geometric_(0.12, generator=gen).clamp_(max=levels)
+        sf = 0.5 + torch.rand(b, device=dev, dtype=torch.float64, generator=gen)
+        val.append(torch.log1p(k / sf[nz[:, 0]]))
+        idx.append(nz[:, 1].to(torch.int32))
+        ps.append(cnt)
+        del mask, nz, k
+    cnt = torch.cat(ps)
+    p = torch.cumsum(cnt, 0)
+    nnz = int(p[-1].item())
+    assert nnz < 2**31 - 1, "more than 2^31-1 stored values: 32-bit dgCMatrix slots"
+    return p.to(torch.int32), torch.cat(idx), torch.cat(val), nnz, int(cnt.max().item())
