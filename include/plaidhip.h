@@ -90,7 +90,9 @@ enum plaidhip_option {
                                           ~145x the flops of the SpMM, ~1e-7 relative; measured beside it, never default) */
   PLAIDHIP_OPT_SPMM_SPARSE_KERNEL = 2, /* 0 auto: by nnz(X) (default) | 1 scatter | 2 gather                        */
   PLAIDHIP_OPT_NT_STORE = 3,           /* -1 auto (default) | 0 plain stores of S | 1 streaming stores              */
-  PLAIDHIP_OPT_RANKS_F32 = 4,          /* 1 (default): rank inputs take the fp32-staged crossprod (exact) | 0: fp64 */
+  PLAIDHIP_OPT_RANKS_F32 = 4,          /* staging of RANK inputs in the crossprod, all three exact and bit-identical:
+                                          2 (default) u16 (2 * rank), four samples per LDS entry, integer sums |
+                                          1 fp32 staging | 0 the fp64 kernels                                        */
   PLAIDHIP_OPT_RANK_KERNEL = 5         /* 0 auto (default) | 1 sorting network | 2 bucket ranker                    */
 };
 int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value);
@@ -127,6 +129,16 @@ int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]);
  * the global max(rX) never visits the host.  `flags` (device uint32[4], may be NULL): see above. */
 int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
                                 int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
+                                double beta, void* S, int64_t lds, void* flags);
+/* The same crossprod for an X that holds RANKS -- exactly what plaidhip_dev_colranks_dense_f64 writes with power = 1 and
+ * is_signed = 0 (half-integers in [0.5, nrow(X)]), or such ranks after replaid.ucell's max - rank / pmin map: the rank
+ * matrix of replaid.sing (R/plaid.R:215-217), replaid.ssgsea(alpha = 0) (:245-253), replaid.ucell (:277-279).  2 * rank
+ * is staged as u16 (four sample columns per 8-byte LDS entry) and summed in integers: exact, order-independent and
+ * bit-identical to plaidhip_dev_spmm_dense_f64 on the same input, at a quarter of its LDS bytes per score.  A value
+ * whose double is >= 32,768 sets flags[3] (the scores are then meaningless); shapes the kernel does not take
+ * (nrow(X) <= 8,192 or > 20,448, odd ldx) run the general kernels.                                                  */
+int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,
+                                int64_t ldr, int32_t n, int stat, double alpha, const void* alpha_div,
                                 double beta, void* S, int64_t lds, void* flags);
 /* same with X as CSC (dgCMatrix) -- sparse branch of Matrix::crossprod at R/plaid.R:107.
  * `nnz`: number of stored values of X when the caller knows it (Xp[n] on the host), else -1.  It picks

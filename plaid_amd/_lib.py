@@ -20,7 +20,7 @@ OPTIONS = {
     "spmm_dense_kernel": (1, {"auto": 0, "single": 1, "pair": 2, "mfma": 3}),
     "spmm_sparse_kernel": (2, {"auto": 0, "scatter": 1, "gather": 2}),
     "nt_store": (3, {"auto": -1, "off": 0, "on": 1}),
-    "ranks_f32": (4, {"off": 0, "on": 1}),
+    "ranks_f32": (4, {"off": 0, "on": 1, "f64": 0, "f32": 1, "u16": 2}),   # staging of rank inputs (default 2 = u16)
     "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2}),
 }
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "plaidhip_geneset_destroy": [_vp],
     "plaidhip_geneset_info": [_vp, C.POINTER(_i64)],
     "plaidhip_dev_spmm_dense_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_spmm_ranks_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _vp],

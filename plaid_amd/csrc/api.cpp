@@ -240,7 +240,7 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
       ctx->opt_nt_store = value;
       break;
     case PLAIDHIP_OPT_RANKS_F32:
-      PH_REQUIRE(value == 0 || value == 1, "set_option: ranks_f32 %d (0, 1)", value);
+      PH_REQUIRE(value >= 0 && value <= 2, "set_option: ranks_f32 %d (0 fp64, 1 fp32 staging, 2 u16 staging)", value);
       ctx->opt_ranks_f32 = value;
       break;
     case PLAIDHIP_OPT_RANK_KERNEL:
@@ -371,6 +371,21 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(X), ldx, n, stat, alpha,
                                static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                                static_cast<uint32_t*>(flags));
+}
+
+int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,
+                                int64_t ldr, int32_t n, int stat, double alpha, const void* alpha_div,
+                                double beta, void* S, int64_t lds, void* flags) {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm_ranks: null geneset");
+  PH_REQUIRE(n >= 0, "spmm_ranks: n=%d", n);
+  PH_REQUIRE(n == 0 || (R != nullptr && S != nullptr), "spmm_ranks: null R/S");
+  PH_REQUIRE(ldr >= gs->g && lds >= gs->m, "spmm_ranks: leading dims ldr=%lld (g=%d) lds=%lld (m=%d)",
+             (long long)ldr, gs->g, (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_ranks: bad stat %d", stat);
+  return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(R), ldr, n, stat, alpha,
+                               static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
+                               static_cast<uint32_t*>(flags), PLAIDHIP_X_RANKS);
 }
 
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
@@ -640,13 +655,13 @@ int dense_average_ranks(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
 }
 
 int plaid_on_device(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* dX, int32_t g, int32_t n, int32_t m,
-                    int stat, int normalize, double* dS, DevBuf& dsmall) {
+                    int stat, int normalize, double* dS, DevBuf& dsmall, int x_kind = PLAIDHIP_X_ANY) {
   PH_TRY(dsmall.alloc(64 + (size_t)n * 8));
   uint32_t* d_flags = dsmall.as<uint32_t>();
   double* d_red = reinterpret_cast<double*>(dsmall.as<char>() + 16);
   double* d_med = reinterpret_cast<double*>(dsmall.as<char>() + 64);
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
-  PH_TRY(launch_spmm_dense_f64(ctx, gs, dX, g, n, stat, 1.0, nullptr, 0.0, dS, m, d_flags));
+  PH_TRY(launch_spmm_dense_f64(ctx, gs, dX, g, n, stat, 1.0, nullptr, 0.0, dS, m, d_flags, x_kind));
   if (normalize) PH_TRY(normalize_on_device(ctx, dS, m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));
   return PLAIDHIP_OK;
 }
@@ -670,7 +685,10 @@ int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, cons
   PH_TRY(launch_map(ctx, ri.R, (int64_t)g * n, 0, rmax + 1.0, ri.d_gmax));            // R/plaid.R:278
   DevBuf dS, dsmall, dadd;
   PH_TRY(dS.alloc((size_t)m * n * 8));
-  PH_TRY(plaid_on_device(ctx, gh.gs, ri.R, g, n, m, PLAIDHIP_STAT_MEAN, 1, dS.as<double>(), dsmall));   // :279
+  // pmin(max(rX) - rX, rmax + 1) of average ranks: still half-integers in [0, nrow(X)] when rmax + 1 is one
+  const double cap2 = 2.0 * (rmax + 1.0);
+  const int xk = (cap2 == std::floor(cap2) && cap2 < 65536.0) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY;
+  PH_TRY(plaid_on_device(ctx, gh.gs, ri.R, g, n, m, PLAIDHIP_STAT_MEAN, 1, dS.as<double>(), dsmall, xk));   // :279
   std::vector<double> add(m);
   for (int32_t j = 0; j < m; ++j) add[j] = 1.0 + (k_full[j] + 1.0) / (2.0 * rmax);   // :280
   PH_TRY(dadd.alloc((size_t)m * 8));
@@ -890,7 +908,7 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   PH_TRY(launch_max(ctx, d_colmax, n, d_gmax));
   PH_HIP(hipMemsetAsync(d_flags, 0, 16, ctx->stream));
   PH_TRY(launch_spmm_dense_f64(ctx, gh.gs, dR.as<double>(), ldg, n, PLAIDHIP_STAT_MEAN, 1.0, d_gmax, 0.0, dS.as<double>(),
-                               m, d_flags, /*x_exact_in_f32=*/!(tau > 0.0)));   // signed average ranks
+                               m, d_flags, tau > 0.0 ? PLAIDHIP_X_ANY : PLAIDHIP_X_EXACT_F32));   // signed average ranks
   PH_TRY(normalize_on_device(ctx, dS.as<double>(), m, n, PLAIDHIP_IGNORE_ZERO_AUTO, d_flags, true, d_med, d_red));   // :360 plaid()
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));

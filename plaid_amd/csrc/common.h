@@ -63,7 +63,7 @@ struct plaidhip_ctx {
   int opt_dense_kernel = 0;    // 0 auto | 1 one-column | 2 pair wherever it applies | 3 dense bf16x3 GEMM on MFMA
   int opt_sparse_kernel = 0;   // 0 auto | 1 scatter | 2 gather
   int opt_nt_store = -1;       // -1 auto | 0 | 1
-  int opt_ranks_f32 = 1;       // rank inputs take the fp32-staged crossprod
+  int opt_ranks_f32 = 2;       // rank inputs: 0 fp64 kernels | 1 fp32 staging | 2 u16 staging, integer sums (all exact)
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
   // pinned staging of the pipelined host uploads (multi.cpp): kFeeders feeder threads x 2 buffers, their streams
   static constexpr int kFeeders = 4;
@@ -220,7 +220,14 @@ void p_adjust_fdr(const double* p, int64_t m, double* q);
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags,
-                          bool x_exact_in_f32 = false);   // X holds (half-)integer ranks: fp32 staging loses nothing
+                          int x_kind = 0);   // PLAIDHIP_X_*: what the caller knows about the values of X
+// values of X as the internal callers know them (a compact exact staging is chosen from this, never a rounding one)
+enum { PLAIDHIP_X_ANY = 0,        // arbitrary doubles
+       PLAIDHIP_X_EXACT_F32 = 1,  // (half-)integers of magnitude <= 20,448, any sign (signed ranks): exact in fp32
+       PLAIDHIP_X_RANKS = 2 };    // what colranks returns: half-integers in [0, nrow(X)]: 2x is a u16
+// the crossprod of a rank matrix the rank kernel wrote as u16 (2 * rank; plaidhip_dev_colranks_dense_u16)
+int launch_spmm_ranks_u16(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const uint16_t* U, int64_t ldu, int32_t n, int stat,
+                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 int launch_spmm_mfma_f64(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n, int stat,
                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,

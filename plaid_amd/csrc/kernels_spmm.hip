@@ -1300,6 +1300,395 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Quad kernel for RANK-valued X (replaid.sing R/plaid.R:215-217, replaid.ssgsea(alpha = 0) :245-253, replaid.ucell
+// :277-279, replaid.aucell, replaid.gsva(tau = 0) on unsigned ranks): what `colranks` returns are half-integers in
+// [0.5, nrow(X)], so 2 * rank is an integer <= 40,896 for every column the LDS-resident kernels take -- a u16.
+// FOUR sample columns share one 8-byte LDS entry {2rA, 2rB, 2rC, 2rD}; one address op + one ds_read_b64 serve four
+// scores (2 bytes of LDS per score against 8 in the fp64 kernels and 4 with fp32 staging), the whole 20k-gene column
+// quad fits the LDS (no gene slices, no partial sums) and the sums are 32-bit integers: EXACT, independent of the
+// summation order, and -- after the one conversion sum / 2 in the epilogue -- bit-identical to what the fp64 kernels
+// produce (their sums of half-integers are exact too).  Same host schedule as the one-column kernel (32-lane halves
+// of ds_read_b64 against 32 bank pairs), same per-wave tile streams, same epilogue.
+// X arrives as the doubles `colranks` wrote (U16IN = false: four column streams, converted while staging with one
+// fp64 add per value: the low word of x + 2^51 is 2x) or as the u16 matrix plaidhip_dev_colranks_*_u16 wrote
+// (U16IN = true: a quarter of the bytes, the whole next quad prefetched in registers).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
+__device__ __forceinline__ u32x2 lds_u32x2_at(uint32_t byte_off) {
+  return *reinterpret_cast<lds_cu32x2*>(static_cast<uintptr_t>(byte_off));
+}
+// 2x of a half-integer 0 <= x < 2^31 as an integer: the ulp of x + 2^51 is 1/2, so its low mantissa word counts halves
+__device__ __forceinline__ uint32_t add_hi16(uint32_t acc, uint32_t v) {   // acc + (v >> 16) in one instruction
+  uint32_t r;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(acc), "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t twice_as_u32(double x) { return (uint32_t)__double2loint(x + 0x1p51); }
+
+struct SpmmQuadArgs {
+  SpmmArgs s;
+  const uint16_t* U;     // U16IN: 2 * rank, genes x samples column-major, leading dimension ldu (a multiple of 8)
+  int64_t ldu;
+};
+
+template <bool STAMP, bool U16IN>
+__global__ void __launch_bounds__(1024)
+spmm_colquad_u16(SpmmQuadArgs qa_) {
+  const SpmmArgs& a = qa_.s;
+  constexpr int BLOCK = 1024;
+  unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
+  if constexpr (STAMP) t_all0 = __builtin_amdgcn_s_memtime();
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  u32x2* ent = reinterpret_cast<u32x2*>(smem_raw);
+  {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t f = 0, chk = 0;
+  const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
+  const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
+  const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
+  const int ch_end = ((cptr_i32)a.wave_chunk_off)[wave + 1];
+  const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
+  const int nquads = (a.n + 3) >> 2;
+
+  // ---- staging ------------------------------------------------------------------------------------------------
+  // fp64 input: an "item" is 1,024 gene pairs: per thread one 16-byte load {x[2i], x[2i+1]} from each of the four
+  // columns -> two LDS entries, one ds_write_b128.  Items 0..5 of the NEXT quad are requested when the wavefront has
+  // finished its stream (their registers are free then); items 6..9 follow behind the barrier.
+  // u16 input: an item is 1,024 groups of 8 genes: one 16-byte load (8 ranks) per column and thread -> eight entries.
+  const int g2 = a.g >> 1;   // fp64: gene pairs
+  const int g8 = a.g >> 3;   // u16: groups of eight genes (the rest, < 8 genes, is staged by scalar code)
+  f64x2 pa0, pb0, pc0, pd0, pa1, pb1, pc1, pd1, pa2, pb2, pc2, pd2, pa3, pb3, pc3, pd3, pa4, pb4, pc4, pd4, pa5, pb5, pc5, pd5;
+  u32x4 ua0, ub0, uc0, ud0, ua1, ub1, uc1, ud1, ua2, ub2, uc2, ud2;
+  pa0 = pb0 = pc0 = pd0 = pa1 = pb1 = pc1 = pd1 = pa2 = pb2 = pc2 = pd2 = f64x2{0.0, 0.0};
+  pa3 = pb3 = pc3 = pd3 = pa4 = pb4 = pc4 = pd4 = pa5 = pb5 = pc5 = pd5 = f64x2{0.0, 0.0};
+  ua0 = ub0 = uc0 = ud0 = ua1 = ub1 = uc1 = ud1 = ua2 = ub2 = uc2 = ud2 = u32x4{0u, 0u, 0u, 0u};
+
+#define PLAIDHIP_QCOLS(qq_)                                                     \
+  const int c0_ = 4 * (qq_);                                                     \
+  const int c1_ = (c0_ + 1 < a.n) ? c0_ + 1 : c0_;                               \
+  const int c2_ = (c0_ + 2 < a.n) ? c0_ + 2 : c0_;                               \
+  const int c3_ = (c0_ + 3 < a.n) ? c0_ + 3 : c0_;
+#define PLAIDHIP_LD_F64(k, ra, rb, rc, rd)                                                                          \
+  {                                                                                                                  \
+    const bool in_ = (k + 1) * BLOCK <= g2 || (k * BLOCK < g2 && tid_o + k * BLOCK < g2);                            \
+    ra = rb = rc = rd = f64x2{0.0, 0.0};                                                                             \
+    if (in_) {                                                                                                       \
+      ra = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xa_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rb = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xb_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rc = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xc_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rd = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xd_ + (size_t)k * BLOCK * 16 + loff16));       \
+    }                                                                                                                \
+  }
+#define PLAIDHIP_ST_F64(k, ra, rb, rc, rd)                                                                           \
+  if (k * BLOCK < g2) {                                                                                              \
+    const int i_ = tid_o + k * BLOCK;                                                                                \
+    if (i_ < g2) {                                                                                                   \
+      const uint32_t a0_ = twice_as_u32(ra.x), b0_ = twice_as_u32(rb.x), c0v_ = twice_as_u32(rc.x), d0_ = twice_as_u32(rd.x); \
+      const uint32_t a1_ = twice_as_u32(ra.y), b1_ = twice_as_u32(rb.y), c1v_ = twice_as_u32(rc.y), d1_ = twice_as_u32(rd.y); \
+      chk |= (a0_ | b0_) | (c0v_ | d0_) | (a1_ | b1_) | (c1v_ | d1_);                                                \
+      ent4[i_] = u32x4{a0_ | (b0_ << 16), c0v_ | (d0_ << 16), a1_ | (b1_ << 16), c1v_ | (d1_ << 16)};                \
+    }                                                                                                                \
+  }
+#define PLAIDHIP_XPTRS_F64(qq_)                                                                      \
+  PLAIDHIP_QCOLS(qq_)                                                                                 \
+  const char* xa_ = reinterpret_cast<const char*>(a.X + (int64_t)c0_ * a.ldx);                        \
+  const char* xb_ = reinterpret_cast<const char*>(a.X + (int64_t)c1_ * a.ldx);                        \
+  const char* xc_ = reinterpret_cast<const char*>(a.X + (int64_t)c2_ * a.ldx);                        \
+  const char* xd_ = reinterpret_cast<const char*>(a.X + (int64_t)c3_ * a.ldx);
+  // u16: lane's 8 genes of column A as {A0|A1<<16, A2|A3<<16, A4|A5<<16, A6|A7<<16}
+#define PLAIDHIP_LD_U16(k, ra, rb, rc, rd)                                                                           \
+  {                                                                                                                  \
+    const bool in_ = (k + 1) * BLOCK <= g8 || (k * BLOCK < g8 && tid_o + k * BLOCK < g8);                            \
+    ra = rb = rc = rd = u32x4{0u, 0u, 0u, 0u};                                                                       \
+    if (in_) {                                                                                                       \
+      ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xa_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xc_ + (size_t)k * BLOCK * 16 + loff16));       \
+      rd = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xd_ + (size_t)k * BLOCK * 16 + loff16));       \
+    }                                                                                                                \
+  }
+  // {A_even | B_even << 16} = perm of the low halves, {A_odd | B_odd << 16} of the high halves (v_perm_b32)
+#define PLAIDHIP_LO2(x_, y_) __builtin_amdgcn_perm((y_), (x_), 0x05040100u)
+#define PLAIDHIP_HI2(x_, y_) __builtin_amdgcn_perm((y_), (x_), 0x07060302u)
+#define PLAIDHIP_ST_U16(k, ra, rb, rc, rd)                                                                           \
+  if (k * BLOCK < g8) {                                                                                              \
+    const int i_ = tid_o + k * BLOCK;                                                                                \
+    if (i_ < g8) {                                                                                                   \
+      ent4[4 * i_ + 0] = u32x4{PLAIDHIP_LO2(ra.x, rb.x), PLAIDHIP_LO2(rc.x, rd.x), PLAIDHIP_HI2(ra.x, rb.x), PLAIDHIP_HI2(rc.x, rd.x)}; \
+      ent4[4 * i_ + 1] = u32x4{PLAIDHIP_LO2(ra.y, rb.y), PLAIDHIP_LO2(rc.y, rd.y), PLAIDHIP_HI2(ra.y, rb.y), PLAIDHIP_HI2(rc.y, rd.y)}; \
+      ent4[4 * i_ + 2] = u32x4{PLAIDHIP_LO2(ra.z, rb.z), PLAIDHIP_LO2(rc.z, rd.z), PLAIDHIP_HI2(ra.z, rb.z), PLAIDHIP_HI2(rc.z, rd.z)}; \
+      ent4[4 * i_ + 3] = u32x4{PLAIDHIP_LO2(ra.w, rb.w), PLAIDHIP_LO2(rc.w, rd.w), PLAIDHIP_HI2(ra.w, rb.w), PLAIDHIP_HI2(rc.w, rd.w)}; \
+    }                                                                                                                \
+  }
+#define PLAIDHIP_XPTRS_U16(qq_)                                                                      \
+  PLAIDHIP_QCOLS(qq_)                                                                                 \
+  const char* xa_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c0_ * qa_.ldu);                    \
+  const char* xb_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c1_ * qa_.ldu);                    \
+  const char* xc_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c2_ * qa_.ldu);                    \
+  const char* xd_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c3_ * qa_.ldu);
+  // what a wavefront requests of the next quad when its stream is done
+#define PLAIDHIP_PREFETCH(qq_)                                                                        \
+  do {                                                                                                \
+    int tid_o = tid;                                                                                  \
+    asm volatile("" : "+v"(tid_o));                                                                   \
+    const uint32_t loff16 = (uint32_t)tid_o * 16u;                                                    \
+    if constexpr (U16IN) {                                                                            \
+      PLAIDHIP_XPTRS_U16(qq_)                                                                         \
+      PLAIDHIP_LD_U16(0, ua0, ub0, uc0, ud0) PLAIDHIP_LD_U16(1, ua1, ub1, uc1, ud1) PLAIDHIP_LD_U16(2, ua2, ub2, uc2, ud2) \
+    } else {                                                                                          \
+      PLAIDHIP_XPTRS_F64(qq_)                                                                         \
+      PLAIDHIP_LD_F64(0, pa0, pb0, pc0, pd0) PLAIDHIP_LD_F64(1, pa1, pb1, pc1, pd1) PLAIDHIP_LD_F64(2, pa2, pb2, pc2, pd2) \
+      PLAIDHIP_LD_F64(3, pa3, pb3, pc3, pd3) PLAIDHIP_LD_F64(4, pa4, pb4, pc4, pd4) PLAIDHIP_LD_F64(5, pa5, pb5, pc5, pd5) \
+    }                                                                                                 \
+  } while (0)
+
+  int q = blockIdx.x;
+  if (q < nquads) PLAIDHIP_PREFETCH(q);
+  for (; q < nquads; q += gridDim.x) {
+    const int cA = 4 * q;
+    const int ncol = (a.n - cA) < 4 ? (a.n - cA) : 4;   // columns of this quad that exist
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
+    {
+      int tid_o = tid;
+      asm volatile("" : "+v"(tid_o));
+      const uint32_t loff16 = (uint32_t)tid_o * 16u;
+      u32x4* ent4 = reinterpret_cast<u32x4*>(smem_raw);
+      if constexpr (U16IN) {
+        PLAIDHIP_XPTRS_U16(q)
+        PLAIDHIP_ST_U16(0, ua0, ub0, uc0, ud0) PLAIDHIP_ST_U16(1, ua1, ub1, uc1, ud1) PLAIDHIP_ST_U16(2, ua2, ub2, uc2, ud2)
+        // the genes behind the last whole group of eight (< 8; one thread each)
+        const int rest = a.g - 8 * g8;
+        if (tid_o < rest) {
+          const int i_ = 8 * g8 + tid_o;
+          const uint32_t va = reinterpret_cast<const uint16_t*>(xa_)[i_], vb = reinterpret_cast<const uint16_t*>(xb_)[i_];
+          const uint32_t vc = reinterpret_cast<const uint16_t*>(xc_)[i_], vd = reinterpret_cast<const uint16_t*>(xd_)[i_];
+          ent[i_] = u32x2{va | (vb << 16), vc | (vd << 16)};
+        }
+      } else {
+        PLAIDHIP_XPTRS_F64(q)
+        PLAIDHIP_ST_F64(0, pa0, pb0, pc0, pd0) PLAIDHIP_ST_F64(1, pa1, pb1, pc1, pd1) PLAIDHIP_ST_F64(2, pa2, pb2, pc2, pd2)
+        // items 6..8 take the registers of 0..2 while 3..5 are converted; item 9 follows
+        PLAIDHIP_LD_F64(6, pa0, pb0, pc0, pd0) PLAIDHIP_LD_F64(7, pa1, pb1, pc1, pd1) PLAIDHIP_LD_F64(8, pa2, pb2, pc2, pd2)
+        PLAIDHIP_ST_F64(3, pa3, pb3, pc3, pd3) PLAIDHIP_ST_F64(4, pa4, pb4, pc4, pd4) PLAIDHIP_ST_F64(5, pa5, pb5, pc5, pd5)
+        PLAIDHIP_LD_F64(9, pa3, pb3, pc3, pd3)
+        PLAIDHIP_ST_F64(6, pa0, pb0, pc0, pd0) PLAIDHIP_ST_F64(7, pa1, pb1, pc1, pd1) PLAIDHIP_ST_F64(8, pa2, pb2, pc2, pd2)
+        PLAIDHIP_ST_F64(9, pa3, pb3, pc3, pd3)
+        if ((a.g & 1) && tid_o == 0) {
+          const int64_t gl = a.g - 1;
+          const uint32_t va = twice_as_u32(reinterpret_cast<const double*>(xa_)[gl]), vb = twice_as_u32(reinterpret_cast<const double*>(xb_)[gl]);
+          const uint32_t vc = twice_as_u32(reinterpret_cast<const double*>(xc_)[gl]), vd = twice_as_u32(reinterpret_cast<const double*>(xd_)[gl]);
+          chk |= (va | vb) | (vc | vd);
+          ent[gl] = u32x2{va | (vb << 16), vc | (vd << 16)};
+        }
+      }
+      if (tid_o < kPadSlots) ent[a.g + tid_o] = u32x2{0u, 0u};
+    }
+    __syncthreads();
+    if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
+    const int nq = q + gridDim.x;
+    const bool want_pf = nq < nquads;
+
+    if (ch_begin < ch_end) {
+      gptr_u8 ibase = (gptr_u8)a.tile_idx + (int64_t)ch_begin * 1024;  // uniform
+      uint32_t lane_o = (uint32_t)lane;
+      asm volatile("" : "+v"(lane_o));
+      const uint32_t ioff = lane_o * 16u;
+      const uint32_t moff4 = lane_o * 4u, moff8 = lane_o * 8u;
+      const cptr_i32 wtile_end = (cptr_i32)a.wtile_end;
+#define PLAIDHIP_LOADQ(rel) (*(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff))
+#define PLAIDHIP_GATHER4A(qv)                                                \
+  va0 = lds_u32x2_at(off_lo((qv).x)); va1 = lds_u32x2_at(off_hi((qv).x));     \
+  va2 = lds_u32x2_at(off_lo((qv).y)); va3 = lds_u32x2_at(off_hi((qv).y));
+#define PLAIDHIP_GATHER4B(qv)                                                \
+  vb0 = lds_u32x2_at(off_lo((qv).z)); vb1 = lds_u32x2_at(off_hi((qv).z));     \
+  vb2 = lds_u32x2_at(off_lo((qv).w)); vb3 = lds_u32x2_at(off_hi((qv).w));
+      // Four u16 fields per gathered entry {lo | hi << 16, lo' | hi' << 16}.  Per dword two running sums: H = sum of the
+      // high fields (v_add_u32_sdwa: the field select is free) and T = sum of the WHOLE dwords modulo 2^32 (v_add3_u32:
+      // one instruction per two gathers); the low fields' sum is T - (H << 16) modulo 2^32, exact because it is < 2^32
+      // (<= 20,448 ranks of <= 40,896).  3 vector instructions per gather instead of 4 adds + 4 field extractions.
+#define PLAIDHIP_ACC2(v, w)                                                  \
+  tx = tx + (v).x + (w).x; ty = ty + (v).y + (w).y;                           \
+  hx = add_hi16(hx, (v).x); hx = add_hi16(hx, (w).x);                         \
+  hy = add_hi16(hy, (v).y); hy = add_hi16(hy, (w).y);
+#define PLAIDHIP_ADD4(V) PLAIDHIP_ACC2(V##0, V##1) PLAIDHIP_ACC2(V##2, V##3)
+#define PLAIDHIP_EPI(isum, cc)                                                 \
+  {                                                                            \
+    const double sum_ = 0.5 * (double)(isum);   /* exact */                    \
+    const double w_ = is_mean ? mw : 1.0;                                      \
+    const double v_ = alpha * (sum_ * w_) + a.beta * (mk * w_);                \
+    if (a.nt_store) __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);  \
+    else a.S[(int64_t)(cc) * a.lds + mj] = v_;                                 \
+    f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                              \
+    f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                            \
+    f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                              \
+  }
+#define PLAIDHIP_TILE_END(chv)                                                                 \
+  if ((chv) + 1 == next_end) { /* wave-uniform: tile finished -> epilogue */                   \
+    if (mj >= 0) {                                                                             \
+      PLAIDHIP_EPI(tx - (hx << 16), cA)                                                        \
+      if (ncol > 1) PLAIDHIP_EPI(hx, cA + 1)                                                   \
+      if (ncol > 2) PLAIDHIP_EPI(ty - (hy << 16), cA + 2)                                      \
+      if (ncol > 3) PLAIDHIP_EPI(hy, cA + 3)                                                   \
+    }                                                                                          \
+    ++k;                                                                                       \
+    next_end = wtile_end[k];                                                                   \
+    mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
+    mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
+    mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
+    tx = ty = hx = hy = 0u;                                                                    \
+  }
+      // 8 index chunks (8 KiB per wave) in flight: a chunk of this kernel is worth few cycles (3 vector instructions and
+      // one 8-byte LDS read per FOUR scores), so the index stream from L2 needs the depth to stay ahead
+      u32x4 qa = PLAIDHIP_LOADQ(0);
+      u32x4 qb = PLAIDHIP_LOADQ(1);
+      u32x4 qc = PLAIDHIP_LOADQ(2);
+      u32x4 qd = PLAIDHIP_LOADQ(3);
+      u32x4 qe = PLAIDHIP_LOADQ(4);
+      u32x4 qf = PLAIDHIP_LOADQ(5);
+      u32x4 qg = PLAIDHIP_LOADQ(6);
+      u32x4 qh = PLAIDHIP_LOADQ(7);
+      int k = tk_begin;
+      int next_end = wtile_end[k];
+      uint32_t tx = 0u, ty = 0u, hx = 0u, hy = 0u;
+      int mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);
+      double mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);
+      double mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
+      u32x2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+      // half-chunk software pipeline: the four gathers of the next half are in the LDS queue while the adds of the
+      // current half issue (spare chunks exist behind the stream: over-read ids are gathered, never added)
+      int ch = ch_begin;
+      ibase += 8 * 1024;
+#define PLAIDHIP_STEP(qcur, qnext, rel, chv)                                             \
+  PLAIDHIP_GATHER4B(qcur)                                                                \
+  qcur = PLAIDHIP_LOADQ(rel);                                                            \
+  PLAIDHIP_ADD4(va)                                                                      \
+  PLAIDHIP_GATHER4A(qnext)                                                               \
+  PLAIDHIP_ADD4(vb)                                                                      \
+  PLAIDHIP_TILE_END(chv)
+#define PLAIDHIP_STEP_TAIL(qcur, qnext)                                                  \
+  if (ch < ch_end) {                                                                     \
+    PLAIDHIP_GATHER4B(qcur) PLAIDHIP_ADD4(va) PLAIDHIP_GATHER4A(qnext) PLAIDHIP_ADD4(vb) \
+    PLAIDHIP_TILE_END(ch)                                                                \
+    ++ch;                                                                                \
+  }
+      PLAIDHIP_GATHER4A(qa)
+      for (; ch + 7 < ch_end; ch += 8, ibase += 8 * 1024) {
+        PLAIDHIP_STEP(qa, qb, 0, ch)
+        PLAIDHIP_STEP(qb, qc, 1, ch + 1)
+        PLAIDHIP_STEP(qc, qd, 2, ch + 2)
+        PLAIDHIP_STEP(qd, qe, 3, ch + 3)
+        PLAIDHIP_STEP(qe, qf, 4, ch + 4)
+        PLAIDHIP_STEP(qf, qg, 5, ch + 5)
+        PLAIDHIP_STEP(qg, qh, 6, ch + 6)
+        PLAIDHIP_STEP(qh, qa, 7, ch + 7)
+      }
+      PLAIDHIP_STEP_TAIL(qa, qb)
+      PLAIDHIP_STEP_TAIL(qb, qc)
+      PLAIDHIP_STEP_TAIL(qc, qd)
+      PLAIDHIP_STEP_TAIL(qd, qe)
+      PLAIDHIP_STEP_TAIL(qe, qf)
+      PLAIDHIP_STEP_TAIL(qf, qg)
+      PLAIDHIP_STEP_TAIL(qg, qh)
+#undef PLAIDHIP_STEP
+#undef PLAIDHIP_STEP_TAIL
+#undef PLAIDHIP_GATHER4A
+#undef PLAIDHIP_GATHER4B
+#undef PLAIDHIP_ACC2
+#undef PLAIDHIP_ADD4
+#undef PLAIDHIP_TILE_END
+#undef PLAIDHIP_EPI
+#undef PLAIDHIP_LOADQ
+    }
+    if (want_pf) {
+      PLAIDHIP_PREFETCH(nq);
+    } else {
+      pa0 = pb0 = pc0 = pd0 = pa1 = pb1 = pc1 = pd1 = pa2 = pb2 = pc2 = pd2 = f64x2{0.0, 0.0};
+      pa3 = pb3 = pc3 = pd3 = pa4 = pb4 = pc4 = pd4 = pa5 = pb5 = pc5 = pd5 = f64x2{0.0, 0.0};
+      ua0 = ub0 = uc0 = ud0 = ua1 = ub1 = uc1 = ud1 = ua2 = ub2 = uc2 = ud2 = u32x4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (STAMP) ts2 = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // the quad is overwritten by the next iteration
+    if constexpr (STAMP) {
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      t_stage += ts1 - ts0;
+      t_gather += ts2 - ts1;
+      t_wait += ts3 - ts2;
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && a.dbg != nullptr) {
+      unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (BLOCK / 64) + wave) * 4;
+      d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
+    }
+  }
+  // a value that is not a rank (2x does not fit 16 bits) was staged: the scores are wrong, say so (flags[3])
+  if (!U16IN) {
+    for (int off = 32; off >= 1; off >>= 1) chk |= __shfl_xor(chk, off, 64);
+    if (a.flags != nullptr && lane == 0 && (chk >> 16) != 0u)
+      __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  publish_flags(f, a.flags);
+#undef PLAIDHIP_PREFETCH
+#undef PLAIDHIP_QCOLS
+#undef PLAIDHIP_LD_F64
+#undef PLAIDHIP_ST_F64
+#undef PLAIDHIP_XPTRS_F64
+#undef PLAIDHIP_LD_U16
+#undef PLAIDHIP_ST_U16
+#undef PLAIDHIP_XPTRS_U16
+#undef PLAIDHIP_LO2
+#undef PLAIDHIP_HI2
+}
+
+// g <= kMaxLdsGenes and 2 g < 65,536 always hold for the one-slice plan (20,448 genes)
+static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs a, const uint16_t* U, int64_t ldu) {
+  const plaidhip_slice& sl = gs->slices[0];
+  a.g = sl.gs;
+  a.g0 = 0;
+  a.acc_mode = 0;
+  a.tile_idx = reinterpret_cast<const uint4*>(sl.d_tile_idx);
+  a.wave_chunk_off = sl.d_wave_chunk_off;
+  a.wave_tile_off = sl.d_wave_tile_off;
+  a.wtile_end = sl.d_wtile_end;
+  a.meta_j = sl.d_meta_j;
+  a.meta_w = sl.d_meta_w;
+  a.meta_k = sl.d_meta_k;
+  SpmmQuadArgs qa{a, U, ldu};
+  const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
+  int grid = ctx->num_cu;
+  const int nquads = (a.n + 3) / 4;
+  if (grid > nquads) grid = nquads;
+#ifdef PLAIDHIP_DIAG
+  if (g_ablate == 4) {   // in-kernel stamps
+    qa.s.dbg = g_dbg;
+    if (U != nullptr) {
+      PH_FULL_LDS(ctx, (&spmm_colquad_u16<true, true>));
+      hipLaunchKernelGGL((spmm_colquad_u16<true, true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
+    } else {
+      PH_FULL_LDS(ctx, (&spmm_colquad_u16<true, false>));
+      hipLaunchKernelGGL((spmm_colquad_u16<true, false>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
+    }
+  } else
+#endif
+  if (U != nullptr) {
+    PH_FULL_LDS(ctx, (&spmm_colquad_u16<false, true>));
+    hipLaunchKernelGGL((spmm_colquad_u16<false, true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
+  } else {
+    PH_FULL_LDS(ctx, (&spmm_colquad_u16<false, false>));
+    hipLaunchKernelGGL((spmm_colquad_u16<false, false>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
+  }
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 static int nt_store_mode(const plaidhip_ctx* ctx, const plaidhip_geneset* gs) {
   if (ctx->opt_nt_store >= 0) return ctx->opt_nt_store;
   return gs->rows_in_order ? 1 : 0;
@@ -1471,16 +1860,26 @@ static void fill_args(const plaidhip_ctx* ctx, SpmmArgs& a, const plaidhip_genes
 
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
-                          double beta, double* S, int64_t lds, uint32_t* flags, bool x_exact_in_f32) {
+                          double beta, double* S, int64_t lds, uint32_t* flags, int x_kind) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
   if (ctx->opt_dense_kernel == 3)   // opt-in: the dense contraction on the matrix cores (kernels_mfma.hip)
     return launch_spmm_mfma_f64(ctx, const_cast<plaidhip_geneset*>(gs), X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags);
-  // fp32 staging: opt-in, or free of any rounding when X holds ranks (integers / half-integers <= 20,448 are
-  // exact in fp32, and so are the four-term fp32 partial sums of the kernel: < 2^17 with one fractional bit)
-  if (!ctx->opt_ranks_f32) x_exact_in_f32 = false;   // PLAIDHIP_OPT_RANKS_F32 = 0: rank inputs stay on the fp64 kernels (tests compare the two)
-  if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && (g_ablate == 0 || g_ablate == 4) && (ldx & 1) == 0 &&
-      (reinterpret_cast<uintptr_t>(X) & 15) == 0 && gs->slices.size() == 1 && gs->slices[0].waves == 16) {
-    // opt-in: fp32 operand staging (plaidhip_set_precision); one gene slice and the 1024-thread schedule only
+  // Exact compact staging for rank inputs (PLAIDHIP_OPT_RANKS_F32: 0 keeps them on the fp64 kernels -- tests compare):
+  //   u16: X holds what colranks returns (half-integers <= nrow): 2x as u16, four columns per LDS entry, integer sums;
+  //   fp32: (half-)integers <= 20,448 of any sign are exact in fp32, and so are the four-term fp32 partial sums of the
+  //   kernel (< 2^17 with one fractional bit).  The opt-in mixed precision takes the fp32 kernel for any X.
+  const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16 && (ldx & 1) == 0 &&
+                            (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (g_ablate == 0 || g_ablate == 4);
+  if (x_kind == PLAIDHIP_X_RANKS && ctx->opt_ranks_f32 >= 2 && one_slice_16) {
+    SpmmArgs a{};
+    a.X = X;
+    a.ldx = ldx;
+    fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+    return launch_colquad(ctx, gs, a, nullptr, 0);
+  }
+  const bool x_exact_in_f32 = x_kind != PLAIDHIP_X_ANY && ctx->opt_ranks_f32 >= 1;
+  if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && one_slice_16) {
+    // fp32 operand staging; one gene slice and the 1024-thread schedule only
     SpmmArgs a{};
     a.X = X;
     a.ldx = ldx;
@@ -1500,6 +1899,18 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.ldx = ldx;
   fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
   return launch_colgather<false>(ctx, gs, a);
+}
+
+int launch_spmm_ranks_u16(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const uint16_t* U, int64_t ldu, int32_t n, int stat,
+                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
+  if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
+  if (!(gs->slices.size() == 1 && gs->slices[0].waves == 16 && (ldu & 7) == 0 && (reinterpret_cast<uintptr_t>(U) & 15) == 0)) {
+    set_error("spmm_ranks_u16: needs 8,192 < nrow(X) <= %d, ldu a multiple of 8 and a 16-byte aligned matrix", kMaxLdsGenes);
+    return PLAIDHIP_EUNSUPPORTED;
+  }
+  SpmmArgs a{};
+  fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  return launch_colquad(ctx, gs, a, U, ldu);
 }
 
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,

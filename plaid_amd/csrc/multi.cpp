@@ -338,7 +338,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, zx, stat, a, nullptr, b,
                                  dS.as<double>(), m, d_flags);
     return launch_spmm_dense_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags,
-                                 /*x_exact_in_f32=*/c.method == 1 || (c.method == 2 && c.alpha == 0.0));
+                                 (c.method == 1 || (c.method == 2 && c.alpha == 0.0)) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY);
   });
 
   // ---- normalize_medians (R/plaid.R:554-575): two more scalars --------------------------------------------------------

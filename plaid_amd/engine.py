@@ -121,6 +121,13 @@ class Context:
         check(self.lib.plaidhip_dev_spmm_dense_f64(self.handle, gs.handle, X, ldx, n, STAT[stat], alpha,
                                                    alpha_div, beta, S, lds, flags))
 
+    def dev_spmm_ranks(self, gs: Geneset, R: int, ldr: int, n: int, S: int, lds: int, stat="mean",
+                       alpha=1.0, beta=0.0, flags: int | None = None, alpha_div: int | None = None):
+        """the crossprod of a RANK matrix (what dev_colranks_dense wrote with power 1, unsigned): u16 staging, integer
+        sums -- bit-identical to dev_spmm_dense on the same input"""
+        check(self.lib.plaidhip_dev_spmm_ranks_f64(self.handle, gs.handle, R, ldr, n, STAT[stat], alpha,
+                                                   alpha_div, beta, S, lds, flags))
+
     def dev_spmm_csc(self, gs: Geneset, Xp: int, Xi: int, Xx: int, n: int, S: int, lds: int,
                      stat="mean", alpha=1.0, beta=0.0, flags: int | None = None,
                      alpha_div: int | None = None, nnz: int = -1):

@@ -44,7 +44,7 @@ def hip_ctx():
 @pytest.fixture
 def pinned_ctx(hip_ctx):
     """the session context with kernel-selection options pinned for one test (plaidhip_set_option), reset afterwards"""
-    defaults = {"spmm_dense_kernel": "auto", "spmm_sparse_kernel": "auto", "nt_store": "auto", "ranks_f32": 1,
+    defaults = {"spmm_dense_kernel": "auto", "spmm_sparse_kernel": "auto", "nt_store": "auto", "ranks_f32": 2,
                 "rank_kernel": "auto"}
 
     def pin(**opts):

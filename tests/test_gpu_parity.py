@@ -564,21 +564,70 @@ def test_spmm_mixed_precision_mode_is_opt_in_and_within_the_bar():
 
 def test_rank_inputs_take_the_fp32_staged_kernel_without_any_rounding(pinned_ctx):
     """replaid.sing / replaid.ssgsea(alpha = 0) / replaid.gsva(tau = 0) feed (half-)integer ranks <= 20,448 to the
-    crossprod: those are exact in fp32 and so are the kernel's four-term fp32 partial sums, so the fp32-staged
-    pair kernel is used for them by default and must give the fp64 kernels' scores BIT FOR BIT"""
+    crossprod.  Three stagings exist for them and all must give the fp64 kernels' scores BIT FOR BIT: u16 (2 * rank,
+    four samples per LDS entry, integer sums: the default for unsigned ranks), fp32 (exact for such values and for the
+    kernel's four-term fp32 partial sums: signed ranks take it), fp64."""
     from plaid_amd import synth as sy
     g, n, m = 20000, 9, 300
     Gp, Gi = sy.geneset_csc(g, m, sort_by_size=False)
     X = sy.dense_columns(g, 0, n, tied=True)
     outs = {}
-    for flag in ("1", "0"):
-        hip_ctx = pinned_ctx(ranks_f32=int(flag))
-        outs[flag] = (hip_ctx.sing_dense(X, Gp, Gi), hip_ctx.ssgsea_dense(X, Gp, Gi, 0.0), hip_ctx.gsva(X - 8.0, Gp, Gi, 0.0))
-    for a, b in zip(outs["1"], outs["0"]):
-        assert np.array_equal(a, b)
+    for flag in (2, 1, 0):
+        hip_ctx = pinned_ctx(ranks_f32=flag)
+        outs[flag] = (hip_ctx.sing_dense(X, Gp, Gi), hip_ctx.ssgsea_dense(X, Gp, Gi, 0.0), hip_ctx.gsva(X - 8.0, Gp, Gi, 0.0),
+                      hip_ctx.ucell(X, Gp, Gi, np.diff(Gp).astype(float)), hip_ctx.ucell(X, Gp, Gi, np.diff(Gp).astype(float), rmax=99.3))
+    for flag in (2, 1):
+        for a, b in zip(outs[flag], outs[0]):
+            assert np.array_equal(a, b)
     rn = [str(k) for k in range(g)]
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
-    close(outs["1"][0], _oracle().replaid_sing(X, rn, G, rn))
+    close(outs[2][0], _oracle().replaid_sing(X, rn, G, rn))
+
+
+@pytest.mark.parametrize("g,n,m", [(8193, 1, 70), (10001, 2, 130), (12345, 3, 64), (20000, 4, 700), (20000, 5, 5000),
+                                   (20448, 7, 333), (20447, 13, 65)])
+@pytest.mark.parametrize("ties", ["average", "min"])
+def test_rank_crossprod_u16_staging_is_bit_identical_to_fp64(g, n, m, ties):
+    """plaidhip_dev_spmm_ranks_f64 (u16 staging of 2 * rank, four sample columns per pass, integer sums) against
+    plaidhip_dev_spmm_dense_f64 on the same rank matrix: every quad tail (n mod 4), odd and maximal gene counts,
+    unsorted gene sets, mean and sum, the affine epilogue of replaid.sing -- equal bit for bit; and against the oracle"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    Gp, Gi = sy.geneset_csc(g, m, kmin=1, kmax=min(400, g), sort_by_size=(m % 2 == 0))
+    X = sy.dense_columns(g, 0, n, tied=(ties == "average"))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    ldg = g + (g & 1)
+    with torch.cuda.stream(stream):
+        Xd = torch.zeros((n, ldg), dtype=torch.float64, device=dev)
+        Xd[:, :g] = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+        R = torch.zeros_like(Xd)
+        S1 = torch.empty((n, m), dtype=torch.float64, device=dev)
+        S2 = torch.empty_like(S1)
+        f1 = torch.zeros(4, dtype=torch.int32, device=dev)
+        f2 = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.dev_colranks_dense(Xd.data_ptr(), ldg, g, n, R.data_ptr(), ldg, ties, False, 1.0, None)
+        for stat, al, be in (("mean", 1.0 / g, -0.5), ("sum", 1.0, 0.0)):
+            ctx.dev_spmm_ranks(gs, R.data_ptr(), ldg, n, S1.data_ptr(), m, stat, al, be, f1.data_ptr())
+            ctx.dev_spmm_dense(gs, R.data_ptr(), ldg, n, S2.data_ptr(), m, stat, al, be, f2.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(S1, S2), (stat, float((S1 - S2).abs().max()))
+            assert torch.equal(f1, f2) and int(f1[3]) == 0
+        # not a rank matrix: flagged, never silently wrong
+        f1.zero_()
+        ctx.dev_spmm_ranks(gs, Xd.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0, 0.0, f1.data_ptr())
+        Xd[0, 1] = 70000.0
+        ctx.dev_spmm_ranks(gs, Xd.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0, 0.0, f1.data_ptr())
+    torch.cuda.synchronize()
+    assert int(f1[3]) == 1
+    from oracle import c_oracle
+    Ro = c_oracle.colranks_dense(X, ties)
+    close(S2.cpu().numpy().T, c_oracle.crossprod_dense(Ro, Gp, Gi, "sum", 4))
+    gs.close()
+    ctx.close()
 
 
 # ---------------------------------------------------------------- the bucket ranker against the sorting network

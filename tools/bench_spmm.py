@@ -109,6 +109,38 @@ def main():
                   f"normalize {e2.elapsed_time(e3):.3f} ms  total {e0.elapsed_time(e3):.3f} ms -> "
                   f"{m*n/e0.elapsed_time(e3)/1e-3:.3e} scores/s")
         return
+    if a.kernel == "sing":
+        # crossprod of a rank matrix (replaid.sing) under the three exact stagings: u16 (default), fp32, fp64
+        X = torch.round((torch.randn((n, g), dtype=torch.float64, device=dev) * 2 + 8) * 10) / 10
+        R = torch.empty_like(X)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        ref = None
+        with torch.cuda.stream(stream):
+            ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, "average", False, 1.0, None)
+        for name in ("u16", "f32", "f64"):
+            ctx.set_option("ranks_f32", name)
+            ms = []
+            for it in range(a.iters + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    ctx.dev_spmm_ranks(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0 / g, -0.5, None)
+                    e1.record(stream)
+                torch.cuda.synchronize()
+                if it:
+                    ms.append(e0.elapsed_time(e1))
+            if ref is None:
+                ref = S.clone()
+            print(f"sing crossprod ({g}x{n}x{m}) staging {name}: min {min(ms):.3f} ms median {sorted(ms)[len(ms)//2]:.3f} ms "
+                  f"-> {m*n/min(ms)/1e-3:.3e} scores/s; bit-identical to u16: {bool(torch.equal(S, ref))}")
+            if dbg is not None and a.ablate == 4:
+                waves = info["waves"]
+                nwg = min((n + 3) // 4, 256)
+                d = dbg.cpu().numpy()[: nwg * waves * 4].reshape(nwg, waves, 4).astype(float)
+                tot = d[:, :, 3].mean()
+                print(f"  stamps: stage {100*d[:,:,0].mean()/tot:.1f}% gather {100*d[:,:,1].mean()/tot:.1f}% "
+                      f"end-barrier wait {100*d[:,:,2].mean()/tot:.1f}% total {tot:.0f} cycles")
+        return
     if a.kernel == "host_plaid":
         # PCIe-inclusive rate of the host-pointer entry point (what R's .Call binds)
         Xh = np.asfortranarray(np.random.default_rng(0).normal(8, 2, size=(g, n)))
