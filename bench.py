@@ -176,6 +176,44 @@ def _full_minmax(torch, Sraw):
     return float(Sraw.min().item()), bool((Sraw == 0).any().item())
 
 
+
+def _bench_gather(env, S, n_total, modes):
+    """reassemble the score matrix on rank 0 (R/plaid.R:110-119 fills ONE matrix): timed separately, never part of
+    `value`.  "host": every rank copies its block into its rows of one shared host matrix (completes at any size the
+    host can hold); "device": slabs peer->root over xGMI (fp64 when it fits the root's free HBM, else fp32).  A gather
+    that cannot complete is REFUSED before anything is allocated and reported as such -- never an exception."""
+    torch, dist, rank = env["torch"], env["dist"], env["rank"]
+    from plaid_amd import sharded
+    world = env["world"]
+    m = S.shape[1]
+    out = {}
+    for mode in modes:
+        for dt in ((None,) if mode == "host" else (None, torch.float32)):
+            key = mode if dt is None else f"{mode}_fp32"
+            if key == "device_fp32" and out.get("device", {}).get("completed"):
+                continue
+            try:
+                dist.barrier()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                full = sharded.gather_scores(S, n_total, dst=0, to=mode, dtype=dt)
+                torch.cuda.synchronize()
+                dist.barrier()
+                tg = time.perf_counter() - tg
+                item = 4 if dt is not None else 8
+                moved = (n_total - (S.shape[0] if mode == "device" else 0)) * m * item
+                out[key] = {"completed": True, "ms": round(1e3 * tg, 2), "GB": round(moved / 1e9, 2),
+                            "GB/s": round(moved / tg / 1e9, 1), "dtype": "f32" if dt is not None else "f64"}
+                del full
+            except sharded.GatherRefused as exc:
+                out[key] = {"completed": False, "refused": str(exc)[:300], "needed_GB": round(exc.needed / 1e9, 1),
+                            "available_GB": round(exc.available / 1e9, 1)}
+            torch.cuda.empty_cache()
+    out["note"] = ("GB = bytes that crossed a link (device: the peers' blocks into the root over xGMI; host: every block over "
+                   "its own PCIe link into one shared host matrix); not part of `value`")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- C2 (headline)
 def run_c2(a, env):
     import numpy as np
@@ -270,22 +308,7 @@ def run_c2(a, env):
         "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
     }
 
-    gather = None
-    if use_dist and not a.no_gather:
-        try:
-            from plaid_amd import sharded
-            dist.barrier()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            full = sharded.gather_scores(S, world * n, dst=0)   # grouped peer->root irecv/isend
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter() - tg
-            del full
-            nbytes = (world - 1) * S.numel() * 8
-            gather = {"ms": round(1e3 * tg, 3), "GB/s_into_root": round(nbytes / tg / 1e9, 1)}
-        except Exception as exc:  # pragma: no cover
-            gather = {"error": str(exc)[:200]}
+    gather = _bench_gather(env, S, world * n, ("device",)) if (use_dist and not a.no_gather) else None
 
     cpu = None
     parity = None
@@ -483,6 +506,8 @@ def run_sparse_ssgsea(a, env, n, label, collective):
             "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
     }
+    if collective and not a.no_gather:
+        out["gather"] = _bench_gather(env, S, world * n, ("host", "device"))
     if not collective and rank == 0 and a.cpu_sample > 0:
         from oracle import c_oracle
         nc = min(2048, n)
@@ -721,7 +746,7 @@ def main():
                 except Exception as exc:  # a failing secondary block must not take the headline line with it
                     blocks[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
                     torch.cuda.empty_cache()
-    elif a.config == "all":
+    elif a.config in ("all", "c3"):
         try:
             blocks["c5_shard"] = run_sparse_ssgsea(a, env, a.c5_cells_per_gpu, "C5 shard", True)
         except Exception as exc:

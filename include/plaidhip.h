@@ -232,8 +232,10 @@ int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
  * -- are combined on the host between the phases.  Nothing else crosses between devices (no RCCL).
  * `devices`: ndev distinct device ordinals, or NULL for 0 .. ndev-1.  X: dense g x n (Xp == NULL, X_or_x are
  * the doubles) or a dgCMatrix (Xp, Xi, X_or_x = @x).  The contexts are created on first use and kept by the
- * library until plaidhip_multi_finalize().  Results equal the single-device entry points bit for bit
- * (shards only change which device computes a column).                                                    */
+ * library until plaidhip_multi_finalize().  For dense X the results equal the single-device entry points bit
+ * for bit (shards only change which device computes a column).  For a dgCMatrix every sharding takes the same
+ * kernel (chosen from the density of the whole matrix); the sparse-aware scatter kernel adds in arrival order, so
+ * its scores agree to the last bits only (~1e-16 relative), between shardings as between two runs.             */
 int plaidhip_shard_bounds(int64_t n, int ndev, int k, int64_t* lo, int64_t* hi);   /* columns [lo, hi) of shard k */
 int plaidhip_plaid_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                          int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat,
@@ -243,6 +245,9 @@ int plaidhip_sing_multi(const int* devices, int ndev, const double* X, int32_t g
 int plaidhip_ssgsea_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                           int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
                           double* S_out);
+/* precision of the dense crossprod on the library-owned contexts of the *_multi entry points (plaidhip_set_precision's
+ * counterpart; default PLAIDHIP_PRECISION_F64) */
+int plaidhip_multi_set_precision(int mode);
 int plaidhip_multi_finalize(void);
 
 /* ---- "next" rows of the scope table: thin callers of the same two kernels --------------- */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "plaidhip_sing_multi": [_vp, _int, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_ssgsea_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_multi_finalize": [],
+    "plaidhip_multi_set_precision": [_int],
     "plaidhip_ucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _f64, _vp],
     "plaidhip_aucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],

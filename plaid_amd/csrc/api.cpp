@@ -66,11 +66,15 @@ int ctx_buffer(plaidhip_ctx* ctx, int k, size_t bytes, void** out) {
   return PLAIDHIP_OK;
 }
 
-int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask) {
-  const uint32_t bit = 1u << (ctx->device & 31);
-  if (*done_mask & bit) return PLAIDHIP_OK;
+int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, std::atomic<uint32_t>* done_mask) {
+  if (ctx->device >= 32) {   // no bit for it: set the attribute every time (idempotent)
+    PH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    return PLAIDHIP_OK;
+  }
+  const uint32_t bit = 1u << ctx->device;
+  if (done_mask->load(std::memory_order_acquire) & bit) return PLAIDHIP_OK;
   PH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-  *done_mask |= bit;
+  done_mask->fetch_or(bit, std::memory_order_release);
   return PLAIDHIP_OK;
 }
 

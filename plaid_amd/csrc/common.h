@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,7 @@ struct plaidhip_ctx {
   int opt_nt_store = -1;       // -1 auto | 0 | 1
   int opt_ranks_f32 = 2;       // rank inputs: 0 fp64 kernels | 1 fp32 staging | 2 u16 staging, integer sums (all exact)
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
+  int debug_fail_crossprod = 0;   // test hook (plaidhip_debug_sharded_on_one_device): this context's shard fails in the crossprod phase
   // pinned staging of the pipelined host uploads (multi.cpp): kFeeders feeder threads x 2 buffers, their streams
   static constexpr int kFeeders = 4;
   void* pin[kFeeders][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
@@ -190,10 +192,10 @@ int run_sharded(plaidhip_ctx* const* ctxs, int ndev, int method, const int32_t* 
                 int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double alpha,
                 double* S_out);
 // opt a kernel into the full 160 KiB of dynamic LDS, once per (kernel, device)
-int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, uint32_t* done_mask);
+int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, std::atomic<uint32_t>* done_mask);
 #define PH_FULL_LDS(ctx, kernel)                                                          \
   do {                                                                                    \
-    static uint32_t mask_ = 0;                                                            \
+    static std::atomic<uint32_t> mask_{0};   /* per call site; bit = device ordinal; host threads of several devices meet here */ \
     int rc_l_ = ::plaidhip::allow_full_lds((ctx), reinterpret_cast<const void*>(kernel), &mask_); \
     if (rc_l_ != PLAIDHIP_OK) return rc_l_;                                               \
   } while (0)

@@ -14,6 +14,8 @@
 //     lane of the accumulator tile is a set: 32 lanes store 32 neighbouring rows of S (column-major sets x samples).
 //   * operands staged through LDS with rows padded to 144 bytes (the four 16-lane groups of ds_read_b128 then hit
 //     16 distinct 16-byte slots: conflict-free), next K step prefetched into registers during the MFMAs.
+#include <mutex>
+
 #include "common.h"
 
 namespace plaidhip {
@@ -170,25 +172,33 @@ crossprod_mfma_bf16x3_kernel(MfmaArgs a) {
 
 // dense 0/1 membership, sets x genes, bf16, built on first use from the pattern kept with the gene-set collection
 static int ensure_dense_g(plaidhip_ctx* ctx, plaidhip_geneset* gs) {
+  // the lazily built matrix is the one mutable part of a prepared collection: built into local pointers, published
+  // (d_dense_g, dense_gk) only once every step has succeeded, under a lock
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   if (gs->d_dense_g != nullptr) return PLAIDHIP_OK;
   const int32_t gk = (gs->g + kMfmaBK - 1) / kMfmaBK * kMfmaBK;
   const int32_t mpad = (gs->m + kMfmaTile - 1) / kMfmaTile * kMfmaTile;
   const size_t bytes = (size_t)mpad * gk * 2;
-  int32_t *dGp = nullptr, *dGi = nullptr;
-  PH_HIP(hipMalloc(&gs->d_dense_g, bytes));
-  PH_HIP(hipMemsetAsync(gs->d_dense_g, 0, bytes, ctx->stream));
-  PH_HIP(hipMalloc(reinterpret_cast<void**>(&dGp), (size_t)(gs->m + 1) * 4));
-  PH_HIP(hipMalloc(reinterpret_cast<void**>(&dGi), std::max<size_t>(gs->h_Gi.size(), 1) * 4));
-  PH_HIP(hipMemcpyAsync(dGp, gs->h_Gp.data(), (size_t)(gs->m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  struct Tmp {   // freed on every exit path
+    void* p = nullptr;
+    ~Tmp() { if (p) hipFree(p); }
+  } dG, dGp, dGi;
+  PH_HIP(hipMalloc(&dG.p, bytes));
+  PH_HIP(hipMemsetAsync(dG.p, 0, bytes, ctx->stream));
+  PH_HIP(hipMalloc(&dGp.p, (size_t)(gs->m + 1) * 4));
+  PH_HIP(hipMalloc(&dGi.p, std::max<size_t>(gs->h_Gi.size(), 1) * 4));
+  PH_HIP(hipMemcpyAsync(dGp.p, gs->h_Gp.data(), (size_t)(gs->m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   if (!gs->h_Gi.empty())
-    PH_HIP(hipMemcpyAsync(dGi, gs->h_Gi.data(), gs->h_Gi.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(densify_sets_kernel, dim3(gs->m < 65535 ? gs->m : 65535), dim3(256), 0, ctx->stream, dGp, dGi, gs->m, gk,
-                     reinterpret_cast<__bf16*>(gs->d_dense_g));
+    PH_HIP(hipMemcpyAsync(dGi.p, gs->h_Gi.data(), gs->h_Gi.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(densify_sets_kernel, dim3(gs->m < 65535 ? gs->m : 65535), dim3(256), 0, ctx->stream,
+                     static_cast<const int32_t*>(dGp.p), static_cast<const int32_t*>(dGi.p), gs->m, gk,
+                     reinterpret_cast<__bf16*>(dG.p));
   PH_HIP(hipGetLastError());
   PH_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(dGp);
-  hipFree(dGi);
   gs->dense_gk = gk;
+  gs->d_dense_g = dG.p;
+  dG.p = nullptr;
   return PLAIDHIP_OK;
 }
 

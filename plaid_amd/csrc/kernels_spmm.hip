@@ -1049,6 +1049,21 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   a.dbg = g_dbg;
 #endif
   const size_t smem = (size_t)(sp.ch + kScatterTrash) * sizeof(double) + kScatterStage;
+  {
+    // the kernel reserves v120..v125 by hand (amdgpu_num_vgpr + one clobber): if a toolchain ever sized its register
+    // file differently it could not be launched with 1,024 threads -- say so here instead of failing at the launch
+    static std::atomic<int> checked{0};
+    if (checked.load(std::memory_order_acquire) == 0) {
+      hipFuncAttributes fa{};
+      PH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spmm_scatter_csc_f64)));
+      if (fa.maxThreadsPerBlock < 1024 || fa.numRegs > 128) {
+        set_error("spmm_scatter_csc_f64 was built with %d registers (max %d threads per workgroup): it needs <= 128 at 1,024 "
+                  "threads; rebuild with the toolchain of the Makefile", fa.numRegs, fa.maxThreadsPerBlock);
+        return PLAIDHIP_EUNSUPPORTED;
+      }
+      checked.store(1, std::memory_order_release);
+    }
+  }
   PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64));
   int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
   if (per_cu > 2) per_cu = 2;

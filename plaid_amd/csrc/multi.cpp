@@ -46,9 +46,11 @@ constexpr size_t kPanelBytes = (size_t)48 << 20;   // pinned staging buffer: 2 p
 
 int ensure_pinned(plaidhip_ctx* ctx) {
   if (ctx->pin_bytes >= kPanelBytes) return PLAIDHIP_OK;
+  // whatever a partial failure leaves behind stays recorded in the context (null-checked here, freed by plaidhip_finalize)
   for (int t = 0; t < plaidhip_ctx::kFeeders; ++t) {
-    for (int b = 0; b < 2; ++b) PH_HIP(hipHostMalloc(&ctx->pin[t][b], kPanelBytes, hipHostMallocDefault));
-    PH_HIP(hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b)
+      if (ctx->pin[t][b] == nullptr) PH_HIP(hipHostMalloc(&ctx->pin[t][b], kPanelBytes, hipHostMallocDefault));
+    if (ctx->copy_stream[t] == nullptr) PH_HIP(hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
   }
   ctx->pin_bytes = kPanelBytes;
   return PLAIDHIP_OK;
@@ -61,8 +63,9 @@ int ensure_pinned(plaidhip_ctx* ctx) {
 int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char* src, size_t row_bytes, int64_t cols,
                      const std::function<int(int64_t, int64_t)>& on_panel) {
   if (cols == 0 || row_bytes == 0) return PLAIDHIP_OK;
-  if (row_bytes * (size_t)cols < ((size_t)8 << 20) || ldd_bytes > kPanelBytes) {
-    // small (or absurdly wide) input: one plain copy
+  if (row_bytes * (size_t)cols < ((size_t)8 << 20) || 2 * ldd_bytes > kPanelBytes) {
+    // small input, or columns so long that a panel of two (the least the pair kernel takes) overflows a staging
+    // buffer: one plain copy
     if (ldd_bytes == row_bytes) {
       PH_HIP(hipMemcpyAsync(dst, src, row_bytes * (size_t)cols, hipMemcpyHostToDevice, ctx->stream));
     } else {
@@ -83,8 +86,13 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
     pb.push_back(std::min(cols, pb.back() + w));
   }
   const int64_t npan = (int64_t)pb.size() - 1;
-  std::vector<hipEvent_t> done((size_t)npan, nullptr);
-  for (auto& e : done) PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  struct Events {   // destroyed on every exit path
+    std::vector<hipEvent_t> v;
+    ~Events() { for (hipEvent_t e : v) if (e) hipEventDestroy(e); }
+    hipEvent_t& operator[](size_t i) { return v[i]; }
+  } done;
+  done.v.assign((size_t)npan, nullptr);
+  for (auto& e : done.v) PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   std::vector<std::atomic<int>> ready((size_t)npan);
   for (auto& r : ready) r.store(0, std::memory_order_relaxed);
   std::atomic<int> failed{0};
@@ -128,7 +136,6 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
     if (on_panel) rc = on_panel(pb[(size_t)p], pb[(size_t)p + 1]);
   }
   for (auto& t : th) t.join();
-  for (auto& e : done) hipEventDestroy(e);
   if (failed.load() != 0 && rc == PLAIDHIP_OK) {
     set_error("pipelined host-to-device copy failed (%s)", hipGetErrorString(hipGetLastError()));
     rc = PLAIDHIP_EHIP;
@@ -327,6 +334,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
 
   // ---- crossprod of the rank-based callers (plaid() did it per panel) ------------------------------------------------
   step([&]() -> int {
+    if (ctx->debug_fail_crossprod) { set_error("injected failure in the crossprod phase (test hook)"); return PLAIDHIP_EHIP; }
     if (nloc == 0) return PLAIDHIP_OK;
     if (c.method == 0 && !sparse) return PLAIDHIP_OK;
     double a = 1.0, b = 0.0;
@@ -334,9 +342,14 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     if (c.method == 1) { a = 1.0 / (double)g; b = -0.5; stat = PLAIDHIP_STAT_MEAN; }       // R/plaid.R:216
     if (c.method == 2) { a = 1.0 / gmax; b = -0.5; stat = PLAIDHIP_STAT_MEAN; }            // R/plaid.R:251
     const double* vals = ranks ? dR.as<double>() : dX.as<double>();
-    if (sparse)
-      return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, zx, stat, a, nullptr, b,
+    if (sparse) {
+      // scatter or gather is chosen from the density of the WHOLE matrix, not of the shard: every sharding of the same
+      // call takes the same kernel (the gather kernels are then bit-identical across shardings; the scatter kernel adds
+      // in arrival order and agrees to the last bits only, as it does from run to run)
+      const int64_t nnz_choice = (int64_t)((double)c.Xp[c.n] / (double)c.n * (double)nloc);
+      return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, nnz_choice, stat, a, nullptr, b,
                                  dS.as<double>(), m, d_flags);
+    }
     return launch_spmm_dense_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags,
                                  (c.method == 1 || (c.method == 2 && c.alpha == 0.0)) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY);
   });
@@ -445,6 +458,7 @@ namespace {
 
 std::mutex g_multi_mu;
 std::vector<plaidhip_ctx*> g_multi_ctx;   // one lazily created context per device, owned by the library
+int g_multi_precision = PLAIDHIP_PRECISION_F64;   // plaidhip_multi_set_precision: applies to these contexts
 
 int multi_contexts(const int* devices, int ndev, std::vector<plaidhip_ctx*>& out) {
   PH_REQUIRE(ndev >= 1 && ndev <= 64, "multi: ndev = %d", ndev);
@@ -458,6 +472,7 @@ int multi_contexts(const int* devices, int ndev, std::vector<plaidhip_ctx*>& out
     PH_REQUIRE(d >= 0 && d < count, "multi: device %d out of range [0, %d)", d, count);
     for (int q = 0; q < k; ++q) PH_REQUIRE((devices ? devices[q] : q) != d, "multi: device %d listed twice", d);
     if (g_multi_ctx[(size_t)d] == nullptr) PH_TRY(plaidhip_init(d, nullptr, &g_multi_ctx[(size_t)d]));
+    g_multi_ctx[(size_t)d]->precision = g_multi_precision;
     out.push_back(g_multi_ctx[(size_t)d]);
   }
   return PLAIDHIP_OK;
@@ -466,6 +481,36 @@ int multi_contexts(const int* devices, int ndev, std::vector<plaidhip_ctx*>& out
 }  // namespace
 
 extern "C" {
+
+// Test hook (not part of include/plaidhip.h): the multi-device engine with `nshards` contexts on ONE device -- worker
+// threads, rendezvous, cross-shard scalars and the failure path are what a 1-GPU box can exercise of plaidhip_*_multi.
+// method 0 plaid, 1 sing, 2 ssgsea; fail_shard >= 0: that shard fails in its crossprod phase (the call must return an
+// error, not hang).
+int plaidhip_debug_sharded_on_one_device(int device, int nshards, int fail_shard, int method, const int32_t* Xp,
+                                         const int32_t* Xi, const double* X_or_x, int32_t g, int32_t n, const int32_t* Gp,
+                                         const int32_t* Gi, int32_t m, int stat, int normalize, double alpha, double* S_out) {
+  PH_REQUIRE(nshards >= 1 && nshards <= 64, "debug_sharded: nshards = %d", nshards);
+  std::vector<plaidhip_ctx*> ctxs((size_t)nshards, nullptr);
+  int rc = PLAIDHIP_OK;
+  for (int k = 0; k < nshards && rc == PLAIDHIP_OK; ++k) {
+    rc = plaidhip_init(device, nullptr, &ctxs[(size_t)k]);
+    if (rc == PLAIDHIP_OK && k == fail_shard) ctxs[(size_t)k]->debug_fail_crossprod = 1;
+  }
+  if (rc == PLAIDHIP_OK)
+    rc = run_sharded(ctxs.data(), nshards, method, Xp, Xi, X_or_x, g, n, Gp, Gi, m, stat, normalize, alpha, S_out);
+  const std::string err = rc != PLAIDHIP_OK ? std::string(last_error_cstr()) : std::string();
+  for (plaidhip_ctx* c : ctxs)
+    if (c) plaidhip_finalize(c);
+  if (rc != PLAIDHIP_OK) set_error("%s", err.c_str());
+  return rc;
+}
+
+int plaidhip_multi_set_precision(int mode) {
+  PH_REQUIRE(mode == PLAIDHIP_PRECISION_F64 || mode == PLAIDHIP_PRECISION_MIXED, "multi_set_precision: bad mode %d", mode);
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  g_multi_precision = mode;
+  return PLAIDHIP_OK;
+}
 
 int plaidhip_multi_finalize(void) {
   std::lock_guard<std::mutex> lk(g_multi_mu);

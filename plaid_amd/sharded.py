@@ -104,14 +104,15 @@ class HipPhaseEngine:
     def new_flags(self):
         return self.torch.zeros(4, dtype=self.torch.int32, device=self.device)
 
-    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None):
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False):
+        """`ranks`: X is what colranks() wrote with power 1 (unsigned): the exact u16-staged crossprod takes it"""
         self._same_stream()
         t = self.torch
         n = X.shape[0]
         S = t.empty((n, self.gs.m), dtype=t.float64, device=self.device)
-        self.ctx.dev_spmm_dense(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta,
-                                flags.data_ptr() if flags is not None else None,
-                                alpha_div.data_ptr() if alpha_div is not None else None)
+        call = self.ctx.dev_spmm_ranks if ranks else self.ctx.dev_spmm_dense
+        call(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta,
+             flags.data_ptr() if flags is not None else None, alpha_div.data_ptr() if alpha_div is not None else None)
         return S
 
     def colranks(self, X, ties="average", signed=False, power=1.0):
@@ -152,13 +153,14 @@ def _world(group):
 
 
 def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
-                  group=None):
+                  group=None, x_is_ranks=False):
     """plaid() body (R/plaid.R:73-85) on this rank's sample shard; returns the local
     (n_local, m) score block.  Collective: every rank of `group` must call it."""
     import torch.distributed as dist
     world, _ = _world(group)
     flags = engine.new_flags()
-    S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags)
+    S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags, ranks=True) if x_is_ranks else \
+        engine.spmm(X_local, stat, alpha, beta, alpha_div, flags)
     if normalize:
         if world > 1:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)       # min(x) == 0 over all samples
@@ -201,7 +203,7 @@ def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
 def sharded_sing(engine, X_local, group=None):
     """replaid.sing (R/plaid.R:213-219): no cross-shard coupling at all."""
     R, _ = engine.colranks(X_local, "min")
-    return sharded_plaid(engine, R, "mean", False, 1.0 / X_local.shape[1], -0.5, None, group)
+    return sharded_plaid(engine, R, "mean", False, 1.0 / X_local.shape[1], -0.5, None, group, x_is_ranks=True)
 
 
 def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):
@@ -211,35 +213,163 @@ def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):
     R, gmax = engine.colranks(X_local, "average", False, 1.0 + alpha)
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-    return sharded_plaid(engine, R, "mean", True, 1.0, -0.5, gmax, group)
+    return sharded_plaid(engine, R, "mean", True, 1.0, -0.5, gmax, group, x_is_ranks=(alpha == 0.0))
 
 
-def gather_scores(S_local, n_total: int, dst: int = 0, group=None):
-    """Reassemble the (n_total, m) score matrix on `dst` from the per-rank blocks laid out by
-    shard_bounds(): direct peer->root transfers, one grouped batch of send/recv.  Returns the
-    full tensor on dst, None elsewhere."""
+class GatherRefused(RuntimeError):
+    """The requested gather cannot complete with the memory there is (code EUNSUPPORTED of the C ABI): nothing was
+    allocated or sent.  `.needed` / `.available` are in bytes."""
+
+    code = 4   # PLAIDHIP_EUNSUPPORTED
+
+    def __init__(self, message: str, needed: int, available: int):
+        super().__init__(f"plaidhip error 4: {message}")
+        self.needed, self.available = int(needed), int(available)
+
+
+def _free_device_bytes(t):
+    if t.is_cuda:
+        import torch
+        return int(torch.cuda.mem_get_info(t.device)[0])
+    return None
+
+
+def _free_shm_bytes(directory="/dev/shm"):
+    import os
+    st = os.statvfs(directory)
+    return int(st.f_bavail) * int(st.f_frsize)
+
+
+def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "device", dtype=None,
+                  chunk_rows: int | None = None, max_bytes: int | None = None, shm_dir: str = "/dev/shm"):
+    """Reassemble the (n_total, m) score matrix on `dst` from the per-rank blocks laid out by shard_bounds()
+    (the reference fills ONE matrix chunk by chunk, R/plaid.R:110-119).  Collective over `group`.
+
+    to="device"  direct peer->root transfers into one tensor on the root's device: each of the root's xGMI links carries
+                 one shard (a ring would be bound by a single link).  The blocks travel in slabs of `chunk_rows` rows,
+                 one grouped batch of send/recv per slab, so an optional cast (`dtype=torch.float32`: half the bytes on
+                 the links and on the root) needs a slab of scratch, not a second copy of the shard.  The root refuses
+                 (GatherRefused, EUNSUPPORTED) BEFORE allocating when n_total * m * itemsize exceeds its free device
+                 memory: config 5 (1e6 cells x 50,000 sets) is 400 GB in fp64 -- more than one GPU's 288 GB.
+    to="host"    every rank copies its block device->host into ITS rows of one host matrix shared between the processes
+                 (a file under `shm_dir`, unlinked once everyone has mapped it): each GPU uses its own PCIe link, no GPU
+                 ever holds more than its shard -- what completes at config 5.  Returns a numpy array on dst.
+    `max_bytes` overrides the free-memory probe (tests).  Returns the full matrix on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
     world, rank = _world(group)
-    if world == 1:
-        return S_local
-    m = S_local.shape[1]
+    if to not in ("device", "host"):
+        raise ValueError("gather_scores: to must be 'device' or 'host'")
+    out_dtype = dtype or S_local.dtype
+    m = int(S_local.shape[1])
+    itemsize = torch.empty((), dtype=out_dtype).element_size()
+    need = int(n_total) * m * itemsize
+    if world == 1 and to == "device":
+        return S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+    rows = chunk_rows or max(1, (256 << 20) // max(1, m * 8))          # ~256 MB slabs
+    if to == "host":
+        return _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, shm_dir, need)
+    # ---- device: the root decides, everyone learns the verdict (a refusal must not leave the peers in a send) ----
+    verdict = torch.zeros(2, dtype=torch.int64)
     if rank == dst:
-        full = torch.empty((n_total, m), dtype=S_local.dtype, device=S_local.device)
         lo, hi = shard_bounds(n_total, world, rank)
-        full[lo:hi].copy_(S_local)
-        ops = []
-        for src in range(world):
-            if src == dst:
-                continue
-            lo, hi = shard_bounds(n_total, world, src)
-            if hi > lo:
-                ops.append(dist.P2POp(dist.irecv, full[lo:hi], src, group))
+        have = max_bytes if max_bytes is not None else _free_device_bytes(S_local)
+        if have is not None and need > have:
+            verdict[0], verdict[1] = 1, have
+    if world > 1:
+        v = verdict.to(S_local.device) if dist.get_backend(group) == "nccl" else verdict
+        dist.broadcast(v, src=dst, group=group)
+        verdict = v.cpu()
+    if int(verdict[0]):
+        raise GatherRefused(f"gather_scores(to='device'): the {n_total} x {m} matrix needs {need / 1e9:.1f} GB on rank {dst}, "
+                            f"{int(verdict[1]) / 1e9:.1f} GB are free; use to='host' or dtype=torch.float32", need, int(verdict[1]))
+    full = None
+    if rank == dst:
+        full = torch.empty((n_total, m), dtype=out_dtype, device=S_local.device)
+        lo, hi = shard_bounds(n_total, world, rank)
+        for r0 in range(lo, hi, rows):
+            r1 = min(hi, r0 + rows)
+            full[r0:r1].copy_(S_local[r0 - lo:r1 - lo])
+    per = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
+    for s0 in range(0, per, rows):                       # slab s of every peer's block in one grouped batch
+        ops, keep = [], []
+        if rank == dst:
+            for src in range(world):
+                if src == dst:
+                    continue
+                lo, hi = shard_bounds(n_total, world, src)
+                r0, r1 = lo + s0, min(hi, lo + s0 + rows)
+                if r1 > r0:
+                    ops.append(dist.P2POp(dist.irecv, full[r0:r1], src, group))
+        else:
+            r0, r1 = s0, min(S_local.shape[0], s0 + rows)
+            if r1 > r0:
+                slab = S_local[r0:r1]
+                slab = slab.contiguous() if out_dtype == slab.dtype else slab.to(out_dtype)
+                keep.append(slab)
+                ops.append(dist.P2POp(dist.isend, slab, dst, group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return full
-    if S_local.shape[0] > 0:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, S_local.contiguous(), dst, group)]):
-            w.wait()
+    return full
+
+
+def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, shm_dir, need):
+    import os
+    import time
+    import torch
+    import torch.distributed as dist
+    world, rank = _world(group)
+    m = int(S_local.shape[1])
+    np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[out_dtype]
+    # the root creates the shared file (or refuses), everyone maps it
+    msg = [None]
+    if rank == dst:
+        have = max_bytes if max_bytes is not None else _free_shm_bytes(shm_dir)
+        if need > have:
+            msg[0] = ("refused", need, have)
+        else:
+            path = os.path.join(shm_dir, f"plaidhip_gather_{os.getpid()}_{time.time_ns()}")
+            mm = np.memmap(path, mode="w+", dtype=np_dtype, shape=(int(n_total), m))
+            msg[0] = ("ok", path)
+    if world > 1:
+        dist.broadcast_object_list(msg, src=dst, group=group)
+    if msg[0][0] == "refused":
+        raise GatherRefused(f"gather_scores(to='host'): the {n_total} x {m} matrix needs {msg[0][1] / 1e9:.1f} GB of shared host "
+                            f"memory under {shm_dir}, {msg[0][2] / 1e9:.1f} GB are free", msg[0][1], msg[0][2])
+    path = msg[0][1]
+    if rank != dst:
+        mm = np.memmap(path, mode="r+", dtype=np_dtype, shape=(int(n_total), m))
+    lo, hi = shard_bounds(n_total, world, rank)
+    nloc = hi - lo
+    if nloc > 0:
+        if S_local.is_cuda:
+            # two pinned slabs: the copy of slab k+1 runs on the bus while slab k is moved into the shared matrix
+            side = torch.cuda.Stream(device=S_local.device)
+            side.wait_stream(torch.cuda.current_stream(S_local.device))
+            pin = [torch.empty((min(rows, nloc), m), dtype=out_dtype).pin_memory() for _ in range(2)]
+            evs = [None, None]
+            slabs = [(r0, min(nloc, r0 + rows)) for r0 in range(0, nloc, rows)]
+
+            def issue(k):
+                r0, r1 = slabs[k]
+                with torch.cuda.stream(side):
+                    pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
+                    evs[k & 1] = torch.cuda.Event()
+                    evs[k & 1].record(side)
+            issue(0)
+            for k, (r0, r1) in enumerate(slabs):
+                evs[k & 1].synchronize()
+                if k + 1 < len(slabs):
+                    issue(k + 1)                                   # the other pinned slab
+                mm[lo + r0:lo + r1] = pin[k & 1][:r1 - r0].numpy()
+        else:
+            src = S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+            mm[lo:hi] = src.numpy()
+    if world > 1:
+        dist.barrier(group=group)
+    if rank == dst:
+        os.unlink(path)            # the mapping outlives the name: the memory goes when the array does
+        return mm
+    del mm
     return None

@@ -9,10 +9,16 @@
 ##                       context is first created)
 ##   plaidhip.devices    integer vector of GPU ordinals: with more than one, plaid() / replaid.sing() /
 ##                       replaid.ssgsea() shard the sample columns over them (a host thread per device inside
-##                       the library, no process per GPU); default: the session device alone
+##                       the library, no process per GPU); one ordinal: that GPU is the session device; default: the
+##                       session device alone.  plaidhip.precision applies to every device of the list.
 ##   plaidhip.precision  "f64" (default: scores equal to the last bits) or "mixed" (dense crossprod stages the
 ##                       sample columns as fp32, sums fp64; ~1e-7 relative, inside the 1e-5 bar; ~1.5x faster)
-.device <- function() as.integer(getOption("plaidhip.device", 0L))
+## a single ordinal in plaidhip.devices IS the session device (it used to be ignored in favour of plaidhip.device)
+.device <- function() {
+  d <- getOption("plaidhip.devices", NULL)
+  if (length(d) == 1L) return(as.integer(d))
+  as.integer(getOption("plaidhip.device", 0L))
+}
 .devices <- function() as.integer(getOption("plaidhip.devices", .device()))
 .session <- function() {
   prec <- match(getOption("plaidhip.precision", "f64"), c("f64", "mixed"))

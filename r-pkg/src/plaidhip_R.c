@@ -36,6 +36,7 @@ SEXP R_plaidhip_session(SEXP device, SEXP precision) {
   if (d != g_device && g_ctx != NULL) { plaidhip_finalize(g_ctx); g_ctx = NULL; }
   g_device = d;
   check(plaidhip_set_precision(ctx(), Rf_asInteger(precision)));
+  check(plaidhip_multi_set_precision(Rf_asInteger(precision)));   /* options(plaidhip.devices) with several GPUs */
   return R_NilValue;
 }
 

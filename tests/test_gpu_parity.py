@@ -898,6 +898,69 @@ def test_multi_device_entry_with_one_device_equals_the_context_entry(hip_ctx):
     plaid_amd.multi_finalize()
 
 
+@pytest.mark.parametrize("nshards", [2, 3, 5])
+def test_multi_device_engine_with_several_shards_on_one_gpu(hip_ctx, nshards):
+    """plaidhip_*_multi's engine with ndev >= 2 (what a 1-GPU box cannot reach through the public entry points): a test
+    hook runs it with `nshards` contexts on device 0 -- worker threads, rendezvous barriers, the cross-shard max(rX) /
+    flags / {sum, count} reductions, shards of unequal size, empty shards (n < nshards), and a shard that fails (the call
+    returns an error instead of hanging).  Dense input must equal the one-context result bit for bit; CSC input takes
+    the same kernel for every sharding (chosen from the global density) and is compared with the oracle tolerance."""
+    import ctypes as C
+    import plaid_amd
+    from plaid_amd import synth as sy
+    from plaid_amd._lib import load
+    lib = load()
+    fn = lib.plaidhip_debug_sharded_on_one_device
+    vp = C.c_void_p
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int, C.c_int,
+                   C.c_double, vp]
+
+    def run(method, X, Gp, Gi, stat=0, normalize=1, alpha=0.0, fail=-1, Xcsc=None):
+        g = X.shape[0] if Xcsc is None else Xcsc.shape[0]
+        n = X.shape[1] if Xcsc is None else Xcsc.shape[1]
+        m = len(Gp) - 1
+        S = np.full((m, n), np.nan, order="F")
+        if Xcsc is None:
+            Xf = np.asfortranarray(X)
+            rc = fn(0, nshards, fail, method, None, None, Xf.ctypes.data, g, n, Gp.ctypes.data, Gi.ctypes.data, m, stat,
+                    normalize, alpha, S.ctypes.data)
+        else:
+            p_, i_, x_ = (np.ascontiguousarray(Xcsc.indptr, dtype=np.int32), np.ascontiguousarray(Xcsc.indices, dtype=np.int32),
+                          np.ascontiguousarray(Xcsc.data, dtype=np.float64))
+            rc = fn(0, nshards, fail, method, p_.ctypes.data, i_.ctypes.data, x_.ctypes.data, g, n, Gp.ctypes.data,
+                    Gi.ctypes.data, m, stat, normalize, alpha, S.ctypes.data)
+        return rc, S
+
+    g, m = 9000, 150
+    Gp, Gi = sy.geneset_csc(g, m, kmax=300)
+    rn = [str(k) for k in range(g)]
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    for n in (1, nshards - 1, 2 * nshards + 1, 37):
+        X = sy.dense_columns(g, 0, n, tied=True)
+        rc, S = run(0, X, Gp, Gi)
+        assert rc == 0 and np.array_equal(S, hip_ctx.plaid_dense(X, Gp, Gi, "mean", True))
+        rc, S = run(1, X, Gp, Gi)
+        assert rc == 0 and np.array_equal(S, hip_ctx.sing_dense(X, Gp, Gi))
+        rc, S = run(2, X, Gp, Gi, alpha=0.25)
+        assert rc == 0 and np.array_equal(S, hip_ctx.ssgsea_dense(X, Gp, Gi, 0.25))
+        Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+        Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, n))
+        rc, S = run(0, None, Gp, Gi, Xcsc=Xs)
+        assert rc == 0
+        close(S, _oracle().plaid(Xs, rn, G, rn))
+        rc, S = run(2, None, Gp, Gi, alpha=0.25, Xcsc=Xs)
+        assert rc == 0
+        close(S, _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
+    # a failing shard: every worker still reaches every rendezvous, the call reports the failure
+    X = sy.dense_columns(g, 0, 37)
+    for fail in (0, nshards - 1):
+        rc, _ = run(2, X, Gp, Gi, alpha=0.25, fail=fail)
+        assert rc != 0
+        assert b"injected failure" in lib.plaidhip_last_error_string()
+    rc, S = run(0, X, Gp, Gi)                                          # and the engine is usable afterwards
+    assert rc == 0 and np.array_equal(S, hip_ctx.plaid_dense(X, Gp, Gi, "mean", True))
+
+
 def test_pipelined_host_upload_many_panels(hip_ctx):
     """a matrix larger than the pinned staging (several 48 MB panels per feeder thread, odd gene count so that the
     device leading dimension differs from nrow): the crossprod per landed panel gives the oracle's scores"""

@@ -400,3 +400,27 @@ def test_r_shim_is_consistent_without_r():
     exported = re.findall(r"[\w.]+", ns.split("export(")[1].split(")")[0])
     for fn in exported:
         assert re.search(r"^" + re.escape(fn) + r"\s*<-\s*function", rsrc, re.M), f"NAMESPACE exports {fn}, not defined"
+
+
+def test_host_code_is_clean_under_asan_and_ubsan():
+    """sanitizers on the CPU build.  `make host-asan` compiles the library's host code -- the index
+    planners of geneset.cpp (incl. a 50,000-set collection and every slice shape), the GMT parser / gmt2mat, the p-value
+    tails -- with g++ -fsanitize=address,undefined against host stand-ins for the HIP runtime and runs it; any report
+    aborts the binary."""
+    import subprocess
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "plaid_amd", "csrc"), "host-asan"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "[host-asan] ok" in out.stdout
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_r_shim_goes_through_a_c_compiler():
+    """r-pkg/src/plaidhip_R.c cannot be built here (no R): it is at least compiled (-fsyntax-only -Wall -Wextra) against
+    test-only declarations of the R API functions it uses and against include/plaidhip.h -- argument counts and types of
+    every plaidhip_* call, every registration entry, every PROTECT / allocMatrix use are checked by the compiler"""
+    import subprocess
+    out = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type",
+                          "-I" + os.path.join(ROOT, "tests", "r_api_stub"), "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "r-pkg", "src", "plaidhip_R.c")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]

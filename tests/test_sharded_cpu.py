@@ -29,7 +29,7 @@ class OraclePhaseEngine:
     def new_flags(self):
         return torch.zeros(4, dtype=torch.int32)
 
-    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None):
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False):
         Xn = X.numpy().T                                        # g x n_local
         raw = np.asarray(self.G.T @ Xn)
         w = 1.0 / (1e-8 + self.k) if stat == "mean" else np.ones_like(self.k)
@@ -113,8 +113,24 @@ def _worker(rank, world, port, n, case, out_path):
         res["plaid_csc"] = sharded.sharded_plaid_csc(eng, shard)
         res["ssgsea_csc"] = sharded.sharded_ssgsea_csc(eng, shard, alpha=0.25)
         full = {k: sharded.gather_scores(v, n, dst=0) for k, v in res.items()}
+        # the gathers that complete at config 5's size: slabs of a few rows, to the host (one shared matrix, every rank
+        # writes its rows) and to the device with an fp32 cast; and the refusals, raised on EVERY rank before any transfer
+        host = sharded.gather_scores(res["plaid"], n, dst=0, to="host", chunk_rows=3)
+        host32 = sharded.gather_scores(res["ssgsea"], n, dst=0, to="host", dtype=torch.float32, chunk_rows=2)
+        dev32 = sharded.gather_scores(res["plaid"], n, dst=0, dtype=torch.float32, chunk_rows=2)
+        dev_slabs = sharded.gather_scores(res["sing"], n, dst=0, chunk_rows=1)
+        refused = 0
+        for kw in ({"to": "device", "max_bytes": 8}, {"to": "host", "max_bytes": 8}):
+            try:
+                sharded.gather_scores(res["plaid"], n, dst=0, **kw)
+            except sharded.GatherRefused as exc:
+                refused += int(exc.code == 4 and exc.needed == n * 41 * 8 and exc.available == 8)
+        assert refused == 2
+        assert (host is None) == (rank != 0) and (dev32 is None) == (rank != 0)
         if rank == 0:
-            np.savez(out_path, **{k: v.numpy().T for k, v in full.items()})
+            assert isinstance(host, np.ndarray) and host.shape == (n, 41) and host32.dtype == np.float32
+            np.savez(out_path, host=np.asarray(host).T, host32=np.asarray(host32).T, dev32=dev32.numpy().T,
+                     dev_slabs=dev_slabs.numpy().T, **{k: v.numpy().T for k, v in full.items()})
     finally:
         dist.destroy_process_group()
 
@@ -133,6 +149,9 @@ def test_sharded_equals_unsharded_gloo(tmp_path, n, case):
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
     rn = [str(k) for k in range(g)]
     np.testing.assert_allclose(got["plaid"], po.plaid(X, rn, G, rn), rtol=1e-10, atol=1e-12)
+    assert np.array_equal(got["host"], got["plaid"]) and np.array_equal(got["dev_slabs"], got["sing"])
+    assert np.array_equal(got["dev32"], got["plaid"].astype(np.float32))
+    assert np.array_equal(got["host32"], got["ssgsea"].astype(np.float32))
     np.testing.assert_allclose(got["sing"], po.replaid_sing(X, rn, G, rn), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(got["ssgsea"], po.replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-10, atol=1e-12)
     Xz = np.where(np.random.default_rng(5).random(X.shape) < 0.85, 0.0, X)

@@ -1,0 +1,42 @@
+// Host stand-ins for the few HIP runtime calls the HOST-side code of the library makes (geneset.cpp's uploads, the
+// context helpers): "device" memory is plain heap memory, so AddressSanitizer sees every byte the planners upload.
+// Used only by `make -C plaid_amd/csrc host-asan` (g++ -fsanitize=address,undefined; no GPU, no hipcc): the sanitizers
+// are not available for device code on this pool, and the index planning, the GMT parser and the statistics tails are
+// host code anyway.  Never linked into libplaidhip.so.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../plaid_amd/csrc/common.h"
+
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "stub"; }
+}
+
+namespace plaidhip {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+int hip_fail(hipError_t, const char* what, const char* file, int line) {
+  set_error("%s failed at %s:%d", what, file, line);
+  return PLAIDHIP_EHIP;
+}
+const char* last_error_cstr() { return g_err.c_str(); }
+}  // namespace plaidhip
