@@ -93,7 +93,11 @@ enum plaidhip_option {
   PLAIDHIP_OPT_RANKS_F32 = 4,          /* staging of RANK inputs in the crossprod, all three exact and bit-identical:
                                           2 (default) u16 (2 * rank), four samples per LDS entry, integer sums |
                                           1 fp32 staging | 0 the fp64 kernels                                        */
-  PLAIDHIP_OPT_RANK_KERNEL = 5         /* 0 auto (default) | 1 sorting network | 2 bucket ranker                    */
+  PLAIDHIP_OPT_RANK_KERNEL = 5,        /* 0 auto (default) | 1 sorting network | 2 bucket ranker                    */
+  PLAIDHIP_OPT_SCATTER_FIXED = 6,      /* sparse-X scatter kernel, inputs declared bounded (rank weights): 1 (default) u64
+                                          fixed-point accumulators: exact integer sums, bit-reproducible | 0 fp64 atomics  */
+  PLAIDHIP_OPT_SCATTER_ORDER = 7       /* sparse-X scatter kernel: 1 (default) all workgroups on one chunk of sets at a
+                                          time (chunk, column order) | 0 column after column                              */
 };
 int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value);
 /* device memory helpers for hosts without a tensor library (R) */
@@ -147,6 +151,16 @@ int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                               const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                               const void* alpha_div, double beta, void* S, int64_t lds, void* flags);
+
+/* The sparse crossprod for RANK WEIGHTS: Rx is what plaidhip_dev_colranks_csc_f64 wrote (rank^power of the stored values,
+ * so 0 <= Rx <= *rmax, rmax = their maximum on the device -- the max(rX) replaid.ssgsea divides by, R/plaid.R:251: alpha is
+ * divided by it as by alpha_div).  Knowing the range, the scatter kernel sums in u64 fixed point: one rounding of each
+ * weight to a grid finer than the last bit an fp64 sum keeps, exact integer sums, so the scores do not depend on the order
+ * in which the LDS atomics arrive (plaidhip_dev_spmm_csc_f64's do, in their last bits).  A value outside [0, *rmax] sets
+ * flags[3].  rmax is required.                                                                                       */
+int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
+                                    const void* Xi, const void* Rx, int32_t n, int64_t nnz, int stat, double alpha,
+                                    const void* rmax, double beta, void* S, int64_t lds, void* flags);
 
 /* colranks(), dense branch: t(matrixStats::colRanks(as.matrix(X), ties.method))
  * (R/plaid.R:611-619); `is_signed` = sign(X)*rank(|X|) (R/plaid.R:612-615).  Optional fused

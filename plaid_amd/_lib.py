@@ -22,6 +22,8 @@ OPTIONS = {
     "nt_store": (3, {"auto": -1, "off": 0, "on": 1}),
     "ranks_f32": (4, {"off": 0, "on": 1, "f64": 0, "f32": 1, "u16": 2}),   # staging of rank inputs (default 2 = u16)
     "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2}),
+    "scatter_fixed": (6, {"off": 0, "on": 1}),
+    "scatter_order": (7, {"column": 0, "chunk": 1}),
 }
 
 
@@ -54,6 +56,7 @@ SIGNATURES = {
     "plaidhip_dev_spmm_dense_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_ranks_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_spmm_csc_ranks_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _vp],
     "plaidhip_dev_colranks_csc_dense_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],

@@ -247,6 +247,14 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
       PH_REQUIRE(value >= 0 && value <= 2, "set_option: ranks_f32 %d (0 fp64, 1 fp32 staging, 2 u16 staging)", value);
       ctx->opt_ranks_f32 = value;
       break;
+    case PLAIDHIP_OPT_SCATTER_FIXED:
+      PH_REQUIRE(value == 0 || value == 1, "set_option: scatter_fixed %d (0, 1)", value);
+      ctx->opt_scatter_fixed = value;
+      break;
+    case PLAIDHIP_OPT_SCATTER_ORDER:
+      PH_REQUIRE(value == 0 || value == 1, "set_option: scatter_order %d (0 column-major, 1 chunk-major)", value);
+      ctx->opt_scatter_order = value;
+      break;
     case PLAIDHIP_OPT_RANK_KERNEL:
       PH_REQUIRE(value >= 0 && value <= 2, "set_option: rank kernel %d (0 auto, 1 network, 2 bucket)", value);
       ctx->opt_rank_kernel = value;
@@ -411,6 +419,22 @@ static int check_ties(int ties) {
   PH_REQUIRE(ties == PLAIDHIP_TIES_AVERAGE || ties == PLAIDHIP_TIES_MIN || ties == PLAIDHIP_TIES_MAX,
              "colranks: unsupported ties.method code %d (average/min/max)", ties);
   return PLAIDHIP_OK;
+}
+
+int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
+                                    const void* Xi, const void* Rx, int32_t n, int64_t nnz, int stat, double alpha,
+                                    const void* rmax, double beta, void* S, int64_t lds, void* flags) {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm_csc_ranks: null geneset");
+  PH_REQUIRE(n >= 0, "spmm_csc_ranks: n=%d", n);
+  PH_REQUIRE(n == 0 || (Xp != nullptr && S != nullptr), "spmm_csc_ranks: null Xp/S");
+  PH_REQUIRE(rmax != nullptr, "spmm_csc_ranks: rmax (device double: the maximum of Rx) is required");
+  PH_REQUIRE(lds >= gs->m, "spmm_csc_ranks: lds=%lld < m=%d", (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_csc_ranks: bad stat %d", stat);
+  return launch_spmm_csc_f64(ctx, gs, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
+                             static_cast<const double*>(Rx), n, nnz, stat, alpha, static_cast<const double*>(rmax), beta,
+                             static_cast<double*>(S), lds, static_cast<uint32_t*>(flags), /*bounded=*/true,
+                             static_cast<const double*>(rmax), 0.0);
 }
 
 int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ldx, int32_t g,

@@ -66,6 +66,8 @@ struct plaidhip_ctx {
   int opt_nt_store = -1;       // -1 auto | 0 | 1
   int opt_ranks_f32 = 2;       // rank inputs: 0 fp64 kernels | 1 fp32 staging | 2 u16 staging, integer sums (all exact)
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
+  int opt_scatter_fixed = 1;   // scatter kernel: u64 fixed-point accumulators for inputs declared bounded (rank weights)
+  int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
   int debug_fail_crossprod = 0;   // test hook (plaidhip_debug_sharded_on_one_device): this context's shard fails in the crossprod phase
   // pinned staging of the pipelined host uploads (multi.cpp): kFeeders feeder threads x 2 buffers, their streams
   static constexpr int kFeeders = 4;
@@ -141,6 +143,7 @@ struct plaidhip_pair_plan {
 // consecutive (chunk, gene) pairs are contiguous.)
 struct plaidhip_scatter_plan {
   int32_t ch = 0, nch = 0;
+  int32_t kbits = 0;           // bits of the largest set size + 1: headroom of the fixed-point sums
   int64_t nseg = 0;
   int32_t* d_seg = nullptr;
   uint16_t* d_ids = nullptr;
@@ -235,10 +238,13 @@ int launch_spmm_mfma_f64(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* 
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
-                                bool auto_select);
+                                bool auto_select, bool bounded = false, const double* xmax_dev = nullptr, double xmax_host = 0.0);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz /* -1: unknown */, int stat, double alpha,
-                        const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
+                        const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                        // bounded: every stored value lies in [0, xmax] (rank weights; xmax = max(rX) on the device, or on
+                        // the host when xmax_dev is null): the scatter kernel may use exact fixed-point accumulators
+                        bool bounded = false, const double* xmax_dev = nullptr, double xmax_host = 0.0);
 #ifdef PLAIDHIP_DIAG
 void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ build only, make diag)
 void debug_set_rank_stamps(void* dbg);          // per-phase cycle stamps of the bucket rank kernel

@@ -640,6 +640,12 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     // 1.7x SLOWER -- the passes are bound by their chains of dependent loads, not by L2 misses.)
     sp.ch = std::min<int32_t>((m + 15) & ~15, kScatterChunk);   // multiple of 16: the trash slots keep their banks
     sp.nch = (m + sp.ch - 1) / sp.ch;
+    {
+      int32_t kmax = 1;
+      for (int32_t j = 0; j < m; ++j) kmax = std::max(kmax, Gp[j + 1] - Gp[j]);
+      sp.kbits = 1;
+      while (((int64_t)1 << sp.kbits) <= (int64_t)kmax) ++sp.kbits;   // kmax < 2^kbits
+    }
     std::vector<int32_t> cnt((size_t)sp.nch * g, 0);
     for (int32_t j = 0; j < m; ++j)
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) ++cnt[(size_t)(j / sp.ch) * g + Gi[p]];

@@ -693,6 +693,13 @@ struct ScatterArgs {
   double* S;
   int64_t lds;
   uint32_t* flags;
+  int32_t chunk_major;       // item order: 0 (column, chunk, round) | 1 (chunk, column, round): every workgroup is on the
+                             // same chunk of sets at the same time, so the id lists in use are one chunk's (a third of them)
+  // FIXED (u64 fixed-point accumulators, for inputs known to lie in [0, xmax]: rank weights): xmax on the device
+  // (the max(rX) the caller also divides by) or, when null, on the host; kbits = bits of the largest set size
+  const double* xmax_dev;
+  double xmax_host;
+  int32_t kbits;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
 };
 
@@ -716,6 +723,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// FIXED: the accumulators are u64 fixed-point numbers (ds_add_u64: 6.0 cycles per wave-instruction against 8.05 for
+// ds_add_f64, tools/ubench/lds_atomics.hip).  For inputs in [0, xmax] -- the rank weights rank^(1 + alpha) of
+// replaid.ssgsea, xmax = max(rX) -- the scale 2^e is chosen so that the largest possible sum (the largest set size x xmax)
+// stays below 2^63; a value is rounded ONCE to that grid (2^-e is at most half an ulp of xmax / 2^(kbits): finer than the
+// last bit the fp64 sum would keep), the integer sums are exact, so the score does not depend on the order in which the
+// LDS atomics arrive: bit-reproducible from run to run, which the fp64 atomics are not.
+template <bool FIXED>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
 spmm_scatter_csc_f64(ScatterArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -731,7 +745,17 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  for (int i = tid; i < a.ch + kScatterTrash; i += 1024) acc[i] = 0.0;
+  double fx_scale = 1.0, fx_inv = 1.0, fx_max = 0.0;
+  uint32_t fx_bad = 0;
+  if constexpr (FIXED) {
+    fx_max = (a.xmax_dev != nullptr) ? *a.xmax_dev : a.xmax_host;
+    int q = 0;
+    if (fx_max > 0.0 && fx_max < 1e300) (void)frexp(fx_max, &q);     // xmax < 2^q
+    const int e = 63 - q - a.kbits;
+    fx_scale = ldexp(1.0, e);
+    fx_inv = ldexp(1.0, -e);
+  }
+  for (int i = tid; i < a.ch + kScatterTrash; i += 1024) acc[i] = 0.0;   // (all-zero bits: 0 in either number format)
   __syncthreads();
   const uint32_t* __restrict__ idw = reinterpret_cast<const uint32_t*>(a.ids);   // two u16 ids per lane and load
   // one dword = two u16 accumulator ids per lane -> two ds_add_f64 wave-instructions.  No compare and no branch
@@ -740,13 +764,22 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   // The accumulators start at LDS address 0, so id << 3 IS the LDS address.  (Plain C on purpose: next to an inline-asm
   // statement hipcc stops counting vmcnt and drains every load in flight, which would serialise the double buffer.)
   typedef __attribute__((address_space(3))) double lds_f64;
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  // (FIXED: `val` carries the bits of the u64 fixed-point value in a double, see the conversion where v is set)
+#define PLAIDHIP_ADD_AT(addr_, val)                                                                              \
+  {                                                                                                              \
+    if constexpr (FIXED)                                                                                         \
+      __hip_atomic_fetch_add(reinterpret_cast<lds_u64*>(static_cast<uintptr_t>(addr_)),                          \
+                             (unsigned long long)__double_as_longlong(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    else                                                                                                         \
+      __hip_atomic_fetch_add(reinterpret_cast<lds_f64*>(static_cast<uintptr_t>(addr_)), (val), __ATOMIC_RELAXED, \
+                             __HIP_MEMORY_SCOPE_WORKGROUP);                                                      \
+  }
 #define PLAIDHIP_SCATTER2(id2, val)                                                                              \
   {                                                                                                              \
-    __hip_atomic_fetch_add(reinterpret_cast<lds_f64*>(static_cast<uintptr_t>(((id2) & 0xffffu) << 3)), (val),    \
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                      \
+    PLAIDHIP_ADD_AT(((id2) & 0xffffu) << 3, val)                                                                 \
     if (((uint32_t)__builtin_amdgcn_readfirstlane((int)(id2)) >> 16) != 0xffffu)                                 \
-      __hip_atomic_fetch_add(reinterpret_cast<lds_f64*>(static_cast<uintptr_t>(((id2) >> 16) << 3)), (val),      \
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                    \
+      PLAIDHIP_ADD_AT(((id2) >> 16) << 3, val)                                                                   \
   }
   // The id segments a wavefront has to apply are a flat work list: lane u holds stored value u of its 64 and the
   // segment range [s0, s1) of that value's gene in the current chunk; "pass" p takes segment s0 + p of every lane
@@ -852,7 +885,8 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
       const int i = tid_e + u * 1024;                                                               \
       if (i < nj) {                                                                                 \
-        const double sum = acc[i];                                                                  \
+        double sum = acc[i];                                                                        \
+        if constexpr (FIXED) sum = (double)(unsigned long long)__double_as_longlong(sum) * fx_inv;  \
         acc[i] = 0.0;                                                                               \
         const double wj = is_mean ? kwv[u].y : 1.0;                                                 \
         const double val = alpha * (sum * wj) + a.beta * (kwv[u].x * wj);                           \
@@ -896,6 +930,11 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   if (c_ < a.n) {                                                                                       \
     if (r_ + 1 < PLAIDHIP_ITEM_ROUNDS(q0_, q1_)) {                                                      \
       ++r_;                                                                                             \
+    } else if (a.chunk_major) { /* next column of this workgroup; behind the last one, its first column in the next chunk */ \
+      r_ = 0;                                                                                           \
+      c_ += gridDim.x;                                                                                  \
+      if (c_ >= a.n) { ++ch_; c_ = (ch_ < a.nch) ? (int)blockIdx.x : a.n; }                             \
+      if (c_ < a.n) { q0_ = ((cptr_i32)a.Xp)[c_]; q1_ = ((cptr_i32)a.Xp)[c_ + 1]; }                     \
     } else {                                                                                            \
       r_ = 0;                                                                                           \
       if (ch_ + 1 < a.nch) {                                                                            \
@@ -955,6 +994,10 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     PLAIDHIP_ITEM_MINE(rr, q0, q1, qi_cur, have)
     const int ns = have ? s1 - s0 : 0;
     if (!have) v = 0.0;
+    if constexpr (FIXED) {   // one rounding to the fixed-point grid; values outside [0, xmax] (or NaN) are not rank weights
+      fx_bad |= (v >= 0.0 && v <= fx_max) ? 0u : 1u;
+      v = __longlong_as_double((long long)__double2ull_rn(v * fx_scale));
+    }
     const bool n1_loads = c1 < a.n, n2_loads = c2 < a.n && q12 > q02;
     // requests for the items behind this one (before the walk's own loads: vmcnt retires in order)
     if (n1_loads) PLAIDHIP_ASM_LOAD_SEG(a.seg + (int64_t)chunk1 * a.g + gene1);
@@ -1006,7 +1049,13 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_WALK_SEGMENTS
 #undef PLAIDHIP_CHUNK_EPILOGUE
 #undef PLAIDHIP_EPI_PREFETCH
+  if constexpr (FIXED) {   // an input outside [0, xmax]: the scores are meaningless, say so (flags[3])
+    for (int off = 32; off >= 1; off >>= 1) fx_bad |= __shfl_xor(fx_bad, off, 64);
+    if (a.flags != nullptr && lane == 0 && fx_bad != 0u)
+      __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   publish_flags(f, a.flags);
+#undef PLAIDHIP_ADD_AT
 #undef PLAIDHIP_SCATTER2
 #undef PLAIDHIP_FETCH_GROUP
 #undef PLAIDHIP_LOAD_GROUP
@@ -1020,9 +1069,14 @@ static int sparse_mode(const plaidhip_ctx* ctx) { return ctx->opt_sparse_kernel;
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
-                                bool auto_select) {
+                                bool auto_select, bool bounded, const double* xmax_dev, double xmax_host) {
   const plaidhip_scatter_plan& sp = gs->scatter;
   ScatterArgs a{};
+  const bool fixed = bounded && ctx->opt_scatter_fixed != 0;
+  a.chunk_major = ctx->opt_scatter_order;
+  a.xmax_dev = xmax_dev;
+  a.xmax_host = xmax_host;
+  a.kbits = sp.kbits;
   a.Xp = Xp;
   a.Xi = Xi;
   a.Xx = Xx;
@@ -1055,7 +1109,11 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
     static std::atomic<int> checked{0};
     if (checked.load(std::memory_order_acquire) == 0) {
       hipFuncAttributes fa{};
-      PH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spmm_scatter_csc_f64)));
+      hipFuncAttributes fb{};
+      PH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<false>)));
+      PH_HIP(hipFuncGetAttributes(&fb, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<true>)));
+      if (fb.numRegs > fa.numRegs) fa.numRegs = fb.numRegs;
+      if (fb.maxThreadsPerBlock < fa.maxThreadsPerBlock) fa.maxThreadsPerBlock = fb.maxThreadsPerBlock;
       if (fa.maxThreadsPerBlock < 1024 || fa.numRegs > 128) {
         set_error("spmm_scatter_csc_f64 was built with %d registers (max %d threads per workgroup): it needs <= 128 at 1,024 "
                   "threads; rebuild with the toolchain of the Makefile", fa.numRegs, fa.maxThreadsPerBlock);
@@ -1064,13 +1122,15 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
       checked.store(1, std::memory_order_release);
     }
   }
-  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64));
+  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<false>));
+  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<true>));
   int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
   if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > n) grid = n;
-  hipLaunchKernelGGL(spmm_scatter_csc_f64, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  if (fixed) hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  else hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }
@@ -1930,7 +1990,8 @@ int launch_spmm_ranks_u16(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const u
 
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz, int stat, double alpha,
-                        const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
+                        const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                        bool bounded, const double* xmax_dev, double xmax_host) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
   if ((g_ablate == 0 || g_ablate == 100) && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
     // sparse-aware scatter or dense-work gather.  With nnz(X) from the caller the choice is made here (one
@@ -1939,7 +2000,8 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
     int sm = sparse_mode(ctx);
     if (sm == 0 && nnz >= 0) sm = (nnz * 8 < (int64_t)gs->g * n) ? 1 : 2;
     if (sm != 2) {
-      const int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);
+      const int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0,
+                                                 bounded, xmax_dev, xmax_host);
       if (rc != PLAIDHIP_OK || sm == 1) return rc;
     }
     return launch_colpair(ctx, gs, nullptr, 0, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);

@@ -173,7 +173,7 @@ struct Shared {
   double gmax = 0.0;               // max(rX) over all shards
   bool gmax_set = false;
   uint32_t flags[4] = {0, 0, 0, 0};
-  double med_sum = 0.0, med_cnt = 0.0;
+  std::vector<double> med_all;     // medx of every sample column, global column order (each shard writes its block)
   std::atomic<int> abort{0};
 };
 
@@ -213,6 +213,20 @@ struct CtxBuf {
 #else
 #define PH_TRACE(tag) do { } while (0)
 #endif
+
+// {sum, count} of the non-NaN entries of v in exactly the order of sum_kernel (kernels_norm.hip): 1,024 strided partial
+// sums, then a halving tree -- IEEE additions in the same order give the same bits on the host
+double mean_like_device_sum(const double* v, int64_t count) {
+  std::vector<double> s(1024, 0.0), cnt(1024, 0.0);
+  for (int t = 0; t < 1024; ++t)
+    for (int64_t i = t; i < count; i += 1024) {
+      const double x = v[i];
+      if (x == x) { s[(size_t)t] += x; cnt[(size_t)t] += 1.0; }
+    }
+  for (int h = 512; h >= 1; h >>= 1)
+    for (int t = 0; t < h; ++t) { s[(size_t)t] += s[(size_t)(t + h)]; cnt[(size_t)t] += cnt[(size_t)(t + h)]; }
+  return s[0] / cnt[0];
+}
 
 int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) {
   int rc = PLAIDHIP_OK;
@@ -347,8 +361,9 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       // call takes the same kernel (the gather kernels are then bit-identical across shardings; the scatter kernel adds
       // in arrival order and agrees to the last bits only, as it does from run to run)
       const int64_t nnz_choice = (int64_t)((double)c.Xp[c.n] / (double)c.n * (double)nloc);
+      // replaid.ssgsea: the values are rank weights in [0, max(rX)] (the scatter kernel may sum them in fixed point)
       return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, nnz_choice, stat, a, nullptr, b,
-                                 dS.as<double>(), m, d_flags);
+                                 dS.as<double>(), m, d_flags, /*bounded=*/c.method == 2, nullptr, gmax);
     }
     return launch_spmm_dense_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags,
                                  (c.method == 1 || (c.method == 2 && c.alpha == 0.0)) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY);
@@ -371,22 +386,18 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     }
     sh.rv.arrive_and_wait();
     const int ignore_zero = (sh.flags[1] != 0 && sh.flags[0] == 0) ? 1 : 0;   // min(x) == 0, R/plaid.R:556-557
-    double red[2] = {0.0, 0.0};
     step([&]() -> int {
       if (nloc == 0) return PLAIDHIP_OK;
       PH_TRY(launch_col_medians(ctx, dS.as<double>(), m, m, nloc, ignore_zero, nullptr, d_med));
-      PH_TRY(launch_sum(ctx, d_med, nloc, d_red));
-      PH_HIP(hipMemcpyAsync(red, d_red, 16, hipMemcpyDeviceToHost, ctx->stream));
+      PH_HIP(hipMemcpyAsync(sh.med_all.data() + lo, d_med, (size_t)nloc * 8, hipMemcpyDeviceToHost, ctx->stream));
       PH_HIP(hipStreamSynchronize(ctx->stream));
       return PLAIDHIP_OK;
     });
-    {
-      std::lock_guard<std::mutex> lk(sh.mu);
-      sh.med_sum += red[0];
-      sh.med_cnt += red[1];
-    }
     sh.rv.arrive_and_wait();
-    const double mean_med = sh.med_sum / sh.med_cnt;                         // mean(medx, na.rm = TRUE), R/plaid.R:572
+    // mean(medx, na.rm = TRUE), R/plaid.R:572, over ALL columns in the summation order of the device's sum kernel
+    // (launch_sum): the value does not depend on how the columns were sharded, so every sharding -- one device
+    // included -- normalises with the same bits
+    const double mean_med = live() ? mean_like_device_sum(sh.med_all.data(), c.n) : 0.0;
     step([&]() -> int {
       if (nloc == 0) return PLAIDHIP_OK;
       return launch_shift_columns(ctx, dS.as<double>(), m, m, nloc, d_med, mean_med, nullptr);
@@ -427,6 +438,7 @@ int run_sharded(plaidhip_ctx* const* ctxs, int ndev, int method, const int32_t* 
   if (Xp != nullptr) PH_TRY(check_host_csc(Xp, Xi, g, n));
   Call c{method, Xp, Xi, X_or_x, g, n, Gp, Gi, m, stat, normalize, alpha, S_out};
   Shared sh(ndev);
+  sh.med_all.assign((size_t)n, 0.0);
   if (ndev == 1) return shard_worker(ctxs[0], c, 1, 0, sh);
   std::vector<int> rcs((size_t)ndev, PLAIDHIP_OK);
   std::vector<std::string> errs((size_t)ndev);

@@ -135,6 +135,13 @@ class Context:
         check(self.lib.plaidhip_dev_spmm_csc_f64(self.handle, gs.handle, Xp, Xi, Xx, n, int(nnz), STAT[stat], alpha,
                                                  alpha_div, beta, S, lds, flags))
 
+    def dev_spmm_csc_ranks(self, gs: Geneset, Xp: int, Xi: int, Rx: int, n: int, S: int, lds: int, rmax: int,
+                           stat="mean", alpha=1.0, beta=0.0, flags: int | None = None, nnz: int = -1):
+        """the sparse crossprod of rank weights (0 <= Rx <= *rmax, what dev_colranks_csc wrote; alpha is divided by
+        *rmax): order-independent fixed-point sums in the scatter kernel"""
+        check(self.lib.plaidhip_dev_spmm_csc_ranks_f64(self.handle, gs.handle, Xp, Xi, Rx, n, int(nnz), STAT[stat], alpha,
+                                                       rmax, beta, S, lds, flags))
+
     def dev_colranks_dense(self, X: int, ldx: int, g: int, n: int, R: int, ldr: int, ties="average",
                            signed=False, power=1.0, colmax: int | None = None):
         check(self.lib.plaidhip_dev_colranks_dense_f64(self.handle, X, ldx, g, n, TIES[ties], int(signed),

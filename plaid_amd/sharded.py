@@ -76,16 +76,23 @@ class HipPhaseEngine:
                                f"(context stream {self.ctx.stream}, torch current stream {cur}): create the Context with "
                                "stream=<that stream>.cuda_stream and call inside `with torch.cuda.stream(<that stream>)`")
 
-    def spmm_csc(self, X: CscShard, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None):
-        """crossprod with a CSC shard; `values` replaces X.x (e.g. the ranks of the stored values)"""
+    def spmm_csc(self, X: CscShard, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None,
+                 rank_weights=False):
+        """crossprod with a CSC shard; `values` replaces X.x (e.g. the ranks of the stored values).  `rank_weights`: the
+        values lie in [0, *alpha_div] (rank^power and their global maximum): order-independent fixed-point sums"""
         self._same_stream()
         t = self.torch
         S = t.empty((X.n, self.gs.m), dtype=t.float64, device=self.device)
         if X.n > 0:
             xx = X.x if values is None else values
-            self.ctx.dev_spmm_csc(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
-                                  stat, alpha, beta, flags.data_ptr() if flags is not None else None,
-                                  alpha_div.data_ptr() if alpha_div is not None else None, nnz=X.nnz)
+            fl = flags.data_ptr() if flags is not None else None
+            if rank_weights and alpha_div is not None:
+                self.ctx.dev_spmm_csc_ranks(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(),
+                                            self.gs.m, alpha_div.data_ptr(), stat, alpha, beta, fl, nnz=X.nnz)
+            else:
+                self.ctx.dev_spmm_csc(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
+                                      stat, alpha, beta, fl, alpha_div.data_ptr() if alpha_div is not None else None,
+                                      nnz=X.nnz)
         return S
 
     def sparse_colranks(self, X: CscShard, ties="average", signed=False, power=1.0):
@@ -172,12 +179,13 @@ def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=
 
 
 def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
-                      values=None, group=None):
+                      values=None, group=None, rank_weights=False):
     """plaid() on a CSC shard (sparse branch of Matrix::crossprod, R/plaid.R:107); same collectives as sharded_plaid"""
     import torch.distributed as dist
     world, _ = _world(group)
     flags = engine.new_flags()
-    S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values)
+    S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values, rank_weights=True) if rank_weights else \
+        engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values)
     if normalize:
         if world > 1:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
@@ -197,7 +205,7 @@ def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
     Rx, gmax = engine.sparse_colranks(X_local, "average", False, 1.0 + alpha)
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-    return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group)
+    return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group, rank_weights=True)
 
 
 def sharded_sing(engine, X_local, group=None):
@@ -357,12 +365,25 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
                     pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
                     evs[k & 1] = torch.cuda.Event()
                     evs[k & 1].record(side)
+            # the move into the shared matrix takes first-touch page faults (fresh shm pages) and is a plain memcpy: four
+            # threads per rank (numpy releases the GIL while it copies)
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(4)
+
+            def move(dst_rows, src_arr):
+                k4 = max(1, (src_arr.shape[0] + 3) // 4)
+                futs = [pool.submit(lambda a=a: mm.__setitem__(slice(dst_rows + a, dst_rows + min(src_arr.shape[0], a + k4)),
+                                                               src_arr[a:a + k4]))
+                        for a in range(0, src_arr.shape[0], k4)]
+                for f_ in futs:
+                    f_.result()
             issue(0)
             for k, (r0, r1) in enumerate(slabs):
                 evs[k & 1].synchronize()
                 if k + 1 < len(slabs):
                     issue(k + 1)                                   # the other pinned slab
-                mm[lo + r0:lo + r1] = pin[k & 1][:r1 - r0].numpy()
+                move(lo + r0, pin[k & 1][:r1 - r0].numpy())
+            pool.shutdown()
         else:
             src = S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
             mm[lo:hi] = src.numpy()

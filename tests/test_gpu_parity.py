@@ -760,6 +760,59 @@ def test_scatter_kernel_many_columns_per_workgroup(pinned_ctx):
     assert got.shape == (sets, 40) and not got.any()
 
 
+def test_scatter_kernel_fixed_point_sums_are_reproducible_and_match_fp64(pinned_ctx):
+    """plaidhip_dev_spmm_csc_ranks_f64: rank weights in [0, max(rX)] summed in u64 fixed point by the scatter kernel --
+    bit-identical between two runs and between the two item orders (integer sums do not depend on the arrival order of
+    the LDS atomics), within 1e-13 relative of the fp64-atomic sums and of the oracle; an input outside [0, rmax] is flagged"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, m, n, alpha = 20000, 24000, 700, 0.25
+    Gp, Gi = sy.geneset_csc(g, m)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    outs = {}
+    with torch.cuda.stream(stream):
+        dp, di, dx = (torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (Xp.astype(np.int32), Xi.astype(np.int32), Xx))
+        Rx = torch.empty_like(dx)
+        colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+        gmax = torch.zeros(1, dtype=torch.float64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.dev_colranks_csc(dp.data_ptr(), dx.data_ptr(), n, int(np.diff(Xp).max()), Rx.data_ptr(), "average", False, 1.0 + alpha,
+                             colmax.data_ptr())
+        ctx.dev_max(colmax.data_ptr(), n, gmax.data_ptr())
+        for key, fixed, order in (("fx_chunk", "on", "chunk"), ("fx_chunk2", "on", "chunk"), ("fx_col", "on", "column"),
+                                  ("f64_chunk", "off", "chunk"), ("f64_col", "off", "column")):
+            ctx.set_option("scatter_fixed", fixed)
+            ctx.set_option("scatter_order", order)
+            ctx.set_option("spmm_sparse_kernel", "scatter")
+            S = torch.empty((n, m), dtype=torch.float64, device=dev)
+            ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx.data_ptr(), n, S.data_ptr(), m, gmax.data_ptr(), "mean",
+                                   1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+            outs[key] = S
+        torch.cuda.synchronize()
+        assert int(flags[3]) == 0
+        assert torch.equal(outs["fx_chunk"], outs["fx_chunk2"]) and torch.equal(outs["fx_chunk"], outs["fx_col"])
+        for key in ("f64_chunk", "f64_col"):
+            assert float((outs[key] - outs["fx_chunk"]).abs().max()) < 1e-13
+        # a value above rmax: flagged
+        Rx2 = Rx.clone()
+        Rx2[5] = 2.0 * float(gmax[0])
+        ctx.set_option("scatter_fixed", "on")
+        ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx2.data_ptr(), n, S.data_ptr(), m, gmax.data_ptr(), "mean",
+                               1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+    torch.cuda.synchronize()
+    assert int(flags[3]) == 1
+    from oracle import fullsize
+    _, raw_o = fullsize.ssgsea_csc_raw(Xp.astype(np.int32), Xi, Xx, g, Gp, Gi, alpha, float(gmax[0]))
+    np.testing.assert_allclose(outs["fx_chunk"].cpu().numpy().T, raw_o, rtol=0, atol=1e-13)
+    gs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("rank_kernel", ["bucket", "network"])
 def test_c4_shape_ssgsea_and_sing_dense_fp64_50k_sets(pinned_ctx, g50k, rank_kernel):
     """config 4 per sample in the default fp64 mode: dense 20k-gene columns (the register-blocked network / the

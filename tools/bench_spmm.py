@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
     ap.add_argument("--nt-store", default="auto", choices=["auto", "off", "on"], help="non-temporal stores of the scores")
+    ap.add_argument("--scatter-fixed", default="on", choices=["on", "off"], help="c3: u64 fixed-point accumulators in the scatter kernel")
+    ap.add_argument("--scatter-order", default="chunk", choices=["chunk", "column"], help="c3: item order of the scatter kernel")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -36,6 +38,8 @@ def main():
     ctx.set_option("spmm_dense_kernel", a.dense_kernel)
     ctx.set_option("spmm_sparse_kernel", a.sparse_kernel)
     ctx.set_option("nt_store", a.nt_store)
+    ctx.set_option("scatter_fixed", a.scatter_fixed)
+    ctx.set_option("scatter_order", a.scatter_order)
     dbg = None
     if a.ablate or a.stamps:
         import ctypes
@@ -85,8 +89,8 @@ def main():
                 ctx.dev_max(colmax.data_ptr(), n, red.data_ptr() + 16)
                 e1 = ev()
                 if a.kernel == "c3":
-                    ctx.dev_spmm_csc(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
-                                     flags.data_ptr(), red.data_ptr() + 16, nnz=len(Xx))
+                    ctx.dev_spmm_csc_ranks(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m,
+                                           red.data_ptr() + 16, "mean", 1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
                 else:
                     ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
                                        red.data_ptr() + 16)
