@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LDS_PEAK_GBPS = 157286.4    # 256 CUs x 256 B/clk x 2.4 GHz (MI355X_MICROARCH.md, LDS: ds_read_b64/b128)
+FP64_PEAK_TFLOPS = 78.6     # vector FP64, FMA counted as 2 flop
 
 
 def parse():
@@ -60,29 +61,47 @@ def parse():
 
 
 def _traffic(kernel, shape, columns=None):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json): per launch for the headline shape,
-    per column x the columns of this launch for the kernels measured on a smaller panel of the same shape"""
+    """(HBM bytes per launch, where they were measured) from the committed PMC passes (profiles/traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes -- counters cannot be
+    collected inside the bench): per launch for the headline shape, per column x the columns of this launch for the
+    kernels measured on a smaller panel of the same shape"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         e = json.load(open(path)).get(f"{kernel}/{shape}", {})
+        src = e.get("source", "profiles/traffic.json")
         if columns is not None and "hbm_bytes_per_column" in e:
-            return int(e["hbm_bytes_per_column"] * columns)
-        return e.get("hbm_bytes_per_launch")
+            return int(e["hbm_bytes_per_column"] * columns), src + f" (per column, measured on {e.get('measured_columns', '?')} columns)"
+        v = e.get("hbm_bytes_per_launch")
+        return (v, src) if v is not None else None
     except Exception:
         return None
 
 
 def _roof(kernel, alg_bytes, ms, traffic=None, lds_bytes=None, extra=None):
+    traffic_source = None
+    if isinstance(traffic, tuple):
+        traffic, traffic_source = traffic
     ach = alg_bytes / (ms * 1e-3) / 1e9
     r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
          "kernel_ms": round(ms, 4)}
+    if traffic is not None:
+        r["traffic_source"] = traffic_source or "profiles/traffic.json"   # (PMC passes cannot run inside the bench)
     if lds_bytes is not None:
         la = lds_bytes / (ms * 1e-3) / 1e9
         r["lds_roof"] = {"achieved": round(la, 1), "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": round(la / LDS_PEAK_GBPS, 4),
                          "bytes": int(lds_bytes), "note": "bytes the kernel gathers from LDS per launch / kernel time"}
     if extra:
         r.update(extra)
+    return r
+
+
+def _fp64_roof(r, flop):
+    """FP64-ALU roof of a gather kernel: SURVEY.md 8(d) counts 2 flop per (membership, sample); the kernel issues one fp64
+    add for it, i.e. half a vector lane-slot of the FMA peak"""
+    tf = flop / (r["kernel_ms"] * 1e-3) / 1e12
+    r["fp64_alu_roof"] = {"achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                          "flop": flop}
     return r
 
 
@@ -302,7 +321,7 @@ def run_c2(a, env):
     spmm_kernel = "spmm_colpair_f64" if g % 2 == 0 else "spmm_colgather_f64"
     # every padded membership slot of the plan returns 8 bytes per sample column from LDS
     lds_bytes = float(info["padded_slots"]) * 8.0 * n
-    roofline = _roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes)
+    roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes), 2.0 * z * n)
     kernels = {
         "col_medians": _roof("col_medians_radix_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms),
         "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
@@ -625,8 +644,8 @@ def run_c4(a, env):
         "kernels": {
             "colranks": _roof("colranks_bucket_kernel<512,40>", 16.0 * g * n, rank_ms,
                               _traffic("colranks_bucket_kernel<512,40>", f"{g}xN", n)),
-            "crossprod": _roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
-                               lds_bytes=float(info["padded_slots"]) * 8.0 * n),
+            "crossprod": _fp64_roof(_roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
+                                          lds_bytes=float(info["padded_slots"]) * 8.0 * n), 2.0 * z * n),
             "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),
             "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
@@ -669,6 +688,56 @@ def run_c4(a, env):
         out["mfma_backend"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
     finally:
         ctx.set_option("spmm_dense_kernel", "auto")
+    # replaid.sing (R/plaid.R:213-219) at the same size: min-ties ranks, then the crossprod of the RANK matrix under the
+    # three exact stagings (u16: four samples per LDS entry, integer sums -- the default; fp32; fp64) -- same bits, timed
+    try:
+        sing = {"workload": f"replaid.sing on the same {g} x {n} x {m}: colranks(ties = min) + crossprod(rank / nrow - 0.5), "
+                            "no normalisation"}
+        Sref = None
+        for name in ("u16", "f32", "f64"):
+            ctx.set_option("ranks_f32", name)
+            evs = []
+            for it in range(3):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, "min", False, 1.0, None)
+                    e1.record(stream)
+                    ctx.dev_spmm_ranks(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0 / g, -0.5, flags.data_ptr())
+                    e2.record(stream)
+                evs.append((e0, e1, e2))
+            torch.cuda.synchronize()
+            rk = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in evs[1:]]))
+            cp = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in evs[1:]]))
+            sing[name] = {"colranks_ms": round(rk, 3), "crossprod_ms": round(cp, 3),
+                          "scores_per_s": round(float(n) * m / ((rk + cp) * 1e-3), 1),
+                          "crossprod": _roof({"u16": "spmm_colquad_u16", "f32": "spmm_colpair_mixed", "f64": "spmm_colpair_f64"}[name],
+                                             spmm_alg, cp)}
+            if name == "u16":
+                Sref = S.clone()
+                if a.cpu_sample > 0:
+                    from oracle import c_oracle, fullsize
+                    cols, crosses = fullsize.probe_columns(n, m, 64)
+                    idx = torch.as_tensor(cols, device=dev)
+                    Xc = np_f(X.index_select(0, idx))
+                    r_o = c_oracle.colranks_dense_mt(Xc, "min", False, _cpu_threads())
+                    assert np.array_equal(np_f(R.index_select(0, idx)), r_o), "min-ties ranks differ from the oracle"
+                    s_o = c_oracle.crossprod_dense(r_o / g - 0.5, Gp, Gi, "mean", _cpu_threads())
+                    s_g = np_f(S.index_select(0, idx))
+                    np.testing.assert_allclose(s_g, s_o, rtol=1e-5, atol=1e-9)
+                    sing["parity"] = {"launch": "full", "columns": int(len(cols)), "offsets_past_2^31_checked": bool(crosses),
+                                      "ranks_bit_exact": True, "max_abs_err_vs_oracle": float(np.max(np.abs(s_g - s_o)))}
+            else:
+                sing[name]["bit_identical_to_u16"] = bool(torch.equal(S, Sref))
+        sing["speedup_u16_vs_f32_staging"] = round(sing["f32"]["crossprod_ms"] / sing["u16"]["crossprod_ms"], 2)
+        sing["speedup_u16_vs_f64"] = round(sing["f64"]["crossprod_ms"] / sing["u16"]["crossprod_ms"], 2)
+        del Sref
+        out["sing"] = sing
+    except Exception as exc:  # pragma: no cover
+        out["sing"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+    finally:
+        ctx.set_option("ranks_f32", "u16")
+        torch.cuda.empty_cache()
     if a.cpu_sample > 0:
         from oracle import c_oracle
         nc = min(512, n)

@@ -330,6 +330,16 @@ static int launch_bucket(plaidhip_ctx* ctx, const RankBucketArgs& a, int32_t max
   const size_t keys_bytes = (size_t)kRankMisc + (size_t)max_len * 8;
   const size_t smem = keys_bytes > (size_t)L::hist_bytes ? keys_bytes : (size_t)L::hist_bytes;
   PH_FULL_LDS(ctx, (&colranks_bucket_kernel<BLOCK, KPT>));
+  // persistent: as many workgroups as the chip holds at once (LDS- or thread-limited), each walking its columns with the
+  // next column's values requested while the current one's ranks are written (rank_bucket.h)
+  int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
+  if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
+  if (per_cu < 1) per_cu = 1;
+  bool persistent = (size_t)BLOCK * KPT * 8 > (size_t)64 * 1024;
+#ifdef PLAIDHIP_DIAG
+  if (getenv("PLAIDHIP_RANK_NOPF")) persistent = false;   // one workgroup per column, nothing prefetched (A/B)
+#endif
+  if (persistent && grid > ctx->num_cu * per_cu) grid = ctx->num_cu * per_cu;
   hipLaunchKernelGGL((colranks_bucket_kernel<BLOCK, KPT>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;

@@ -200,6 +200,14 @@ colranks_bucket_kernel(RankBucketArgs a) {
   unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
+  // PERSISTENT use (grid < columns): the NEXT column's values are requested into the key registers as soon as the
+  // current column's keys are dead (behind the in-bucket counts) and land while the current column's ranks are written:
+  // a 20k-gene column fills the LDS, so one workgroup owns a CU and nothing else would overlap its load and store phases.
+  bool have_next = false;          // key[] holds the raw values of column c (requested during the previous column)
+  const double* xc_n = nullptr;
+  double* rc_n = nullptr;
+  uint32_t cnt_n = 0;
+  uint64_t key[KPT];
   for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
     // an opaque copy of the thread id per column: nothing derived from it is hoisted out of the column loop
     // (LICM would keep dozens of per-thread addresses alive across all phases and spill)
@@ -210,6 +218,38 @@ colranks_bucket_kernel(RankBucketArgs a) {
     const double* xc;
     double* rc;
     uint32_t cnt;
+    // descriptor of column cc (dense columns and CSC @x; the densified-CSC form builds its column below)
+#define PH_COLUMN_DESC(cc, xp_, rp_, cn_)                                                                            \
+    if (a.Xp != nullptr) {                                                                                             \
+      /* (wave-uniform and read-only: through the scalar cache -- as a vector load + readfirstlane the column bounds  \
+         are one more dependent L2 round trip in front of every column's value loads) */                              \
+      typedef __attribute__((address_space(4))) const int32_t* cptr_i32_;                                              \
+      const int p0_ = ((cptr_i32_)a.Xp)[cc];                                                                           \
+      cn_ = (uint32_t)(((cptr_i32_)a.Xp)[(cc) + 1] - p0_);                                                             \
+      xp_ = a.Xv + p0_;                                                                                                \
+      rp_ = a.R + p0_;                                                                                                 \
+    } else {                                                                                                           \
+      cn_ = (uint32_t)a.g_dense;                                                                                       \
+      xp_ = a.Xv + (int64_t)(cc) * a.ldx;                                                                              \
+      rp_ = a.R + (int64_t)(cc) * a.ldr;                                                                               \
+    }
+    // every value of the column requested at once (clamped index instead of a guarded load: no exec games).
+    // (Two neighbouring elements per lane -- 16-byte loads and stores, half the vector-memory instructions -- were
+    // measured: no faster, A/B on one box 2.06 vs 2.03 ms per 8,192 columns; the phases are not bound by their issue.)
+#define PH_COLUMN_LOAD(xp_, cn_)                                                                                     \
+    {                                                                                                                  \
+      const uint32_t last_ = (cn_) - 1u;                                                                               \
+      _Pragma("unroll") for (int j0 = 0; j0 < KPT; j0 += 4) {                                                        \
+        if ((uint32_t)(j0) * BLOCK < (cn_)) {                                                                          \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                            \
+            const uint32_t i_ = tid + (uint32_t)(j0 + u) * BLOCK;                                                      \
+            key[j0 + u] = (uint64_t)__double_as_longlong(__builtin_nontemporal_load((xp_) + (i_ < (cn_) ? i_ : last_))); \
+          }                                                                                                            \
+        } else {                                                                                                       \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) key[j0 + u] = ~0ull;                                         \
+        }                                                                                                              \
+      }                                                                                                                \
+    }
     if (a.Xi_dense != nullptr) {
       // colranks(sparse X, keep.zero = FALSE): the reference ranks the densified column (R/plaid.R:603-609)
       double* dcol = a.dense_scratch + (int64_t)blockIdx.x * a.g_dense;
@@ -221,18 +261,10 @@ colranks_bucket_kernel(RankBucketArgs a) {
       cnt = (uint32_t)a.g_dense;
       xc = dcol;
       rc = a.R + (int64_t)c * a.ldr;
-    } else if (a.Xp != nullptr) {
-      // (wave-uniform and read-only: through the scalar cache -- as a vector load + readfirstlane the column bounds are
-      // one more dependent L2 round trip in front of every column's value loads)
-      typedef __attribute__((address_space(4))) const int32_t* cptr_i32_;
-      const int p0 = ((cptr_i32_)a.Xp)[c];
-      cnt = (uint32_t)(((cptr_i32_)a.Xp)[c + 1] - p0);
-      xc = a.Xv + p0;
-      rc = a.R + p0;
+    } else if (have_next) {
+      xc = xc_n; rc = rc_n; cnt = cnt_n;
     } else {
-      cnt = (uint32_t)a.g_dense;
-      xc = a.Xv + (int64_t)c * a.ldx;
-      rc = a.R + (int64_t)c * a.ldr;
+      PH_COLUMN_DESC(c, xc, rc, cnt)
     }
     // The KPT items of a thread are handled in groups of four; a group takes part when any of its 4 * BLOCK
     // elements exists (the same for every thread: no divergence, straight-line code inside a group).  Lanes
@@ -249,25 +281,11 @@ colranks_bucket_kernel(RankBucketArgs a) {
   }
 
     // ---- 1. the column -> registers as ordered keys ------------------------------------------------
-    uint64_t key[KPT];
     uint64_t validmask = 0, nanmask = 0, negmask = 0;
     uint64_t kmin = ~0ull, kmax = 0ull;
     {
-      const uint32_t last = cnt - 1u;
-#pragma unroll
-      for (int j0 = 0; j0 < KPT; j0 += 4) {
-        if (PH_GROUP(j0)) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t i = tid + (uint32_t)(j0 + u) * BLOCK;
-            // clamped index instead of a guarded load: no exec games, every load of the column in flight at once
-            key[j0 + u] = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(xc + (i < cnt ? i : last)));
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) key[j0 + u] = ~0ull;
-        }
-      }
+      if (!have_next) PH_COLUMN_LOAD(xc, cnt)
+      have_next = false;
       // zero the histograms (and the tie flags) while the loads are in flight
       {
         uint4* z = reinterpret_cast<uint4*>(smem_raw + L::off_c1);
@@ -423,7 +441,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
     if (*s_flag != 0u) {
       if (tid == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = c;
       __syncthreads();
-      continue;
+      continue;          // (have_next is false here: the next column is loaded at its own start)
     }
 
     PH_STAMP(3);   // bucket state + tie test
@@ -461,6 +479,20 @@ colranks_bucket_kernel(RankBucketArgs a) {
       zeromask |= (k == 0x8000000000000000ull) ? (1ull << j) : 0u;
     })
     PH_STAMP(4);   // scatter + in-bucket counts
+    {
+      // the keys are dead: their registers take the next column's values, which land during the output pass below
+      // (only for the shapes whose keys fill most of the LDS: smaller columns overlap through occupancy, and the extra
+      // live state would cost the 256-thread kernels a wavefront per SIMD)
+      constexpr bool kPrefetch = (size_t)CAP * 8 > (size_t)64 * 1024;
+      const int cnx = c + (int)gridDim.x;
+      if (kPrefetch && a.Xi_dense == nullptr && cnx < a.n) {
+        PH_COLUMN_DESC(cnx, xc_n, rc_n, cnt_n)
+        if (cnt_n > 0) {
+          PH_COLUMN_LOAD(xc_n, cnt_n)
+          have_next = true;
+        }
+      }
+    }
     double vmax = (a.Xp != nullptr && a.Xi_dense == nullptr) ? 0.0 : -INFINITY;   // sparse ranks: the implicit zeros
     const bool generic_pow = a.pow_q4 == 0 && a.power != 1.0;   // uniform
     if (generic_pow) __syncthreads();                           // every in-bucket count is done: the LDS is free again
@@ -508,6 +540,8 @@ colranks_bucket_kernel(RankBucketArgs a) {
     PH_STAMP(5);   // ranks -> power -> store (+ column maximum)
 #undef PH_GROUP
 #undef PH_FOR_ITEMS
+#undef PH_COLUMN_DESC
+#undef PH_COLUMN_LOAD
   }
 #ifdef PLAIDHIP_DIAG
   if (a.dbg != nullptr && threadIdx.x == 0)

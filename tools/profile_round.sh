@@ -1,12 +1,21 @@
 #!/bin/bash
-# One-shot evidence run for profiles/ (round 2 layout): the bench line, rocprofv3 kernel stats of the same command,
-# PMC passes (separate --pmc runs: FETCH_SIZE / WRITE_SIZE / SQ set) for the dominant kernels of C2, C3 and C4, and the
-# micro-benchmarks quoted in DESIGN.md.  Run through gpurun:   gpurun -- 'bash tools/profile_round.sh gpurun_out/r02x'
+# One-shot evidence run for profiles/ (round 3 layout).  Run through gpurun:
+#     gpurun --timeout 2400 -- 'bash tools/profile_round.sh gpurun_out/r03x'
+#  * the bench line (all blocks);
+#  * rocprofv3 --kernel-trace --stats of `python3 bench.py --config c2`, `--config c3`, `--config c4` SEPARATELY, so that
+#    every tracked kernel_stats CSV has one launch shape per kernel row (the pair kernel's C2 and C4 launches are not
+#    pooled any more) and its average duration can be read against the bench line's HIP-event time;
+#  * PMC passes (separate --pmc runs: FETCH_SIZE / WRITE_SIZE / the SQ set / TCC hits / GRBM) for the dominant kernels of
+#    C2 (pair kernel), C3 (scatter kernel, fixed-point and fp64 accumulators), C4 (pair kernel at 50k sets, bucket
+#    ranker) and of the rank crossprod (quad kernel), summarised per kernel;
+#  * the micro-benchmarks quoted in DESIGN.md.
 out=${1:-gpurun_out/prof}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --cpu-sample 0 --no-mixed > $out/stats.log 2>&1
+for cfg in c2 c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$cfg -- python3 bench.py --config $cfg --cpu-sample 0 --no-mixed > $out/stats_$cfg.log 2>&1
+done
 SQSET="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY"
 run_pmc() {   # tag, then bench_spmm.py arguments
   tag=$1; shift
@@ -18,19 +27,20 @@ run_pmc() {   # tag, then bench_spmm.py arguments
 }
 run_pmc c2 --kernel spmm --iters 3
 run_pmc c3 --kernel c3 --samples 8192 --sets 50000 --iters 3
+run_pmc c3f64 --kernel c3 --samples 8192 --sets 50000 --iters 3 --scatter-fixed off --scatter-order column
 run_pmc c4 --kernel c4 --samples 4096 --sets 50000 --iters 3
+run_pmc sing --kernel sing --samples 4096 --sets 50000 --iters 2
 python3 tools/bench_spmm.py --kernel c3 --samples 4096 --sets 50000 --iters 3 > $out/c3_4096.log 2>&1
 python3 tools/bench_spmm.py --kernel c4 --samples 2048 --sets 50000 --iters 3 > $out/c4_2048.log 2>&1
+python3 tools/bench_spmm.py --kernel sing --samples 4096 --sets 50000 --iters 3 > $out/sing_4096_50k.log 2>&1
+python3 tools/bench_spmm.py --kernel sing --samples 10000 --sets 5000 --iters 3 > $out/sing_10000_5k.log 2>&1
 python3 tools/bench_rank.py > $out/rank.log 2>&1
 python3 tools/bench_shift.py > $out/shift.log 2>&1
 python3 tools/bench_spmm.py --kernel medians --samples 8192 --sets 50000 --iters 10 > $out/medians_50k.log 2>&1
-hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_cost.hip -o /tmp/valu_cost 2>/dev/null && UBENCH_ONLY_PAIR=1 /tmp/valu_cost > $out/ubench_pair_loops.txt 2>&1
-hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/ubench/lds_atomics.hip -o /tmp/lds_atomics 2>/dev/null && /tmp/lds_atomics > $out/ubench_lds_atomics.txt 2>&1
-hipcc -O2 tools/ubench/pcie.cpp -o /tmp/pcie -lpthread 2>/dev/null && /tmp/pcie > $out/ubench_pcie.txt 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
-for tag in ("c2", "c3", "c4"):
+for tag in ("c2", "c3", "c3f64", "c4", "sing"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + f"/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -42,9 +52,10 @@ for tag in ("c2", "c3", "c4"):
             fh.write(k + "\n")
             for c, v in sorted(d.items()):
                 fh.write(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
-# kernel stats of the bench run: one csv
-for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
-    os.replace(f, out + "/bench_kernel_stats.csv")
+# kernel stats of the three bench runs: one csv each
+for cfg in ("c2", "c3", "c4"):
+    for f in glob.glob(out + f"/stats_{cfg}/**/*kernel_stats.csv", recursive=True):
+        os.replace(f, out + f"/bench_{cfg}_kernel_stats.csv")
 print(open(out + "/pmc_c2_summary.txt").read()[:1500])
 PY
-tail -c 600 $out/bench.json; tail -1 $out/c3_4096.log; tail -1 $out/c4_2048.log
+tail -c 600 $out/bench.json; tail -1 $out/c3_4096.log; tail -1 $out/c4_2048.log; tail -3 $out/sing_4096_50k.log
