@@ -712,7 +712,7 @@ def run_c4(a, env):
             sing[name] = {"colranks_ms": round(rk, 3), "crossprod_ms": round(cp, 3),
                           "scores_per_s": round(float(n) * m / ((rk + cp) * 1e-3), 1),
                           "crossprod": _roof({"u16": "spmm_colquad_u16", "f32": "spmm_colpair_mixed", "f64": "spmm_colpair_f64"}[name],
-                                             spmm_alg, cp)}
+                                             spmm_alg, cp, _traffic("spmm_colquad_u16", f"{g}xNx{m}", n) if name == "u16" else None)}
             if name == "u16":
                 Sref = S.clone()
                 if a.cpu_sample > 0:
