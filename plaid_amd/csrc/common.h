@@ -230,9 +230,6 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
 enum { PLAIDHIP_X_ANY = 0,        // arbitrary doubles
        PLAIDHIP_X_EXACT_F32 = 1,  // (half-)integers of magnitude <= 20,448, any sign (signed ranks): exact in fp32
        PLAIDHIP_X_RANKS = 2 };    // what colranks returns: half-integers in [0, nrow(X)]: 2x is a u16
-// the crossprod of a rank matrix the rank kernel wrote as u16 (2 * rank; plaidhip_dev_colranks_dense_u16)
-int launch_spmm_ranks_u16(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const uint16_t* U, int64_t ldu, int32_t n, int stat,
-                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 int launch_spmm_mfma_f64(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n, int stat,
                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags);
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,

@@ -1390,9 +1390,9 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
 // summation order, and -- after the one conversion sum / 2 in the epilogue -- bit-identical to what the fp64 kernels
 // produce (their sums of half-integers are exact too).  Same host schedule as the one-column kernel (32-lane halves
 // of ds_read_b64 against 32 bank pairs), same per-wave tile streams, same epilogue.
-// X arrives as the doubles `colranks` wrote (U16IN = false: four column streams, converted while staging with one
-// fp64 add per value: the low word of x + 2^51 is 2x) or as the u16 matrix plaidhip_dev_colranks_*_u16 wrote
-// (U16IN = true: a quarter of the bytes, the whole next quad prefetched in registers).
+// X arrives as the doubles `colranks` wrote: four column streams, converted while staging with one fp64 add per value (the
+// low word of x + 2^51 is 2x).  (A rank kernel that writes the u16 matrix itself would quarter those bytes and let the whole
+// next quad be prefetched in registers -- staging is 20 % of the kernel at 5,000 sets, 3 % at 50,000; not built.)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
 __device__ __forceinline__ u32x2 lds_u32x2_at(uint32_t byte_off) {
@@ -1408,11 +1408,9 @@ __device__ __forceinline__ uint32_t twice_as_u32(double x) { return (uint32_t)__
 
 struct SpmmQuadArgs {
   SpmmArgs s;
-  const uint16_t* U;     // U16IN: 2 * rank, genes x samples column-major, leading dimension ldu (a multiple of 8)
-  int64_t ldu;
 };
 
-template <bool STAMP, bool U16IN>
+template <bool STAMP>
 __global__ void __launch_bounds__(1024)
 spmm_colquad_u16(SpmmQuadArgs qa_) {
   const SpmmArgs& a = qa_.s;
@@ -1440,14 +1438,10 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
   // fp64 input: an "item" is 1,024 gene pairs: per thread one 16-byte load {x[2i], x[2i+1]} from each of the four
   // columns -> two LDS entries, one ds_write_b128.  Items 0..5 of the NEXT quad are requested when the wavefront has
   // finished its stream (their registers are free then); items 6..9 follow behind the barrier.
-  // u16 input: an item is 1,024 groups of 8 genes: one 16-byte load (8 ranks) per column and thread -> eight entries.
-  const int g2 = a.g >> 1;   // fp64: gene pairs
-  const int g8 = a.g >> 3;   // u16: groups of eight genes (the rest, < 8 genes, is staged by scalar code)
+  const int g2 = a.g >> 1;   // gene pairs
   f64x2 pa0, pb0, pc0, pd0, pa1, pb1, pc1, pd1, pa2, pb2, pc2, pd2, pa3, pb3, pc3, pd3, pa4, pb4, pc4, pd4, pa5, pb5, pc5, pd5;
-  u32x4 ua0, ub0, uc0, ud0, ua1, ub1, uc1, ud1, ua2, ub2, uc2, ud2;
   pa0 = pb0 = pc0 = pd0 = pa1 = pb1 = pc1 = pd1 = pa2 = pb2 = pc2 = pd2 = f64x2{0.0, 0.0};
   pa3 = pb3 = pc3 = pd3 = pa4 = pb4 = pc4 = pd4 = pa5 = pb5 = pc5 = pd5 = f64x2{0.0, 0.0};
-  ua0 = ub0 = uc0 = ud0 = ua1 = ub1 = uc1 = ud1 = ua2 = ub2 = uc2 = ud2 = u32x4{0u, 0u, 0u, 0u};
 
 #define PLAIDHIP_QCOLS(qq_)                                                     \
   const int c0_ = 4 * (qq_);                                                     \
@@ -1481,51 +1475,15 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
   const char* xb_ = reinterpret_cast<const char*>(a.X + (int64_t)c1_ * a.ldx);                        \
   const char* xc_ = reinterpret_cast<const char*>(a.X + (int64_t)c2_ * a.ldx);                        \
   const char* xd_ = reinterpret_cast<const char*>(a.X + (int64_t)c3_ * a.ldx);
-  // u16: lane's 8 genes of column A as {A0|A1<<16, A2|A3<<16, A4|A5<<16, A6|A7<<16}
-#define PLAIDHIP_LD_U16(k, ra, rb, rc, rd)                                                                           \
-  {                                                                                                                  \
-    const bool in_ = (k + 1) * BLOCK <= g8 || (k * BLOCK < g8 && tid_o + k * BLOCK < g8);                            \
-    ra = rb = rc = rd = u32x4{0u, 0u, 0u, 0u};                                                                       \
-    if (in_) {                                                                                                       \
-      ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xa_ + (size_t)k * BLOCK * 16 + loff16));       \
-      rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb_ + (size_t)k * BLOCK * 16 + loff16));       \
-      rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xc_ + (size_t)k * BLOCK * 16 + loff16));       \
-      rd = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xd_ + (size_t)k * BLOCK * 16 + loff16));       \
-    }                                                                                                                \
-  }
-  // {A_even | B_even << 16} = perm of the low halves, {A_odd | B_odd << 16} of the high halves (v_perm_b32)
-#define PLAIDHIP_LO2(x_, y_) __builtin_amdgcn_perm((y_), (x_), 0x05040100u)
-#define PLAIDHIP_HI2(x_, y_) __builtin_amdgcn_perm((y_), (x_), 0x07060302u)
-#define PLAIDHIP_ST_U16(k, ra, rb, rc, rd)                                                                           \
-  if (k * BLOCK < g8) {                                                                                              \
-    const int i_ = tid_o + k * BLOCK;                                                                                \
-    if (i_ < g8) {                                                                                                   \
-      ent4[4 * i_ + 0] = u32x4{PLAIDHIP_LO2(ra.x, rb.x), PLAIDHIP_LO2(rc.x, rd.x), PLAIDHIP_HI2(ra.x, rb.x), PLAIDHIP_HI2(rc.x, rd.x)}; \
-      ent4[4 * i_ + 1] = u32x4{PLAIDHIP_LO2(ra.y, rb.y), PLAIDHIP_LO2(rc.y, rd.y), PLAIDHIP_HI2(ra.y, rb.y), PLAIDHIP_HI2(rc.y, rd.y)}; \
-      ent4[4 * i_ + 2] = u32x4{PLAIDHIP_LO2(ra.z, rb.z), PLAIDHIP_LO2(rc.z, rd.z), PLAIDHIP_HI2(ra.z, rb.z), PLAIDHIP_HI2(rc.z, rd.z)}; \
-      ent4[4 * i_ + 3] = u32x4{PLAIDHIP_LO2(ra.w, rb.w), PLAIDHIP_LO2(rc.w, rd.w), PLAIDHIP_HI2(ra.w, rb.w), PLAIDHIP_HI2(rc.w, rd.w)}; \
-    }                                                                                                                \
-  }
-#define PLAIDHIP_XPTRS_U16(qq_)                                                                      \
-  PLAIDHIP_QCOLS(qq_)                                                                                 \
-  const char* xa_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c0_ * qa_.ldu);                    \
-  const char* xb_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c1_ * qa_.ldu);                    \
-  const char* xc_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c2_ * qa_.ldu);                    \
-  const char* xd_ = reinterpret_cast<const char*>(qa_.U + (int64_t)c3_ * qa_.ldu);
   // what a wavefront requests of the next quad when its stream is done
 #define PLAIDHIP_PREFETCH(qq_)                                                                        \
   do {                                                                                                \
     int tid_o = tid;                                                                                  \
     asm volatile("" : "+v"(tid_o));                                                                   \
     const uint32_t loff16 = (uint32_t)tid_o * 16u;                                                    \
-    if constexpr (U16IN) {                                                                            \
-      PLAIDHIP_XPTRS_U16(qq_)                                                                         \
-      PLAIDHIP_LD_U16(0, ua0, ub0, uc0, ud0) PLAIDHIP_LD_U16(1, ua1, ub1, uc1, ud1) PLAIDHIP_LD_U16(2, ua2, ub2, uc2, ud2) \
-    } else {                                                                                          \
-      PLAIDHIP_XPTRS_F64(qq_)                                                                         \
-      PLAIDHIP_LD_F64(0, pa0, pb0, pc0, pd0) PLAIDHIP_LD_F64(1, pa1, pb1, pc1, pd1) PLAIDHIP_LD_F64(2, pa2, pb2, pc2, pd2) \
-      PLAIDHIP_LD_F64(3, pa3, pb3, pc3, pd3) PLAIDHIP_LD_F64(4, pa4, pb4, pc4, pd4) PLAIDHIP_LD_F64(5, pa5, pb5, pc5, pd5) \
-    }                                                                                                 \
+    PLAIDHIP_XPTRS_F64(qq_)                                                                           \
+    PLAIDHIP_LD_F64(0, pa0, pb0, pc0, pd0) PLAIDHIP_LD_F64(1, pa1, pb1, pc1, pd1) PLAIDHIP_LD_F64(2, pa2, pb2, pc2, pd2) \
+    PLAIDHIP_LD_F64(3, pa3, pb3, pc3, pd3) PLAIDHIP_LD_F64(4, pa4, pb4, pc4, pd4) PLAIDHIP_LD_F64(5, pa5, pb5, pc5, pd5) \
   } while (0)
 
   int q = blockIdx.x;
@@ -1540,18 +1498,7 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
       asm volatile("" : "+v"(tid_o));
       const uint32_t loff16 = (uint32_t)tid_o * 16u;
       u32x4* ent4 = reinterpret_cast<u32x4*>(smem_raw);
-      if constexpr (U16IN) {
-        PLAIDHIP_XPTRS_U16(q)
-        PLAIDHIP_ST_U16(0, ua0, ub0, uc0, ud0) PLAIDHIP_ST_U16(1, ua1, ub1, uc1, ud1) PLAIDHIP_ST_U16(2, ua2, ub2, uc2, ud2)
-        // the genes behind the last whole group of eight (< 8; one thread each)
-        const int rest = a.g - 8 * g8;
-        if (tid_o < rest) {
-          const int i_ = 8 * g8 + tid_o;
-          const uint32_t va = reinterpret_cast<const uint16_t*>(xa_)[i_], vb = reinterpret_cast<const uint16_t*>(xb_)[i_];
-          const uint32_t vc = reinterpret_cast<const uint16_t*>(xc_)[i_], vd = reinterpret_cast<const uint16_t*>(xd_)[i_];
-          ent[i_] = u32x2{va | (vb << 16), vc | (vd << 16)};
-        }
-      } else {
+      {
         PLAIDHIP_XPTRS_F64(q)
         PLAIDHIP_ST_F64(0, pa0, pb0, pc0, pd0) PLAIDHIP_ST_F64(1, pa1, pb1, pc1, pd1) PLAIDHIP_ST_F64(2, pa2, pb2, pc2, pd2)
         // items 6..8 take the registers of 0..2 while 3..5 are converted; item 9 follows
@@ -1691,8 +1638,7 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
     } else {
       pa0 = pb0 = pc0 = pd0 = pa1 = pb1 = pc1 = pd1 = pa2 = pb2 = pc2 = pd2 = f64x2{0.0, 0.0};
       pa3 = pb3 = pc3 = pd3 = pa4 = pb4 = pc4 = pd4 = pa5 = pb5 = pc5 = pd5 = f64x2{0.0, 0.0};
-      ua0 = ub0 = uc0 = ud0 = ua1 = ub1 = uc1 = ud1 = ua2 = ub2 = uc2 = ud2 = u32x4{0u, 0u, 0u, 0u};
-    }
+        }
     if constexpr (STAMP) ts2 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the quad is overwritten by the next iteration
     if constexpr (STAMP) {
@@ -1709,26 +1655,19 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
     }
   }
   // a value that is not a rank (2x does not fit 16 bits) was staged: the scores are wrong, say so (flags[3])
-  if (!U16IN) {
-    for (int off = 32; off >= 1; off >>= 1) chk |= __shfl_xor(chk, off, 64);
-    if (a.flags != nullptr && lane == 0 && (chk >> 16) != 0u)
-      __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (int off = 32; off >= 1; off >>= 1) chk |= __shfl_xor(chk, off, 64);
+  if (a.flags != nullptr && lane == 0 && (chk >> 16) != 0u)
+    __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   publish_flags(f, a.flags);
 #undef PLAIDHIP_PREFETCH
 #undef PLAIDHIP_QCOLS
 #undef PLAIDHIP_LD_F64
 #undef PLAIDHIP_ST_F64
 #undef PLAIDHIP_XPTRS_F64
-#undef PLAIDHIP_LD_U16
-#undef PLAIDHIP_ST_U16
-#undef PLAIDHIP_XPTRS_U16
-#undef PLAIDHIP_LO2
-#undef PLAIDHIP_HI2
 }
 
 // g <= kMaxLdsGenes and 2 g < 65,536 always hold for the one-slice plan (20,448 genes)
-static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs a, const uint16_t* U, int64_t ldu) {
+static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArgs a) {
   const plaidhip_slice& sl = gs->slices[0];
   a.g = sl.gs;
   a.g0 = 0;
@@ -1740,7 +1679,7 @@ static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArg
   a.meta_j = sl.d_meta_j;
   a.meta_w = sl.d_meta_w;
   a.meta_k = sl.d_meta_k;
-  SpmmQuadArgs qa{a, U, ldu};
+  SpmmQuadArgs qa{a};
   const size_t smem = (size_t)(sl.gs + kPadSlots) * sizeof(double);
   int grid = ctx->num_cu;
   const int nquads = (a.n + 3) / 4;
@@ -1748,21 +1687,13 @@ static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArg
 #ifdef PLAIDHIP_DIAG
   if (g_ablate == 4) {   // in-kernel stamps
     qa.s.dbg = g_dbg;
-    if (U != nullptr) {
-      PH_FULL_LDS(ctx, (&spmm_colquad_u16<true, true>));
-      hipLaunchKernelGGL((spmm_colquad_u16<true, true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
-    } else {
-      PH_FULL_LDS(ctx, (&spmm_colquad_u16<true, false>));
-      hipLaunchKernelGGL((spmm_colquad_u16<true, false>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
-    }
+    PH_FULL_LDS(ctx, (&spmm_colquad_u16<true>));
+    hipLaunchKernelGGL((spmm_colquad_u16<true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
   } else
 #endif
-  if (U != nullptr) {
-    PH_FULL_LDS(ctx, (&spmm_colquad_u16<false, true>));
-    hipLaunchKernelGGL((spmm_colquad_u16<false, true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
-  } else {
-    PH_FULL_LDS(ctx, (&spmm_colquad_u16<false, false>));
-    hipLaunchKernelGGL((spmm_colquad_u16<false, false>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
+  {
+    PH_FULL_LDS(ctx, (&spmm_colquad_u16<false>));
+    hipLaunchKernelGGL((spmm_colquad_u16<false>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
@@ -1954,7 +1885,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     a.X = X;
     a.ldx = ldx;
     fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
-    return launch_colquad(ctx, gs, a, nullptr, 0);
+    return launch_colquad(ctx, gs, a);
   }
   const bool x_exact_in_f32 = x_kind != PLAIDHIP_X_ANY && ctx->opt_ranks_f32 >= 1;
   if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && one_slice_16) {
@@ -1978,18 +1909,6 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.ldx = ldx;
   fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
   return launch_colgather<false>(ctx, gs, a);
-}
-
-int launch_spmm_ranks_u16(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const uint16_t* U, int64_t ldu, int32_t n, int stat,
-                          double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags) {
-  if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if (!(gs->slices.size() == 1 && gs->slices[0].waves == 16 && (ldu & 7) == 0 && (reinterpret_cast<uintptr_t>(U) & 15) == 0)) {
-    set_error("spmm_ranks_u16: needs 8,192 < nrow(X) <= %d, ldu a multiple of 8 and a 16-byte aligned matrix", kMaxLdsGenes);
-    return PLAIDHIP_EUNSUPPORTED;
-  }
-  SpmmArgs a{};
-  fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
-  return launch_colquad(ctx, gs, a, U, ldu);
 }
 
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
