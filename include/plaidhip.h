@@ -162,6 +162,20 @@ int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
                                     const void* Xi, const void* Rx, int32_t n, int64_t nnz, int stat, double alpha,
                                     const void* rmax, double beta, void* S, int64_t lds, void* flags);
 
+/* chunked_crossprod(x, y) = t(x) %*% y (R/plaid.R:100-123, Matrix::crossprod at :107 / :117) for a GENERAL sparse x: the
+ * stored values of x (@x) may differ inside a column -- signed or weighted gene sets -- which the prepared membership
+ * of plaidhip_geneset_create cannot express.  x stays in its dgCMatrix slots (device pointers Wp: m + 1, Wi / Wx: Wp[m];
+ * g rows, m columns); y is g x n dense (leading dimension ldy); S: m x n, leading dimension lds.  Every stored entry of x
+ * is multiplied, explicit zeros included (0 * NaN is NaN, as in Matrix::crossprod); sums are fp64 in an order that
+ * differs from a sequential one (16 partial sums per column of x).  plaid() itself never needs this entry: it builds
+ * the column-scaled 0/1 matrix (:73-77), the path plaidhip_dev_spmm_dense_f64 is made for.                          */
+int plaidhip_dev_crossprod_weighted_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
+                                        int32_t m, const void* Y, int64_t ldy, int32_t n, void* S, int64_t lds);
+/* same with y a dgCMatrix (device pointers Yp: n + 1, Yi / Yx); S is dense                                           */
+int plaidhip_dev_crossprod_weighted_csc_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
+                                            int32_t m, const void* Yp, const void* Yi, const void* Yx, int32_t n,
+                                            void* S, int64_t lds);
+
 /* colranks(), dense branch: t(matrixStats::colRanks(as.matrix(X), ties.method))
  * (R/plaid.R:611-619); `is_signed` = sign(X)*rank(|X|) (R/plaid.R:612-615).  Optional fused
  * power transform rank^power (R/plaid.R:249, power = 1+alpha; pass 1.0 for none).
@@ -215,6 +229,14 @@ int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t 
 int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                        int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
                        int stat, int normalize, double* S_out);
+/* chunked_crossprod(x, y) with a general sparse x (see plaidhip_dev_crossprod_weighted_f64), host pointers: x as
+ * dgCMatrix slots, y dense g x n; S_out m x n, caller-allocated.  The caller's chunk loop (R/plaid.R:110-119) bounds n. */
+int plaidhip_crossprod_weighted_dense(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
+                                      int32_t g, int32_t m, const double* Y, int32_t n, double* S_out);
+/* same for a dgCMatrix y */
+int plaidhip_crossprod_weighted_csc(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
+                                    int32_t g, int32_t m, const int32_t* Yp, const int32_t* Yi, const double* Yx,
+                                    int32_t n, double* S_out);
 /* normalize_medians(x, ignore.zero), R/plaid.R:554-575, in place; med_out (n) may be NULL */
 int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,
                                double* med_out);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "plaidhip_dev_spmm_ranks_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_ranks_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_crossprod_weighted_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _i64],
+    "plaidhip_dev_crossprod_weighted_csc_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64],
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _vp],
     "plaidhip_dev_colranks_csc_dense_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
@@ -67,6 +69,8 @@ SIGNATURES = {
     "plaidhip_dev_max": [_vp, _vp, _i64, _vp],
     "plaidhip_plaid_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
     "plaidhip_plaid_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
+    "plaidhip_crossprod_weighted_dense": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
+    "plaidhip_crossprod_weighted_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
     "plaidhip_normalize_medians": [_vp, _vp, _i32, _i32, _int, _vp],
     "plaidhip_colranks_dense": [_vp, _vp, _i32, _i32, _int, _int, _vp],
     "plaidhip_colranks_csc": [_vp, _vp, _vp, _i32, _int, _int, _vp],

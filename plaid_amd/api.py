@@ -102,44 +102,61 @@ def _crossprod_block(ctx, X: NamedMatrix, j0, j1, Gp, Gi, stats, normalize):
 
 
 def chunked_crossprod(x, y, chunk=None, ctx: Context | None = None):
-    """chunked_crossprod(), R/plaid.R:100-123: t(x) %*% y, `x` the genes x sets membership
-    (binary, optionally column-scaled as plaid() builds it, :73-77), `y` genes x samples with
-    the same rows.  Arbitrary per-entry weights in `x` are outside this path."""
+    """chunked_crossprod(), R/plaid.R:100-123: t(x) %*% y, `x` genes x sets, `y` genes x samples with the same rows.
+    A binary `x`, optionally column-scaled as plaid() builds it (:73-77), takes the scheduled membership kernels; an
+    `x` whose stored values differ inside a column (weighted or signed sets) takes the general sparse kernel
+    (plaidhip_crossprod_weighted_*).  Both run on the device; there is no host fallback."""
     x, y = as_named(x), as_named(y)
     if x.shape[0] != y.shape[0]:
         raise ValueError("non-conformable arguments")
     G = sp.csc_matrix(x.values)
+    G.sort_indices()
     m = G.shape[1]
+    ctx = ctx or default_context()
+    n = y.shape[1]
+    if chunk is None or chunk < 0:
+        chunk = _auto_chunk(m)
     scale = np.ones(m)
     nz = G.data != 0
     col = np.repeat(np.arange(m), np.diff(G.indptr))
+    weighted = False
     if nz.any():
         vmin = np.full(m, np.inf)
         vmax = np.full(m, -np.inf)
         np.minimum.at(vmin, col[nz], G.data[nz])
         np.maximum.at(vmax, col[nz], G.data[nz])
-        has = np.isfinite(vmin)
-        if np.any(vmin[has] != vmax[has]):
-            raise PlaidHipError(EUNSUPPORTED, "chunked_crossprod: x must be a 0/1 membership matrix, "
-                                              "optionally scaled per column")
-        scale[has] = vmin[has]
-    counts = np.bincount(col[nz], minlength=m)
-    Gp = np.zeros(m + 1, dtype=np.int64)
-    np.cumsum(counts, out=Gp[1:])
-    Gp, Gi = Gp.astype(np.int32), G.indices[nz].astype(np.int32)
-    ctx = ctx or default_context()
-    n = y.shape[1]
-    if chunk is None or chunk < 0:
-        chunk = _auto_chunk(m)
+        has = np.isfinite(vmin) & np.isfinite(vmax)
+        # NaN / Inf weights or different values inside a column: not a (scaled) membership pattern
+        weighted = bool(np.any(vmin[has] != vmax[has])) or not np.all(np.isfinite(G.data[nz]))
+        if not weighted:
+            scale[has] = vmin[has]
+    if weighted:
+        Wp, Wi, Wx = G.indptr.astype(np.int32), G.indices.astype(np.int32), G.data.astype(np.float64)
+        g = x.shape[0]
+
+        def block(j0, j1):
+            if y.is_sparse:
+                V = sp.csc_matrix(y.values[:, j0:j1])
+                return ctx.crossprod_weighted(Wp, Wi, Wx, g, Yp=V.indptr, Yi=V.indices, Yx=V.data)
+            return ctx.crossprod_weighted(Wp, Wi, Wx, g, Y=y.values[:, j0:j1])
+    else:
+        counts = np.bincount(col[nz], minlength=m)
+        Gp = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(counts, out=Gp[1:])
+        Gp, Gi = Gp.astype(np.int32), G.indices[nz].astype(np.int32)
+
+        def block(j0, j1):
+            return _crossprod_block(ctx, y, j0, j1, Gp, Gi, "sum", False)
     if n < chunk:
-        S = _crossprod_block(ctx, y, 0, n, Gp, Gi, "sum", False)
+        S = block(0, n)
     else:
         _message(f"[chunked_crossprod] chunked compute: chunk = {chunk}")
         S = np.empty((m, n), dtype=np.float64, order="F")
         for j0 in range(0, n, chunk):
             j1 = min(n, j0 + chunk)
-            S[:, j0:j1] = _crossprod_block(ctx, y, j0, j1, Gp, Gi, "sum", False)
-    S *= scale[:, None]
+            S[:, j0:j1] = block(j0, j1)
+    if not weighted:
+        S *= scale[:, None]
     return NamedMatrix(S, x.colnames, y.colnames)
 
 

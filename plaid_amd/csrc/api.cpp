@@ -415,6 +415,33 @@ int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                              static_cast<uint32_t*>(flags));
 }
 
+int plaidhip_dev_crossprod_weighted_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
+                                        int32_t m, const void* Y, int64_t ldy, int32_t n, void* S, int64_t lds) {
+  PH_CTX(ctx);
+  PH_REQUIRE(g > 0 && m >= 0 && n >= 0, "crossprod_weighted: bad dims g=%d m=%d n=%d", g, m, n);
+  PH_REQUIRE(Wp != nullptr, "crossprod_weighted: null x@p");
+  PH_REQUIRE((int64_t)m * n == 0 || (Y != nullptr && S != nullptr), "crossprod_weighted: null y/S");
+  PH_REQUIRE(ldy >= g && lds >= m, "crossprod_weighted: leading dims ldy=%lld (g=%d) lds=%lld (m=%d)", (long long)ldy, g,
+             (long long)lds, m);
+  return launch_crossprod_weighted_f64(ctx, static_cast<const int32_t*>(Wp), static_cast<const int32_t*>(Wi),
+                                       static_cast<const double*>(Wx), g, m, static_cast<const double*>(Y), ldy, nullptr,
+                                       nullptr, nullptr, n, static_cast<double*>(S), lds);
+}
+
+int plaidhip_dev_crossprod_weighted_csc_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
+                                            int32_t m, const void* Yp, const void* Yi, const void* Yx, int32_t n,
+                                            void* S, int64_t lds) {
+  PH_CTX(ctx);
+  PH_REQUIRE(g > 0 && m >= 0 && n >= 0, "crossprod_weighted_csc: bad dims g=%d m=%d n=%d", g, m, n);
+  PH_REQUIRE(Wp != nullptr, "crossprod_weighted_csc: null x@p");
+  PH_REQUIRE((int64_t)m * n == 0 || (Yp != nullptr && S != nullptr), "crossprod_weighted_csc: null y@p/S");
+  PH_REQUIRE(lds >= m, "crossprod_weighted_csc: lds=%lld < m=%d", (long long)lds, m);
+  return launch_crossprod_weighted_f64(ctx, static_cast<const int32_t*>(Wp), static_cast<const int32_t*>(Wi),
+                                       static_cast<const double*>(Wx), g, m, nullptr, 0, static_cast<const int32_t*>(Yp),
+                                       static_cast<const int32_t*>(Yi), static_cast<const double*>(Yx), n,
+                                       static_cast<double*>(S), lds);
+}
+
 static int check_ties(int ties) {
   PH_REQUIRE(ties == PLAIDHIP_TIES_AVERAGE || ties == PLAIDHIP_TIES_MIN || ties == PLAIDHIP_TIES_MAX,
              "colranks: unsupported ties.method code %d (average/min/max)", ties);
@@ -530,6 +557,66 @@ int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, 
   PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_csc: bad stat %d", stat);
   PH_REQUIRE(Xp != nullptr && (n == 0 || S_out), "plaid_csc: null Xp/S_out");
   return run_sharded(&ctx, 1, 0, Xp, Xi, Xx, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
+}
+
+// chunked_crossprod with a general sparse x: upload the slots, one launch, download (host pointers)
+static int crossprod_weighted_host(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx, int32_t g,
+                                   int32_t m, const double* Y, const int32_t* Yp, const int32_t* Yi, const double* Yx,
+                                   int32_t n, double* S_out) {
+  PH_REQUIRE(g > 0 && m >= 0 && n >= 0, "crossprod_weighted: bad dims g=%d m=%d n=%d", g, m, n);
+  if ((int64_t)m * n == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(S_out != nullptr, "crossprod_weighted: null S_out");
+  PH_TRY(check_host_csc(Wp, Wi, g, m));
+  const int64_t zw = Wp[m];
+  PH_REQUIRE(zw == 0 || (Wi != nullptr && Wx != nullptr), "crossprod_weighted: null x@i / x@x");
+  int64_t zy = 0;
+  if (Yp != nullptr) {
+    PH_TRY(check_host_csc(Yp, Yi, g, n));
+    zy = Yp[n];
+    PH_REQUIRE(zy == 0 || (Yi != nullptr && Yx != nullptr), "crossprod_weighted: null y@i / y@x");
+  } else {
+    PH_REQUIRE(Y != nullptr, "crossprod_weighted: null y");
+  }
+  DevBuf dWp, dWi, dWx, dY, dYi, dYx, dS;
+  PH_TRY(dWp.alloc((size_t)(m + 1) * 4));
+  PH_TRY(dWi.alloc((size_t)(zw > 0 ? zw : 1) * 4));
+  PH_TRY(dWx.alloc((size_t)(zw > 0 ? zw : 1) * 8));
+  PH_TRY(dS.alloc((size_t)m * n * 8));
+  PH_TRY(h2d(ctx, dWp.p, Wp, (size_t)(m + 1) * 4));
+  PH_TRY(h2d(ctx, dWi.p, Wi, (size_t)zw * 4));
+  PH_TRY(h2d(ctx, dWx.p, Wx, (size_t)zw * 8));
+  if (Yp != nullptr) {
+    PH_TRY(dY.alloc((size_t)(n + 1) * 4));
+    PH_TRY(dYi.alloc((size_t)(zy > 0 ? zy : 1) * 4));
+    PH_TRY(dYx.alloc((size_t)(zy > 0 ? zy : 1) * 8));
+    PH_TRY(h2d(ctx, dY.p, Yp, (size_t)(n + 1) * 4));
+    PH_TRY(h2d(ctx, dYi.p, Yi, (size_t)zy * 4));
+    PH_TRY(h2d(ctx, dYx.p, Yx, (size_t)zy * 8));
+    PH_TRY(launch_crossprod_weighted_f64(ctx, dWp.as<int32_t>(), dWi.as<int32_t>(), dWx.as<double>(), g, m, nullptr, 0,
+                                         dY.as<int32_t>(), dYi.as<int32_t>(), dYx.as<double>(), n, dS.as<double>(), m));
+  } else {
+    PH_TRY(dY.alloc((size_t)g * n * 8));
+    PH_TRY(h2d(ctx, dY.p, Y, (size_t)g * n * 8));
+    PH_TRY(launch_crossprod_weighted_f64(ctx, dWp.as<int32_t>(), dWi.as<int32_t>(), dWx.as<double>(), g, m, dY.as<double>(),
+                                         g, nullptr, nullptr, nullptr, n, dS.as<double>(), m));
+  }
+  PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return PLAIDHIP_OK;
+}
+
+int plaidhip_crossprod_weighted_dense(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
+                                      int32_t g, int32_t m, const double* Y, int32_t n, double* S_out) {
+  PH_CTX(ctx);
+  return crossprod_weighted_host(ctx, Wp, Wi, Wx, g, m, Y, nullptr, nullptr, nullptr, n, S_out);
+}
+
+int plaidhip_crossprod_weighted_csc(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
+                                    int32_t g, int32_t m, const int32_t* Yp, const int32_t* Yi, const double* Yx,
+                                    int32_t n, double* S_out) {
+  PH_CTX(ctx);
+  PH_REQUIRE(Yp != nullptr, "crossprod_weighted_csc: null y@p");
+  return crossprod_weighted_host(ctx, Wp, Wi, Wx, g, m, nullptr, Yp, Yi, Yx, n, S_out);
 }
 
 int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,

@@ -242,6 +242,10 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         // bounded: every stored value lies in [0, xmax] (rank weights; xmax = max(rX) on the device, or on
                         // the host when xmax_dev is null): the scatter kernel may use exact fixed-point accumulators
                         bool bounded = false, const double* xmax_dev = nullptr, double xmax_host = 0.0);
+// kernels_wspmm.hip: t(x) %*% y for a sparse x with arbitrary values (device CSC slots); y dense (Yp == nullptr) or CSC
+int launch_crossprod_weighted_f64(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx, int32_t g,
+                                  int32_t m, const double* Y, int64_t ldy, const int32_t* Yp, const int32_t* Yi,
+                                  const double* Yx, int32_t n, double* S, int64_t lds);
 #ifdef PLAIDHIP_DIAG
 void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ build only, make diag)
 void debug_set_rank_stamps(void* dbg);          // per-phase cycle stamps of the bucket rank kernel

@@ -142,6 +142,17 @@ class Context:
         check(self.lib.plaidhip_dev_spmm_csc_ranks_f64(self.handle, gs.handle, Xp, Xi, Rx, n, int(nnz), STAT[stat], alpha,
                                                        rmax, beta, S, lds, flags))
 
+    def dev_crossprod_weighted(self, Wp: int, Wi: int, Wx: int, g: int, m: int, Y: int, ldy: int, n: int, S: int,
+                               lds: int):
+        """t(x) %*% y for a sparse x with arbitrary stored values (device dgCMatrix slots), y dense"""
+        check(self.lib.plaidhip_dev_crossprod_weighted_f64(self.handle, Wp, Wi, Wx, int(g), int(m), Y, int(ldy), int(n),
+                                                           S, int(lds)))
+
+    def dev_crossprod_weighted_csc(self, Wp: int, Wi: int, Wx: int, g: int, m: int, Yp: int, Yi: int, Yx: int,
+                                   n: int, S: int, lds: int):
+        check(self.lib.plaidhip_dev_crossprod_weighted_csc_f64(self.handle, Wp, Wi, Wx, int(g), int(m), Yp, Yi, Yx,
+                                                               int(n), S, int(lds)))
+
     def dev_colranks_dense(self, X: int, ldx: int, g: int, n: int, R: int, ldr: int, ties="average",
                            signed=False, power=1.0, colmax: int | None = None):
         check(self.lib.plaidhip_dev_colranks_dense_f64(self.handle, X, ldx, g, n, TIES[ties], int(signed),
@@ -194,6 +205,27 @@ class Context:
         check(self.lib.plaidhip_plaid_csc(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n,
                                           _np_ptr(Gp), _np_ptr(Gi), m, STAT[stat], int(bool(normalize)),
                                           _np_ptr(S)))
+        return S
+
+    def crossprod_weighted(self, Wp, Wi, Wx, g: int, Y=None, Yp=None, Yi=None, Yx=None) -> np.ndarray:
+        """chunked_crossprod's t(x) %*% y for a sparse x with arbitrary stored values (R/plaid.R:100-123); y dense
+        (`Y`, g x n) or its dgCMatrix slots"""
+        Wp, Wi = _as_i32(Wp), _as_i32(Wi)
+        Wx = np.ascontiguousarray(Wx, dtype=np.float64)
+        m = len(Wp) - 1
+        if Y is not None:
+            Y = _as_f64_fortran(Y)
+            n = Y.shape[1]
+            S = np.empty((m, n), dtype=np.float64, order="F")
+            check(self.lib.plaidhip_crossprod_weighted_dense(self.handle, _np_ptr(Wp), _np_ptr(Wi), _np_ptr(Wx), int(g), m,
+                                                             _np_ptr(Y), n, _np_ptr(S)))
+            return S
+        Yp, Yi = _as_i32(Yp), _as_i32(Yi)
+        Yx = np.ascontiguousarray(Yx, dtype=np.float64)
+        n = len(Yp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_crossprod_weighted_csc(self.handle, _np_ptr(Wp), _np_ptr(Wi), _np_ptr(Wx), int(g), m,
+                                                       _np_ptr(Yp), _np_ptr(Yi), _np_ptr(Yx), n, _np_ptr(S)))
         return S
 
     def normalize_medians(self, S, ignore_zero=None):

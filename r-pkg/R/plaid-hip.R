@@ -75,31 +75,47 @@ plaid <- function(X, matG, stats = c("mean", "sum"), chunk = NULL, normalize = T
   S
 }
 
-## chunked_crossprod(x, y, chunk), R/plaid.R:100-123: t(x) %*% y for the membership matrix plaid() builds
-## (0/1, optionally scaled per column, R/plaid.R:73-77) -- internal in the reference too.  The column scale is
-## read off x and applied to the device's unscaled sums; the chunk loop and its message are the reference's
-## (the device has no 2^31 limit, the loop only bounds the size of one transfer).  An x with different values
-## inside a column is not a membership matrix: Matrix::crossprod keeps that case.
+## chunked_crossprod(x, y, chunk), R/plaid.R:100-123: t(x) %*% y -- internal in the reference too.  For the
+## membership matrix plaid() builds (0/1, optionally scaled per column, R/plaid.R:73-77) the column scale is read off x
+## and applied to the device's unscaled sums (the scheduled membership kernels); an x whose stored values differ inside
+## a column (weighted / signed sets) goes to the general sparse kernel with its @p / @i / @x slots as they are.  The
+## chunk loop and its message are the reference's (the device has no 2^31 limit, the loop only bounds the size of one
+## transfer).
 chunked_crossprod <- function(x, y, chunk = NULL) {
   x <- methods::as(methods::as(x, "CsparseMatrix"), "generalMatrix")
   if (nrow(x) != nrow(y)) stop("non-conformable arguments")
   col <- rep.int(seq_len(ncol(x)), diff(x@p))
-  nz <- x@x != 0
+  nz <- x@x != 0 | is.na(x@x)
   lo <- tapply(x@x[nz], factor(col[nz], levels = seq_len(ncol(x))), min)
   hi <- tapply(x@x[nz], factor(col[nz], levels = seq_len(ncol(x))), max)
-  if (any(lo != hi, na.rm = TRUE)) return(Matrix::crossprod(x, y))
-  scale <- ifelse(is.na(lo), 1, lo)
-  Gp <- c(0L, cumsum(tabulate(col[nz], nbins = ncol(x))))
-  Gi <- x@i[nz]
+  weighted <- any(lo != hi, na.rm = TRUE) || any(!is.finite(x@x[nz]))
   if (is.null(chunk) || chunk < 0) chunk <- round(0.8 * 2147483647 / ncol(x))     # R/plaid.R:103-104
   .session()
-  block <- function(jj) {
-    yy <- y[, jj, drop = FALSE]
-    if (inherits(yy, "CsparseMatrix")) {
-      .Call("R_plaidhip_plaid_csc", yy@p, yy@i, as.double(yy@x), nrow(yy), Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
-    } else {
-      yy <- as.matrix(yy); storage.mode(yy) <- "double"
-      .Call("R_plaidhip_plaid_dense", yy, Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
+  if (weighted) {
+    Wx <- as.double(x@x)
+    block <- function(jj) {
+      yy <- y[, jj, drop = FALSE]
+      if (inherits(yy, "CsparseMatrix")) {
+        .Call("R_plaidhip_crossprod_weighted_csc", x@p, x@i, Wx, yy@p, yy@i, as.double(yy@x), nrow(yy),
+              PACKAGE = "plaidhip")
+      } else {
+        yy <- as.matrix(yy); storage.mode(yy) <- "double"
+        .Call("R_plaidhip_crossprod_weighted_dense", x@p, x@i, Wx, yy, PACKAGE = "plaidhip")
+      }
+    }
+    scale <- 1
+  } else {
+    scale <- ifelse(is.na(lo), 1, lo)
+    Gp <- c(0L, cumsum(tabulate(col[nz], nbins = ncol(x))))
+    Gi <- x@i[nz]
+    block <- function(jj) {
+      yy <- y[, jj, drop = FALSE]
+      if (inherits(yy, "CsparseMatrix")) {
+        .Call("R_plaidhip_plaid_csc", yy@p, yy@i, as.double(yy@x), nrow(yy), Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
+      } else {
+        yy <- as.matrix(yy); storage.mode(yy) <- "double"
+        .Call("R_plaidhip_plaid_dense", yy, Gp, Gi, 1L, FALSE, PACKAGE = "plaidhip")
+      }
     }
   }
   if (ncol(y) < chunk) {

@@ -61,6 +61,26 @@ SEXP R_plaidhip_plaid_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi, S
   return S;
 }
 
+/* chunked_crossprod(x, y) with a general sparse x (stored values differ inside a column): x as its dgCMatrix slots,
+ * y a numeric matrix (R/plaid.R:107, :117: Matrix::crossprod(x, y[, jj])) */
+SEXP R_plaidhip_crossprod_weighted_dense(SEXP Wp, SEXP Wi, SEXP Wx, SEXP Y) {
+  const int g = Rf_nrows(Y), n = Rf_ncols(Y), m = LENGTH(Wp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_crossprod_weighted_dense(ctx(), INTEGER(Wp), INTEGER(Wi), REAL(Wx), g, m, REAL(Y), n, REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+/* same for a dgCMatrix y: slots @p, @i, @x and nrow */
+SEXP R_plaidhip_crossprod_weighted_csc(SEXP Wp, SEXP Wi, SEXP Wx, SEXP Yp, SEXP Yi, SEXP Yx, SEXP g) {
+  const int n = LENGTH(Yp) - 1, m = LENGTH(Wp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_crossprod_weighted_csc(ctx(), INTEGER(Wp), INTEGER(Wi), REAL(Wx), Rf_asInteger(g), m, INTEGER(Yp),
+                                        INTEGER(Yi), REAL(Yx), n, REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
 /* normalize_medians(x, ignore.zero): ignore_zero = NA (NULL in R) / FALSE / TRUE */
 SEXP R_plaidhip_normalize_medians(SEXP x, SEXP ignore_zero) {
   const int m = Rf_nrows(x), n = Rf_ncols(x);
@@ -269,6 +289,8 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_session", (DL_FUNC)&R_plaidhip_session, 2},
     {"R_plaidhip_plaid_dense", (DL_FUNC)&R_plaidhip_plaid_dense, 5},
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
+    {"R_plaidhip_crossprod_weighted_dense", (DL_FUNC)&R_plaidhip_crossprod_weighted_dense, 4},
+    {"R_plaidhip_crossprod_weighted_csc", (DL_FUNC)&R_plaidhip_crossprod_weighted_csc, 7},
     {"R_plaidhip_normalize_medians", (DL_FUNC)&R_plaidhip_normalize_medians, 2},
     {"R_plaidhip_colranks_dense", (DL_FUNC)&R_plaidhip_colranks_dense, 3},
     {"R_plaidhip_colranks_csc", (DL_FUNC)&R_plaidhip_colranks_csc, 4},
