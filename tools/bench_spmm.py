@@ -167,6 +167,29 @@ def main():
     with torch.cuda.stream(stream):
         ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
     torch.cuda.synchronize()
+    if a.kernel == "step":
+        # the plaid() step phase by phase (crossprod / medians + mean / shift), as bench.py's C2 block enqueues it
+        red = torch.zeros(2, dtype=torch.float64, device=dev)
+        rows = []
+        for k in range(a.iters + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            with torch.cuda.stream(stream):
+                flags.zero_()
+                e[0].record(stream)
+                ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
+                e[1].record(stream)
+                ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+                ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
+                e[2].record(stream)
+                ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
+                e[3].record(stream)
+            torch.cuda.synchronize()
+            if k:
+                rows.append([e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3]), e[0].elapsed_time(e[3])])
+        r = np.array(rows)
+        print(f"step ({g}x{n}x{m}) nt={a.nt_store}: min ms  spmm {r[:,0].min():.4f}  "
+              f"medians+sum {r[:,1].min():.4f}  shift {r[:,2].min():.4f}  total {r[:,3].min():.4f}  (median total {np.median(r[:,3]):.4f})")
+        return
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
     for k in range(a.iters):
         with torch.cuda.stream(stream):
