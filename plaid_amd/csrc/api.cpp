@@ -268,6 +268,7 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
 #ifdef PLAIDHIP_DIAG
 int plaidhip_debug_set_ablation(int mode, void* dbg) { debug_set_ablation(mode, dbg); return PLAIDHIP_OK; }
 int plaidhip_debug_set_rank_stamps(void* dbg) { debug_set_rank_stamps(dbg); return PLAIDHIP_OK; }
+int plaidhip_debug_set_median_stamps(void* dbg) { debug_set_median_stamps(dbg); return PLAIDHIP_OK; }
 #endif
 
 const char* plaidhip_last_error_string(void) { return g_err; }

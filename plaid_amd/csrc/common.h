@@ -249,6 +249,7 @@ int launch_crossprod_weighted_f64(plaidhip_ctx* ctx, const int32_t* Wp, const in
 #ifdef PLAIDHIP_DIAG
 void debug_set_ablation(int mode, void* dbg);   // diagnostic kernel variants (tools/ build only, make diag)
 void debug_set_rank_stamps(void* dbg);          // per-phase cycle stamps of the bucket rank kernel
+void debug_set_median_stamps(void* dbg);        // per-phase cycle stamps of the wave-per-column median kernel
 #endif
 // kernels_rank.hip
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,

@@ -831,6 +831,201 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 
+// m <= 64 * ITEMS: the same radix selection with ONE WAVEFRONT per column and the keys in its registers (up to 96 per
+// lane): no workgroup barrier anywhere -- a pass is ITEMS LDS atomics per lane into the wavefront's own 256-bin histogram,
+// a scan of the bins by the same wavefront, and wave-uniform results come back through readlane instead of LDS.  Two
+// wavefronts per SIMD (eight columns in flight per CU, 40 KB each at C2) keep the memory system busy while the others
+// select; the workgroup-per-column kernel above holds four columns per CU and spends its time in the two barriers of a pass.
+// The kernel is bound by its vector instructions (~35 per key), so the common steps work on the HIGH dword of the keys:
+// the first range is [min high dword << 32, max high dword << 32 | ~0] -- wider than [min, max] but covering it -- and
+// while a pass shifts by >= 32 bits (the first one or two do) bin and range test are 32-bit operations; the exact 64-bit
+// form takes over below that.
+__device__ const double g_nan_row = __builtin_nan("");
+
+template <int ITEMS, int WG_PER_CU>
+__global__ void __launch_bounds__(256, WG_PER_CU)
+col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
+                        int ignore_zero_mode, const uint32_t* __restrict__ flags, double* __restrict__ med,
+                        unsigned long long* __restrict__ dbg) {
+#ifdef PLAIDHIP_DIAG
+#define PH_MSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - tl; tl = t_; }
+  unsigned long long st[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime(), npass = 0;
+#else
+#define PH_MSTAMP(k)
+#endif
+  // per wavefront 256 bins + 64 private trash bins (one per lane) that keys outside the current range count into: the
+  // atomic is unconditional, so no per-key lane mask has to live in scalar registers across the unrolled loop
+  __shared__ __align__(16) uint32_t s_hist[4][320];
+  const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* hist = s_hist[wave];
+  *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+  hist[256 + lane] = 0u;
+  wave_lds_sync();
+  const uint32_t trash = 256u + (uint32_t)lane;
+  const int nwaves = gridDim.x * 4;
+  for (int c = blockIdx.x * 4 + wave; c < n; c += nwaves) {
+    const double* sc = S + (int64_t)c * lds;
+    uint64_t key[ITEMS];
+    double raw[ITEMS];
+    int lane_o = lane;                       // opaque per column: the clamped offsets are recomputed, not kept in ITEMS registers
+    asm volatile("" : "+v"(lane_o));
+    // rows behind the column's end read a NaN (masked like any other): the lane mask is used up by the address select and
+    // nothing per key has to be kept until the values arrive
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int i = lane_o + j * 64;
+      raw[j] = __builtin_nontemporal_load(i < m ? sc + i : &g_nan_row);
+    }
+    // a valid key never has an all-ones high dword (that would be a NaN): masked <=> high dword == ~0
+    uint32_t hmn = ~0u, hmx = 0u, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint64_t k = masked_key(raw[j], ignore_zero);
+      key[j] = k;
+      const uint32_t h = (uint32_t)(k >> 32);
+      const bool valid = h != ~0u;
+      cnt += (uint32_t)__popcll(__ballot(valid));
+      hmn = h < hmn ? h : hmn;
+      const uint32_t hx = valid ? h : 0u;
+      hmx = hx > hmx ? hx : hmx;
+      if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled loops from running ahead: registers)
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t a = __shfl_xor(hmn, off, 64), b = __shfl_xor(hmx, off, 64);
+      hmn = a < hmn ? a : hmn;
+      hmx = b > hmx ? b : hmx;
+    }
+    hmn = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmn);
+    hmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmx);
+    PH_MSTAMP(0)   // loads + keys + min/max
+    double r;
+    if (cnt == 0) {
+      r = ignore_zero ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+      const uint32_t k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
+      uint64_t lo = (uint64_t)hmn << 32, range = ((uint64_t)(hmx - hmn) << 32) | 0xffffffffull;
+      if (hmx == hmn) {
+        // every valid key shares its high dword (constant or nearly constant column): exact [min, max] of the low dwords
+        uint32_t lmn = ~0u, lmx = 0u;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const bool valid = (uint32_t)(key[j] >> 32) != ~0u;
+          const uint32_t l = (uint32_t)key[j];
+          lmn = (valid && l < lmn) ? l : lmn;
+          lmx = (valid && l > lmx) ? l : lmx;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint32_t a = __shfl_xor(lmn, off, 64), b = __shfl_xor(lmx, off, 64);
+          lmn = a < lmn ? a : lmn;
+          lmx = b > lmx ? b : lmx;
+        }
+        lo |= (uint64_t)lmn;
+        range = (uint64_t)(lmx - lmn);
+      }
+      uint32_t k = k_lo;         // rank wanted inside [lo, lo + range]
+      uint32_t count = cnt;      // keys inside [lo, lo + range]
+      while (range != 0ull && count > 1u) {
+        const int bits = 64 - __clzll((long long)range);
+        const int shift = bits > 8 ? bits - 8 : 0;
+        if (shift >= 32) {
+          // lo has a zero low dword and range an all-ones one (true of the first range and kept by every pass that
+          // shifts by >= 32): bin and range test from the high dwords alone
+          const uint32_t lo_h = (uint32_t)(lo >> 32), range_h = (uint32_t)(range >> 32);
+          const int sh = shift - 32;
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t dh = (uint32_t)(key[j] >> 32) - lo_h;      // below lo wraps above every range; masked keys lie above
+            const uint32_t bin = (dh <= range_h) ? (dh >> sh) : trash;
+            atomicAdd(&hist[bin], 1u);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t d = key[j] - lo;
+            const uint32_t bin = (d <= range) ? (uint32_t)(d >> shift) : trash;
+            atomicAdd(&hist[bin], 1u);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        wave_lds_sync();
+        // lane l owns bins 4l .. 4l+3
+        const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
+        *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
+        }
+        uint32_t excl = incl - mine;
+        const bool here = mine != 0 && excl <= k && k < incl;
+        uint32_t d = 0, hh = h4.x;
+        if (here) {
+          if (k >= excl + h4.x) { excl += h4.x; d = 1; hh = h4.y;
+            if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
+              if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
+        }
+        const int src = __builtin_ctzll(__ballot(here));     // exactly one lane holds the wanted rank
+        const uint32_t dsel = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 4u + d), src);
+        const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)excl, src);
+        count = (uint32_t)__builtin_amdgcn_readlane((int)hh, src);
+        wave_lds_sync();
+        k -= below;
+        lo += (uint64_t)dsel << shift;
+        range = shift ? ((1ull << shift) - 1ull) : 0ull;
+#ifdef PLAIDHIP_DIAG
+        ++npass;
+#endif
+      }
+      PH_MSTAMP(1)   // histogram passes
+      uint64_t V = lo;                       // range == 0: `count` copies of lo
+      if (range != 0ull) {                   // a single key inside a wider bin: fetch it
+        uint64_t f = ~0ull;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint64_t d = key[j] - lo;
+          f = (d <= range) ? key[j] : f;
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)f, off, 64);
+          f = o < f ? o : f;
+        }
+        V = f;
+      }
+      const uint32_t c_le = (k_lo - k) + count;   // keys <= V
+      uint64_t V2 = V;
+      if (k_hi != k_lo && k_hi >= c_le) {
+        // even count and the upper middle is the next distinct key: smallest key above V
+        uint64_t mn = ~0ull;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint64_t t = key[j] - V - 1ull;        // key <= V wraps to the top
+          mn = t < mn ? t : mn;
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mn, off, 64);
+          mn = o < mn ? o : mn;
+        }
+        V2 = mn + V + 1ull;
+      }
+      r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
+    }
+    if (lane == 0) med[c] = r;
+    PH_MSTAMP(2)   // single-key fetch + upper middle
+  }
+#ifdef PLAIDHIP_DIAG
+  if (dbg != nullptr && lane == 0) {
+    unsigned long long* d = dbg + (size_t)(blockIdx.x * 4 + wave) * 4;
+    d[0] = st[0]; d[1] = st[1]; d[2] = st[2]; d[3] = npass;
+  }
+#endif
+#undef PH_MSTAMP
+}
+
 // key of one value as two dwords (same order as masked_key), masked entries -> {~0, ~0}
 struct Key32 { uint32_t hi, lo; };
 __device__ __forceinline__ Key32 masked_key32(double v, int ignore_zero) {
@@ -1246,6 +1441,24 @@ static void launch_bits(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t
                      m, n, ignore_zero, flags, med);
 }
 
+#ifdef PLAIDHIP_DIAG
+static unsigned long long* g_med_dbg = nullptr;   // tools/ build: per-phase stamps of the wave-per-column kernel
+void debug_set_median_stamps(void* dbg) { g_med_dbg = static_cast<unsigned long long*>(dbg); }
+static unsigned long long* median_stamps() { return g_med_dbg; }
+#else
+static unsigned long long* median_stamps() { return nullptr; }
+#endif
+
+template <int ITEMS, int WG_PER_CU>
+static void launch_wave(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
+                        int ignore_zero, const uint32_t* flags, double* med) {
+  const int cap = ctx->num_cu * WG_PER_CU * 4;            // WG_PER_CU workgroups of four wavefronts per CU, several rounds
+  const int need = (n + 3) / 4;
+  const int grid = need < cap ? need : cap;
+  hipLaunchKernelGGL((col_medians_wave_kernel<ITEMS, WG_PER_CU>), dim3(grid), dim3(256), 0, ctx->stream, S, lds, m, n, ignore_zero,
+                     flags, med, median_stamps());
+}
+
 template <int BLOCK, int ITEMS>
 static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                          int ignore_zero, const uint32_t* flags, double* med) {
@@ -1258,7 +1471,8 @@ static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                        int ignore_zero, const uint32_t* flags, double* med) {
   if (n == 0) return PLAIDHIP_OK;
-  // default: register-resident radix selection up to 6,144 values per column, wave-per-column streaming beyond
+  // default: register-resident radix selection up to 6,144 values per column (one wavefront per column up to 5,120, a
+  // workgroup per column above), wave-per-column streaming beyond
   // (switch-over measured).  PLAIDHIP_MEDIAN_KERNEL = stream | radix | bits | sample | sort |
   // select forces one of the kernels in the tools/ build (make diag; the older ones are kept as cross-checks)
 #ifdef PLAIDHIP_DIAG
@@ -1272,7 +1486,18 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   const bool want_bits = force && force[0] == 'b';
   const bool want_sample = f2 && force[1] == 'a';
   const bool want_select = f2 && force[1] == 'e';   // "sort" (or anything else): the LDS bitonic sort when it fits
-  if (want_stream) {
+  // wave-per-column register-resident selection up to 5,120 values (measured against the workgroup-per-column radix
+  // kernel on 10k columns: 1,000 sets 0.024 vs 0.049 ms, 3,000: 0.063 vs 0.096, 5,000: 0.119 vs 0.176; 6,000 needs 96
+  // keys per lane = one wavefront per SIMD and loses, 0.226 vs 0.202)
+  const bool want_wave = (force && force[0] == 'w') || (!force && m <= 5120);
+  if (want_wave && m <= 6144) {
+    if (m <= 1024) launch_wave<16, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 2048) launch_wave<32, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 3072) launch_wave<48, 3>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 4096) launch_wave<64, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else if (m <= 5120) launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else launch_wave<96, 1>(ctx, S, lds, m, n, ignore_zero, flags, med);
+  } else if (want_stream) {
     const int cap = ctx->num_cu * 8;                      // 8 workgroups x 4 wavefronts per CU
     const int need = (n + 3) / 4;
     // candidate lists of the sampled start: a quarter of a column per wavefront in flight (the sample interval holds

@@ -338,7 +338,7 @@ def test_c2_full_size_properties(hip_ctx):
     close(N2, N1)
 
 
-@pytest.mark.parametrize("m", [1, 2, 3, 64, 2048, 2049, 4096, 4097, 5000, 5120, 5121, 6144, 6145, 16384, 20000, 33000, 50000, 65536, 65537, 70000])
+@pytest.mark.parametrize("m", [1, 2, 3, 64, 65, 1024, 1025, 2048, 2049, 3072, 3073, 4096, 4097, 5000, 5120, 5121, 6144, 6145, 16384, 20000, 33000, 50000, 65536, 65537, 70000])
 def test_medians_every_kernel_size_class(hip_ctx, m):
     """column lengths across the register-resident classes (<=2048/6144/16384/32768/65536), the
     radix-select fallback beyond, heavy ties, both parities of the valid count"""
@@ -354,6 +354,27 @@ def test_medians_every_kernel_size_class(hip_ctx, m):
     for iz in (True, False):
         exp, _ = _oracle().normalize_medians(S, iz)
         got, med = hip_ctx.normalize_medians(S, iz)
+        close(got, exp)
+
+
+@pytest.mark.parametrize("m,n", [(300, 40000), (1500, 20000), (5000, 9000)])
+def test_medians_wave_kernel_many_columns_per_wavefront(hip_ctx, m, n):
+    """the wave-per-column kernel (m <= 5,120) with more columns than wavefronts in the grid: the histogram and the
+    trash bins are reused column after column; ties, zeros, NaN columns, both ignore.zero settings; bit-exact medians"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(m + n)
+    S = rng.normal(8.0, 0.2, size=(m, n))
+    S[:, ::7] = np.round(S[:, ::7], 1)                   # heavy ties
+    S[rng.random(S.shape) < 0.05] = 0.0
+    S[:, 5] = 0.0
+    S[:, 11] = np.nan
+    S[::3, 17] = np.nan
+    S[:, 23] = 3.25                                      # constant column: one high dword, exact low-dword range
+    S[:, 29] = np.where(rng.random(m) < 0.5, 1.0, np.nextafter(1.0, 2.0))
+    for iz in (True, False):
+        exp, emed = c_oracle.normalize_medians(S, iz)
+        got, med = hip_ctx.normalize_medians(S, iz)
+        assert np.array_equal(med, emed, equal_nan=True)
         close(got, exp)
 
 

@@ -167,6 +167,12 @@ def main():
     with torch.cuda.stream(stream):
         ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, flags.data_ptr())
     torch.cuda.synchronize()
+    mdbg = None
+    if a.kernel == "medians" and hasattr(ctx.lib, "plaidhip_debug_set_median_stamps"):
+        import ctypes
+        mdbg = torch.zeros(8192 * 4 * 4, dtype=torch.int64, device=dev)
+        ctx.lib.plaidhip_debug_set_median_stamps.argtypes = [ctypes.c_void_p]
+        ctx.lib.plaidhip_debug_set_median_stamps(mdbg.data_ptr())
     if a.kernel == "step":
         # the plaid() step phase by phase (crossprod / medians + mean / shift), as bench.py's C2 block enqueues it
         red = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -206,6 +212,13 @@ def main():
     print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
     if a.kernel == "medians":
         print("  flags words (3 = bracket misses over all launches):", flags.cpu().tolist())
+        if mdbg is not None:
+            d = mdbg.cpu().numpy().reshape(-1, 4).astype(float)
+            d = d[d[:, 0] > 0]
+            tot = d[:, :3].sum(axis=1).mean()
+            print(f"  stamps (mean over {len(d)} wavefronts, last launch; 100 MHz ticks): load+keys+minmax {d[:,0].mean():.0f} "
+                  f"({100*d[:,0].mean()/tot:.0f}%)  passes {d[:,1].mean():.0f} ({100*d[:,1].mean()/tot:.0f}%)  fetch+upper {d[:,2].mean():.0f} "
+                  f"({100*d[:,2].mean()/tot:.0f}%)  passes per column (last launch) {d[:,3].sum() / n:.2f}")
     if a.ablate == 4 or (a.ablate in (2, 5, 6, 7) and True):
         waves = info["waves"]
         nwg = min(n, 256)
