@@ -1102,6 +1102,111 @@ __device__ __forceinline__ void sweep_column_f64(const double* __restrict__ sc, 
   }
 }
 
+// The same walk, software-pipelined: the 8 KiB of batch k + 1 are requested before batch k is processed (two register
+// buffers), so a wavefront always has a batch in flight while it classifies the previous one.  The plain walk issues a
+// batch, waits for all of it, processes it, and only then asks for the next: with the 16 wavefronts per CU this kernel's
+// LDS lists allow, the column sweep ran at 3.5 TB/s with the vector units 60 % idle.  f must issue the same memory
+// operations for every batch (no wave-uniform branch around a store): hipcc's wait counters then stay exact and the
+// wait before batch k is "all but the 8 loads of batch k + 1", not "everything".  after_batch() runs behind every batch
+// (wave-uniform work: flushing a staging list).
+template <typename F, typename G>
+__device__ __forceinline__ void sweep_column_f64_pipelined(const double* __restrict__ sc, int32_t m, int lane, F&& f, G&& after_batch) {
+  constexpr int UN = 8;
+  const int head = (int)((reinterpret_cast<uintptr_t>(sc) >> 3) & 1u);   // first element not 16-byte aligned
+  const int npairs = (m - head) >> 1;
+  const int tail = (m - head) & 1;
+  {
+    double v = 0.0;
+    bool ok = false;
+    if (lane == 0 && head) { v = sc[0]; ok = true; }
+    if (lane == 1 && tail) { v = sc[m - 1]; ok = true; }
+    f(v, ok);
+    after_batch();
+  }
+  const f64x2_t* __restrict__ p = reinterpret_cast<const f64x2_t*>(sc + head);
+  f64x2_t va[UN], vb[UN];
+#define PH_SWEEP_LOAD(buf, b0)                                          \
+  _Pragma("unroll") for (int u = 0; u < UN; ++u) {                       \
+    const int i = (b0) + u * 64 + lane;                                  \
+    buf[u] = __builtin_nontemporal_load(p + (i < npairs ? i : (npairs > 0 ? npairs - 1 : 0))); \
+  }
+#define PH_SWEEP_USE(buf, b0)                                            \
+  _Pragma("unroll") for (int u = 0; u < UN; ++u) {                       \
+    const bool ok = (b0) + u * 64 + lane < npairs;                       \
+    f(buf[u].x, ok);                                                     \
+    f(buf[u].y, ok);                                                     \
+  }
+  if (npairs > 0) {
+    PH_SWEEP_LOAD(va, 0)
+    for (int base = 0; base < npairs; base += 2 * 64 * UN) {
+      PH_SWEEP_LOAD(vb, base + 64 * UN)
+      PH_SWEEP_USE(va, base)
+      after_batch();
+      PH_SWEEP_LOAD(va, base + 2 * 64 * UN)
+      PH_SWEEP_USE(vb, base + 64 * UN)
+      after_batch();
+    }
+  }
+#undef PH_SWEEP_LOAD
+#undef PH_SWEEP_USE
+}
+
+// k-th smallest (0-based) of the wavefront's register-resident keys (ITEMS per lane; all-ones = no key) by radix selection
+// over [kmin, kmax] with the wavefront's own histogram (256 bins + a trash bin per lane, all zero on entry and on return):
+// the selection loop of col_medians_wave_kernel in its plain 64-bit form.  `count` = number of keys.
+template <int ITEMS>
+__device__ __forceinline__ uint64_t wave_radix_select(const uint64_t (&key)[ITEMS], uint32_t k, uint32_t count, uint64_t kmin,
+                                                      uint64_t kmax, uint32_t* hist, int lane) {
+  const uint32_t trash = 256u + (uint32_t)lane;
+  uint64_t lo = kmin, range = kmax - kmin;
+  while (range != 0ull && count > 1u) {
+    const int bits = 64 - __clzll((long long)range);
+    const int shift = bits > 8 ? bits - 8 : 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint64_t d = key[j] - lo;          // below lo wraps above every range in use; all-ones lies above kmax
+      atomicAdd(&hist[(d <= range) ? (uint32_t)(d >> shift) : trash], 1u);
+    }
+    wave_lds_sync();
+    const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
+    *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    uint32_t excl = incl - mine;
+    const bool here = mine != 0 && excl <= k && k < incl;
+    uint32_t d = 0, hh = h4.x;
+    if (here) {
+      if (k >= excl + h4.x) { excl += h4.x; d = 1; hh = h4.y;
+        if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
+          if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
+    }
+    const int src = __builtin_ctzll(__ballot(here));
+    const uint32_t dsel = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 4u + d), src);
+    const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)excl, src);
+    count = (uint32_t)__builtin_amdgcn_readlane((int)hh, src);
+    wave_lds_sync();
+    k -= below;
+    lo += (uint64_t)dsel << shift;
+    range = shift ? ((1ull << shift) - 1ull) : 0ull;
+  }
+  if (range == 0ull) return lo;              // `count` copies of lo
+  uint64_t f = ~0ull;                        // a single key inside a wider bin: fetch it
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint64_t d = key[j] - lo;
+    f = (d <= range) ? key[j] : f;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)f, off, 64);
+    f = o < f ? o : f;
+  }
+  return f;
+}
+
 // The search interval is [lo, lo + 2^B - 1]; a key K lies inside iff K - lo does not borrow and
 // (K - lo) >> B == 0.  Its bin is (K - lo) >> shift, shift = max(B - 8, 0).  Everything per key is
 // 32-bit arithmetic (64-bit integer compares and shifts run at a quarter of that rate).
@@ -1129,12 +1234,20 @@ struct RangeTest {
 };
 
 template <int CAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)   // four workgroups per CU is what the LDS lists allow: 128 registers
 col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
                           int ignore_zero_mode, const uint32_t* __restrict__ flags,
-                          double* __restrict__ med, unsigned long long* __restrict__ cand_all, int32_t ccap) {
-  __shared__ __align__(16) uint32_t s_hist[4][256];
-  __shared__ unsigned long long s_list[4][CAP];
+                          double* __restrict__ med, unsigned long long* __restrict__ cand_all, int32_t ccap,
+                          unsigned long long* __restrict__ dbg) {
+#ifdef PLAIDHIP_DIAG
+#define PH_SSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - tl; tl = t_; }
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#else
+#define PH_SSTAMP(k)
+#endif
+  // (+64: a private trash bin / trash slot per lane, so that the classification sweep below is free of branches)
+  __shared__ __align__(16) uint32_t s_hist[4][256 + 64];
+  __shared__ unsigned long long s_list[4][CAP + 64];
   // (measured on 8,192 columns x 50k: 16 chunks no faster than 8; 3 sigma 20 % SLOWER -- a miss costs three sweeps)
   constexpr int kSampleChunks = 8;         // x 64 sample values, spread over the column (<= CAP in all)
   constexpr float kSampleSigmas = 4.0f;
@@ -1163,39 +1276,38 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
     //      sweep and the first two histogram sweeps of the generic path.  If the interval misses the middle
     //      rank (probability ~1e-4 per column for exchangeable data) the generic path starts from scratch.
     if (m > 4 * CAP) {
-      uint32_t ns = 0;
+      // the sample stays in registers (8 keys per lane) and the two bracket keys are SELECTED (two short radix
+      // selections on the wavefront's histogram) instead of read off a sorted list: sorting 512 keys in LDS was 45
+      // compare-exchange stages with four round trips each, 13 % of the kernel's time (in-kernel stamps)
+      uint64_t skey[kSampleChunks];
+      double sraw[kSampleChunks];
 #pragma unroll
       for (int u = 0; u < kSampleChunks; ++u) {
         int64_t i = (int64_t)u * m / kSampleChunks + lane;
-        i = i < m ? i : m - 1;
-        const Key32 kk = masked_key32(sc[i], ignore_zero);
-        const bool valid = kk.hi != 0xffffffffu;
-        const unsigned long long bal = __ballot(valid);
-        if (valid)
-          list[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
-              ((unsigned long long)kk.hi << 32) | kk.lo;
-        ns += (uint32_t)__popcll(bal);
+        sraw[u] = sc[i < m ? i : m - 1];
+      }
+      uint32_t ns = 0;
+      uint64_t smn = ~0ull, smx = 0ull;
+#pragma unroll
+      for (int u = 0; u < kSampleChunks; ++u) {
+        const uint64_t kk = masked_key(sraw[u], ignore_zero);
+        skey[u] = kk;
+        const bool valid = kk != ~0ull;
+        ns += (uint32_t)__popcll(__ballot(valid));
+        smn = kk < smn ? kk : smn;
+        smx = (valid && kk > smx) ? kk : smx;
+      }
+      for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t a_ = (uint64_t)__shfl_xor((unsigned long long)smn, off, 64);
+        const uint64_t b_ = (uint64_t)__shfl_xor((unsigned long long)smx, off, 64);
+        smn = a_ < smn ? a_ : smn;
+        smx = b_ > smx ? b_ : smx;
       }
       const uint32_t mid = ns > 0 ? (ns - 1u) >> 1 : 0u;
       const uint32_t w = (uint32_t)(kSampleSigmas * 0.5f * sqrtf((float)ns)) + 2u;   // kSampleSigmas sigma of a sample quantile's rank
       if (ns >= 256u && mid > w && mid + 1u + w < ns - 1u) {
-        uint32_t N = 2;
-        while (N < ns) N <<= 1;
-        for (uint32_t i = ns + lane; i < N; i += 64) list[i] = ~0ull;
-        wave_lds_sync();
-        for (uint32_t kk2 = 2; kk2 <= N; kk2 <<= 1)
-          for (uint32_t j = kk2 >> 1; j >= 1; j >>= 1) {
-            for (uint32_t t = lane; t < (N >> 1); t += 64) {
-              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const uint32_t p2 = i | j;
-              const bool up = (i & kk2) == 0;
-              const unsigned long long x = list[i], y = list[p2];
-              if ((x > y) == up) { list[i] = y; list[p2] = x; }
-            }
-            wave_lds_sync();
-          }
-        const uint64_t qa = list[mid - w], qb = list[mid + 1u + w];
-        wave_lds_sync();
+        const uint64_t qa = wave_radix_select<kSampleChunks>(skey, mid - w, ns, smn, smx, hist, lane);
+        const uint64_t qb = wave_radix_select<kSampleChunks>(skey, mid + 1u + w, ns, smn, smx, hist, lane);
         const int Bw = qb == qa ? 1 : 64 - __clzll((long long)(qb - qa));   // [qa, qa + 2^Bw - 1] covers [qa, qb]
         RangeTest rt;
         rt.lohi = (uint32_t)(qa >> 32);
@@ -1208,30 +1320,50 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         // instead of sweeping the column a second time (1.36 instead of 2 passes over a column that fits no cache).
         const double qa_d = key_to_f64(qa), qb_d = key_to_f64(qb);
         uint32_t below = 0;
-        sweep_column_f64(sc, m, lane, [&](double v, bool ok) {
+        PH_SSTAMP(0)   // sample: strided loads + sort
+        // Branch-free per value: every lane counts into the histogram (lanes outside the interval into their private trash
+        // bin) and writes its key into the wavefront's LDS list (outside the interval, or past the list's end: into its
+        // trash slot), so the 16 values of a batch are one basic block the scheduler can interleave.  Behind each batch
+        // the staged keys -- about a sixth of the batch -- go to the candidate list in global memory with full-wave
+        // stores.  A batch that stages more than CAP keys (an interval far too wide: heavy ties) gives the list up; the
+        // collect sweep then reads the column, as it does without a list.
+        uint32_t nstage = 0;
+        bool list_ok = cand != nullptr;
+        const uint32_t trash_bin = 256u + (uint32_t)lane, trash_slot = (uint32_t)CAP + (uint32_t)lane;
+        sweep_column_f64_pipelined(sc, m, lane, [&](double v, bool ok) {
           const bool valid = ok && (v == v) && !((ignore_zero != 0) && (v == 0.0));
           const bool lt = valid && (v < qa_d);
           const bool in = valid && !(v < qa_d) && (v <= qb_d);
           cnt += (uint32_t)__popcll(__ballot(valid));
           below += (uint32_t)__popcll(__ballot(lt));
           const unsigned long long bal = __ballot(in);
-          if (bal != 0ull) {
-            if (in) {
-              const double c0 = v + 0.0;                                   // -0 -> +0
-              const uint32_t h = (uint32_t)__double2hiint(c0), l = (uint32_t)__double2loint(c0);
-              const uint32_t sgn = (uint32_t)((int32_t)h >> 31);
-              const uint64_t key = ((uint64_t)(h ^ (sgn | 0x80000000u)) << 32) | (uint64_t)(l ^ sgn);
-              atomicAdd(&hist[(uint32_t)((key - qa) >> rt.shift)], 1u);
-              const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-              if (cand != nullptr && pos < (uint32_t)ccap) cand[pos] = key;
-            }
-            ncand += (uint32_t)__popcll(bal);
+          const double c0 = v + 0.0;                                   // -0 -> +0
+          const uint32_t h = (uint32_t)__double2hiint(c0), l = (uint32_t)__double2loint(c0);
+          const uint32_t sgn = (uint32_t)((int32_t)h >> 31);
+          const uint64_t key = ((uint64_t)(h ^ (sgn | 0x80000000u)) << 32) | (uint64_t)(l ^ sgn);
+          const uint32_t b = (uint32_t)((key - qa) >> rt.shift);
+          atomicAdd(&hist[in ? b : trash_bin], 1u);
+          const uint32_t pos = nstage + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          list[(in && pos < (uint32_t)CAP) ? pos : trash_slot] = key;
+          nstage += (uint32_t)__popcll(bal);
+        }, [&]() {
+          nstage = (uint32_t)__builtin_amdgcn_readfirstlane((int)nstage);
+          if (nstage > (uint32_t)CAP) list_ok = false;
+          if (list_ok && nstage != 0u) {
+            wave_lds_sync();
+            for (uint32_t i = (uint32_t)lane; i < nstage; i += 64u)
+              if (ncand + i < (uint32_t)ccap) cand[ncand + i] = list[i];
+            wave_lds_sync();
           }
+          ncand += nstage;
+          nstage = 0;
         });
+        if (!list_ok) ncand = 0xffffffffu;
+        PH_SSTAMP(1)   // classification sweep
         cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
         below = (uint32_t)__builtin_amdgcn_readfirstlane((int)below);
         ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
-        if (cand == nullptr || ncand > (uint32_t)ccap) ncand = 0;   // no list: the collect sweep reads the column
+        if (cand == nullptr || ncand > (uint32_t)ccap) ncand = 0;   // no list (or given up, or overflown): the collect sweep reads the column
         wave_lds_sync();
         const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
         *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
@@ -1269,6 +1401,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         wave_lds_sync();
       }
     }
+    PH_SSTAMP(2)   // scan of the seeded histogram
     if (!seeded) {
     // ---- generic start, sweep 0: range of the keys' high words and the number of unmasked entries ---------
     uint32_t hmin = 0xffffffffu, hmax = 0u;
@@ -1336,6 +1469,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         lo += (uint64_t)dsel << rt.shift;
         B = rt.shift;
       }
+      PH_SSTAMP(3)   // generic start / further histogram sweeps (none after a seeded start that fits the list)
       uint64_t V = lo, V2 = lo;
       bool need_above = false;
       if (B != 0) {
@@ -1358,21 +1492,36 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         if (ncand != 0u) {
           // the interval lies inside the sample interval: its keys are among the candidates (written by this very
           // wavefront a moment ago: same-wave stores and loads are ordered)
-          for (uint32_t i0 = 0; i0 < ncand; i0 += 64 * 4) {
-            unsigned long long kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)lane;
-              kk[u] = cand[i < ncand ? i : ncand - 1u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const bool ok = i0 + (uint32_t)u * 64u + (uint32_t)lane < ncand;
-              Key32 key{(uint32_t)(kk[u] >> 32), (uint32_t)kk[u]};
-              if (!ok) { key.hi = 0xffffffffu; key.lo = 0xffffffffu; }
-              collect(key);
-            }
+          // (16-byte loads, 8 KiB per batch, the next batch requested before the current one is used: read 256 keys at a
+          //  time with a round trip each, this loop was most of the 18 % of the kernel spent behind the sweep)
+          typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+          const u64x2_t* __restrict__ cp = reinterpret_cast<const u64x2_t*>(cand);
+          const uint32_t npair = (ncand + 1u) >> 1;   // (an odd count reads one slot past the last key: inside the list, masked below)
+          constexpr int CB = 8;
+          u64x2_t ka[CB], kb[CB];
+#define PH_CAND_LOAD(buf, b0)                                            \
+  _Pragma("unroll") for (int u = 0; u < CB; ++u) {                        \
+    const uint32_t i = (b0) + (uint32_t)u * 64u + (uint32_t)lane;         \
+    buf[u] = cp[i < npair ? i : npair - 1u];                              \
+  }
+#define PH_CAND_USE(buf, b0)                                              \
+  _Pragma("unroll") for (int u = 0; u < CB; ++u) {                        \
+    const uint32_t i = 2u * ((b0) + (uint32_t)u * 64u + (uint32_t)lane);  \
+    Key32 k0{(uint32_t)(buf[u].x >> 32), (uint32_t)buf[u].x}, k1{(uint32_t)(buf[u].y >> 32), (uint32_t)buf[u].y}; \
+    if (i >= ncand) { k0.hi = 0xffffffffu; k0.lo = 0xffffffffu; }         \
+    if (i + 1u >= ncand) { k1.hi = 0xffffffffu; k1.lo = 0xffffffffu; }    \
+    collect(k0);                                                          \
+    collect(k1);                                                          \
+  }
+          PH_CAND_LOAD(ka, 0u)
+          for (uint32_t i0 = 0; i0 < npair; i0 += 2u * 64u * CB) {
+            PH_CAND_LOAD(kb, i0 + 64u * CB)
+            PH_CAND_USE(ka, i0)
+            PH_CAND_LOAD(ka, i0 + 2u * 64u * CB)
+            PH_CAND_USE(kb, i0 + 64u * CB)
           }
+#undef PH_CAND_LOAD
+#undef PH_CAND_USE
         } else {
           sweep_column(sc, m, ignore_zero, lane, collect);
         }
@@ -1404,6 +1553,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         const uint32_t c_le = (k_lo - k) + count;
         need_above = k_hi != k_lo && k_hi >= c_le;
       }
+      PH_SSTAMP(4)   // collect (candidates or column) + sort
       if (need_above) {   // rare: the upper middle key is the smallest key above V (one more sweep)
         uint64_t above = ~0ull;
         sweep_column(sc, m, ignore_zero, lane, [&](const Key32& key) {
@@ -1419,7 +1569,15 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
       r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
     }
     if (lane == 0) med[c] = r;
+    PH_SSTAMP(5)   // upper-middle sweep (rare)
   }
+#ifdef PLAIDHIP_DIAG
+  if (dbg != nullptr && lane == 0) {
+    unsigned long long* d = dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+    for (int q = 0; q < 6; ++q) d[q] = st[q];
+  }
+#endif
+#undef PH_SSTAMP
 }
 
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags) {
@@ -1498,7 +1656,12 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
     else if (m <= 5120) launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else launch_wave<96, 1>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (want_stream) {
+#ifdef PLAIDHIP_DIAG
+    static const char* wg_env = getenv("PLAIDHIP_STREAM_WGS");
+    const int cap = ctx->num_cu * (wg_env ? atoi(wg_env) : 8);
+#else
     const int cap = ctx->num_cu * 8;                      // 8 workgroups x 4 wavefronts per CU
+#endif
     const int need = (n + 3) / 4;
     // candidate lists of the sampled start: a quarter of a column per wavefront in flight (the sample interval holds
     // about a sixth; a list that overflows is not used and the column is swept twice as before)
@@ -1511,7 +1674,7 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
       cand = reinterpret_cast<unsigned long long*>(ctx->ws);
     }
     hipLaunchKernelGGL((col_medians_stream_kernel<1024>), dim3(grid), dim3(256), 0, ctx->stream, S,
-                       lds, m, n, ignore_zero, flags, med, cand, ccap);
+                       lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
   } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 4096) launch_radix<256, 16>(ctx, S, lds, m, n, ignore_zero, flags, med);

@@ -170,7 +170,7 @@ def main():
     mdbg = None
     if a.kernel == "medians" and hasattr(ctx.lib, "plaidhip_debug_set_median_stamps"):
         import ctypes
-        mdbg = torch.zeros(8192 * 4 * 4, dtype=torch.int64, device=dev)
+        mdbg = torch.zeros(8192 * 4 * 8, dtype=torch.int64, device=dev)
         ctx.lib.plaidhip_debug_set_median_stamps.argtypes = [ctypes.c_void_p]
         ctx.lib.plaidhip_debug_set_median_stamps(mdbg.data_ptr())
     if a.kernel == "step":
@@ -212,7 +212,14 @@ def main():
     print(f"{a.kernel}: ms per launch min {min(ms):.4f} median {sorted(ms)[len(ms) // 2]:.4f} ({g}x{n}x{m})")
     if a.kernel == "medians":
         print("  flags words (3 = bracket misses over all launches):", flags.cpu().tolist())
-        if mdbg is not None:
+        if mdbg is not None and m > 6144:
+            d = mdbg.cpu().numpy().reshape(-1, 8).astype(float)
+            d = d[d[:, :6].sum(axis=1) > 0]
+            tot = d[:, :6].sum(axis=1).mean()
+            names = ("sample+sort", "classify sweep", "scan", "generic/hist sweeps", "collect+sort", "upper-middle sweep")
+            print(f"  stamps (mean over {len(d)} wavefronts, last launch; cycles per wavefront, {n / max(len(d), 1):.2f} columns each): "
+                  + "  ".join(f"{nm} {d[:, q].mean():.0f} ({100 * d[:, q].mean() / tot:.0f}%)" for q, nm in enumerate(names)))
+        elif mdbg is not None:
             d = mdbg.cpu().numpy().reshape(-1, 4).astype(float)
             d = d[d[:, 0] > 0]
             tot = d[:, :3].sum(axis=1).mean()
