@@ -10,6 +10,8 @@
 #include <cstdlib>
 
 #include "common.h"
+
+#include <type_traits>
 #include "device_sort.h"
 
 namespace plaidhip {
@@ -1330,13 +1332,20 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         uint32_t nstage = 0;
         bool list_ok = cand != nullptr;
         const uint32_t trash_bin = 256u + (uint32_t)lane, trash_slot = (uint32_t)CAP + (uint32_t)lane;
-        sweep_column_f64_pipelined(sc, m, lane, [&](double v, bool ok) {
-          const bool valid = ok && (v == v) && !((ignore_zero != 0) && (v == 0.0));
-          const bool lt = valid && (v < qa_d);
-          const bool in = valid && !(v < qa_d) && (v <= qb_d);
-          cnt += (uint32_t)__popcll(__ballot(valid));
-          below += (uint32_t)__popcll(__ballot(lt));
-          const unsigned long long bal = __ballot(in);
+        auto classify = [&](auto iz_c) {
+          return [&, iz_c](double v, bool ok) {
+          // (ordered compares are false for a NaN: `lt` and `in` need no validity test of their own)
+          // The wave-level masks are built from ballots of SINGLE compares combined with scalar ANDs: the ballot of a
+          // combined predicate is materialised by hipcc as v_cndmask + v_cmp per ballot (6 of the 31 vector instructions
+          // per value); the lane's own `in` below is the same combination as a predicate (scalar ANDs of the same masks).
+          const bool nz = decltype(iz_c)::value ? (v != 0.0) : true;
+          const bool in = ok && nz && !(v < qa_d) && (v <= qb_d);
+          const unsigned long long ltm_ = __ballot(v < qa_d);
+          unsigned long long live = __ballot(ok) & __ballot(v == v);
+          if (decltype(iz_c)::value) live &= __ballot(v != 0.0);
+          const unsigned long long bal = live & __ballot(v <= qb_d) & ~ltm_;
+          cnt += (uint32_t)__popcll(live);
+          below += (uint32_t)__popcll(live & ltm_);
           const double c0 = v + 0.0;                                   // -0 -> +0
           const uint32_t h = (uint32_t)__double2hiint(c0), l = (uint32_t)__double2loint(c0);
           const uint32_t sgn = (uint32_t)((int32_t)h >> 31);
@@ -1346,7 +1355,9 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
           const uint32_t pos = nstage + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
           list[(in && pos < (uint32_t)CAP) ? pos : trash_slot] = key;
           nstage += (uint32_t)__popcll(bal);
-        }, [&]() {
+        };
+        };
+        auto flush = [&]() {
           nstage = (uint32_t)__builtin_amdgcn_readfirstlane((int)nstage);
           if (nstage > (uint32_t)CAP) list_ok = false;
           if (list_ok && nstage != 0u) {
@@ -1357,7 +1368,10 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
           }
           ncand += nstage;
           nstage = 0;
-        });
+        };
+        // (the ignore.zero test is compiled in or out: it is the same for every column of the call)
+        if (ignore_zero != 0) sweep_column_f64_pipelined(sc, m, lane, classify(std::true_type{}), flush);
+        else sweep_column_f64_pipelined(sc, m, lane, classify(std::false_type{}), flush);
         if (!list_ok) ncand = 0xffffffffu;
         PH_SSTAMP(1)   // classification sweep
         cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
