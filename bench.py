@@ -323,7 +323,7 @@ def run_c2(a, env):
     lds_bytes = float(info["padded_slots"]) * 8.0 * n
     roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes), 2.0 * z * n)
     kernels = {
-        "col_medians": _roof("col_medians_wave_kernel" if m <= 5120 else ("col_medians_radix_kernel" if m <= 6144 else "col_medians_stream_kernel"), 8.0 * m * n, med_ms),
+        "col_medians": _roof("col_medians_wave_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms),
         "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
     }
 

@@ -842,8 +842,6 @@ typedef double f64x2_t __attribute__((ext_vector_type(2)));
 // the first range is [min high dword << 32, max high dword << 32 | ~0] -- wider than [min, max] but covering it -- and
 // while a pass shifts by >= 32 bits (the first one or two do) bin and range test are 32-bit operations; the exact 64-bit
 // form takes over below that.
-__device__ const double g_nan_row = __builtin_nan("");
-
 template <int ITEMS, int WG_PER_CU>
 __global__ void __launch_bounds__(256, WG_PER_CU)
 col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
@@ -870,26 +868,43 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
     const double* sc = S + (int64_t)c * lds;
     uint64_t key[ITEMS];
     double raw[ITEMS];
-    int lane_o = lane;                       // opaque per column: the clamped offsets are recomputed, not kept in ITEMS registers
+    int lane_o = lane;                       // opaque per column: the offsets are recomputed, not kept in ITEMS registers
     asm volatile("" : "+v"(lane_o));
-    // rows behind the column's end read a NaN (masked like any other): the lane mask is used up by the address select and
-    // nothing per key has to be kept until the values arrive
+    // The first FULL = ITEMS - 16 rows of 64 lie inside every column this instantiation is launched for (m > 64 FULL):
+    // plain loads, no mask.  Only the last 16 rows can reach past the column's end: clamped address, masked below.
+    constexpr int FULL = ITEMS - 16;
+    const double* __restrict__ scl = sc + lane_o;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const int i = lane_o + j * 64;
-      raw[j] = __builtin_nontemporal_load(i < m ? sc + i : &g_nan_row);
+      if (j < FULL) {
+        raw[j] = __builtin_nontemporal_load(scl + j * 64);
+      } else {
+        const int i = lane_o + j * 64;
+        raw[j] = __builtin_nontemporal_load(sc + (i < m ? i : m - 1));
+      }
     }
+    // (the bound is re-read through an opaque copy: the lane masks of the address clamps above must not be kept in
+    //  scalar registers until the values arrive)
+    int m_use = m;
+    asm volatile("" : "+s"(m_use));
     // a valid key never has an all-ones high dword (that would be a NaN): masked <=> high dword == ~0
     uint32_t hmn = ~0u, hmx = 0u, cnt = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const uint64_t k = masked_key(raw[j], ignore_zero);
-      key[j] = k;
-      const uint32_t h = (uint32_t)(k >> 32);
-      const bool valid = h != ~0u;
-      cnt += (uint32_t)__popcll(__ballot(valid));
+      // masked_key() in 32-bit steps, all-ones for NaN, ignored zeros and the rows behind the column's end
+      const double v = raw[j];
+      const double c0 = v + 0.0;                                   // -0 -> +0
+      const uint32_t h0 = (uint32_t)__double2hiint(c0), l0 = (uint32_t)__double2loint(c0);
+      const uint32_t sgn = (uint32_t)((int32_t)h0 >> 31);
+      bool masked = (v != v) | ((ignore_zero != 0) & (v == 0.0));
+      if (j >= FULL) masked = masked | (lane_o + j * 64 >= m_use);
+      const uint32_t h = masked ? ~0u : (h0 ^ (sgn | 0x80000000u));
+      uint32_t l = masked ? ~0u : (l0 ^ sgn);
+      asm volatile("" : "+v"(l));   // computed HERE: hipcc otherwise sinks it to its first use and keeps sign, mask and raw dword per key until then
+      key[j] = ((uint64_t)h << 32) | l;
+      cnt += (uint32_t)__popcll(__ballot(h != ~0u));
       hmn = h < hmn ? h : hmn;
-      const uint32_t hx = valid ? h : 0u;
+      const uint32_t hx = masked ? 0u : h;
       hmx = hx > hmx ? hx : hmx;
       if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled loops from running ahead: registers)
     }
@@ -1624,6 +1639,9 @@ static unsigned long long* median_stamps() { return nullptr; }
 template <int ITEMS, int WG_PER_CU>
 static void launch_wave(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                         int ignore_zero, const uint32_t* flags, double* med) {
+  static_assert(ITEMS >= 16 && ITEMS % 16 == 0, "classes of 1,024 values");
+  // (the kernel reads its first ITEMS - 16 rows of 64 values without a bound: the caller picks the class by m)
+  if (m <= 64 * (ITEMS - 16) || m > 64 * ITEMS) __builtin_trap();
   const int cap = ctx->num_cu * WG_PER_CU * 4;            // WG_PER_CU workgroups of four wavefronts per CU, several rounds
   const int need = (n + 3) / 4;
   const int grid = need < cap ? need : cap;
@@ -1643,8 +1661,8 @@ static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                        int ignore_zero, const uint32_t* flags, double* med) {
   if (n == 0) return PLAIDHIP_OK;
-  // default: register-resident radix selection up to 6,144 values per column (one wavefront per column up to 5,120, a
-  // workgroup per column above), wave-per-column streaming beyond
+  // default: register-resident radix selection up to 6,144 values per column (one wavefront per column), wave-per-column
+  // streaming beyond
   // (switch-over measured).  PLAIDHIP_MEDIAN_KERNEL = stream | radix | bits | sample | sort |
   // select forces one of the kernels in the tools/ build (make diag; the older ones are kept as cross-checks)
 #ifdef PLAIDHIP_DIAG
@@ -1654,21 +1672,21 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
 #endif
   const bool f2 = force && force[0] == 's';
   const bool want_stream = (f2 && force[1] == 't') || (!force && m > 6144);
-  const bool want_radix = (force && force[0] == 'r') || (!force && m <= 6144);
+  const bool want_radix = force && force[0] == 'r';
   const bool want_bits = force && force[0] == 'b';
   const bool want_sample = f2 && force[1] == 'a';
   const bool want_select = f2 && force[1] == 'e';   // "sort" (or anything else): the LDS bitonic sort when it fits
-  // wave-per-column register-resident selection up to 5,120 values (measured against the workgroup-per-column radix
-  // kernel on 10k columns: 1,000 sets 0.024 vs 0.049 ms, 3,000: 0.063 vs 0.096, 5,000: 0.119 vs 0.176; 6,000 needs 96
-  // keys per lane = one wavefront per SIMD and loses, 0.226 vs 0.202)
-  const bool want_wave = (force && force[0] == 'w') || (!force && m <= 5120);
+  // wave-per-column register-resident selection up to 6,144 values (measured against the workgroup-per-column radix
+  // kernel on 10k columns, one box: 1,000 sets 0.023 vs 0.048 ms, 3,000: 0.058 vs 0.096, 5,000: 0.106 vs 0.179, 6,000:
+  // 0.123 vs 0.202); the workgroup kernel stays selectable in the tools/ build as a cross-check
+  const bool want_wave = (force && force[0] == 'w') || (!force && m <= 6144);
   if (want_wave && m <= 6144) {
     if (m <= 1024) launch_wave<16, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 2048) launch_wave<32, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 3072) launch_wave<48, 3>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 4096) launch_wave<64, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 5120) launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else launch_wave<96, 1>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    else launch_wave<96, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
   } else if (want_stream) {
 #ifdef PLAIDHIP_DIAG
     static const char* wg_env = getenv("PLAIDHIP_STREAM_WGS");

@@ -357,9 +357,9 @@ def test_medians_every_kernel_size_class(hip_ctx, m):
         close(got, exp)
 
 
-@pytest.mark.parametrize("m,n", [(300, 40000), (1500, 20000), (5000, 9000)])
+@pytest.mark.parametrize("m,n", [(300, 40000), (1500, 20000), (5000, 9000), (6100, 5000)])
 def test_medians_wave_kernel_many_columns_per_wavefront(hip_ctx, m, n):
-    """the wave-per-column kernel (m <= 5,120) with more columns than wavefronts in the grid: the histogram and the
+    """the wave-per-column kernel (m <= 6,144) with more columns than wavefronts in the grid: the histogram and the
     trash bins are reused column after column; ties, zeros, NaN columns, both ignore.zero settings; bit-exact medians"""
     from oracle import c_oracle
     rng = np.random.default_rng(m + n)
