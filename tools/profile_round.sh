@@ -8,7 +8,8 @@
 #  * PMC passes (separate --pmc runs: FETCH_SIZE / WRITE_SIZE / the SQ set / TCC hits / GRBM) for the dominant kernels of
 #    C2 (pair kernel), C3 (scatter kernel, fixed-point and fp64 accumulators), C4 (pair kernel at 50k sets, bucket
 #    ranker) and of the rank crossprod (quad kernel), summarised per kernel;
-#  * the micro-benchmarks quoted in DESIGN.md.
+#  * the micro-benchmarks quoted in DESIGN.md (single kernels, the plaid step phase by phase, the general weighted crossprod,
+#    the access-pattern ceiling of the wave-per-column kernels).
 out=${1:-gpurun_out/prof}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
@@ -30,6 +31,7 @@ run_pmc c3 --kernel c3 --samples 8192 --sets 50000 --iters 3
 run_pmc c3f64 --kernel c3 --samples 8192 --sets 50000 --iters 3 --scatter-fixed off --scatter-order column
 run_pmc c4 --kernel c4 --samples 4096 --sets 50000 --iters 3
 run_pmc sing --kernel sing --samples 4096 --sets 50000 --iters 2
+run_pmc c2step --kernel step --iters 3
 python3 tools/bench_spmm.py --kernel c3 --samples 4096 --sets 50000 --iters 3 > $out/c3_4096.log 2>&1
 python3 tools/bench_spmm.py --kernel c4 --samples 2048 --sets 50000 --iters 3 > $out/c4_2048.log 2>&1
 python3 tools/bench_spmm.py --kernel sing --samples 4096 --sets 50000 --iters 3 > $out/sing_4096_50k.log 2>&1
@@ -37,10 +39,14 @@ python3 tools/bench_spmm.py --kernel sing --samples 10000 --sets 5000 --iters 3 
 python3 tools/bench_rank.py > $out/rank.log 2>&1
 python3 tools/bench_shift.py > $out/shift.log 2>&1
 python3 tools/bench_spmm.py --kernel medians --samples 8192 --sets 50000 --iters 10 > $out/medians_50k.log 2>&1
+for m in 1000 3000 5000 6000 8000 20000; do python3 tools/bench_spmm.py --kernel medians --samples 10000 --sets $m --iters 10 2>&1 | grep "^medians" >> $out/medians_sizes.log; done
+python3 tools/bench_spmm.py --kernel step --iters 10 2>&1 | grep "^step" > $out/step_c2.log
+python3 tools/bench_weighted.py > $out/weighted.log 2>&1
+[ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
-for tag in ("c2", "c3", "c3f64", "c4", "sing"):
+for tag in ("c2", "c3", "c3f64", "c4", "sing", "c2step"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + f"/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
