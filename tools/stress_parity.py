@@ -20,7 +20,7 @@ def run_case(ctx, seed):
     out = []
     g = int(rng.choice([7, 64, 300, 2049, 8193, 10224, 10225, 16001, 20352, 20353, 20448, 20449, 26000]))
     n = int(rng.integers(1, 9))
-    m = int(rng.choice([1, 3, 64, 65, 200, 1500, 21000])) if g >= 2049 else int(rng.integers(1, 80))
+    m = int(rng.choice([1, 3, 64, 65, 200, 1500, 3000, 5000, 6100, 21000])) if g >= 2049 else int(rng.integers(1, 80))
     kmax = int(min(g, rng.choice([3, 40, 400])))
     sizes = rng.integers(0, kmax + 1, size=m)
     sets = [np.sort(rng.choice(g, size=int(k), replace=False)) for k in sizes]
