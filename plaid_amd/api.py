@@ -110,7 +110,8 @@ def chunked_crossprod(x, y, chunk=None, ctx: Context | None = None):
     if x.shape[0] != y.shape[0]:
         raise ValueError("non-conformable arguments")
     G = sp.csc_matrix(x.values)
-    G.sort_indices()
+    if not G.has_sorted_indices:
+        G = G.sorted_indices()                                 # (a copy: the caller's matrix is not touched)
     m = G.shape[1]
     ctx = ctx or default_context()
     n = y.shape[1]

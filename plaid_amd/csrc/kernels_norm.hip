@@ -1250,7 +1250,7 @@ struct RangeTest {
   }
 };
 
-template <int CAP>
+template <int CAP, int kSampleChunks>   // kSampleChunks x 64 sample values, spread over the column
 __global__ void __launch_bounds__(256, 4)   // four workgroups per CU is what the LDS lists allow: 128 registers
 col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
                           int ignore_zero_mode, const uint32_t* __restrict__ flags,
@@ -1266,7 +1266,6 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
   __shared__ __align__(16) uint32_t s_hist[4][256 + 64];
   __shared__ unsigned long long s_list[4][CAP + 64];
   // (measured on 8,192 columns x 50k: 16 chunks no faster than 8; 3 sigma 20 % SLOWER -- a miss costs three sweeps)
-  constexpr int kSampleChunks = 8;         // x 64 sample values, spread over the column (<= CAP in all)
   constexpr float kSampleSigmas = 4.0f;
   const int ignore_zero = resolve_ignore_zero(ignore_zero_mode, flags);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1640,8 +1639,6 @@ template <int ITEMS, int WG_PER_CU>
 static void launch_wave(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
                         int ignore_zero, const uint32_t* flags, double* med) {
   static_assert(ITEMS >= 16 && ITEMS % 16 == 0, "classes of 1,024 values");
-  // (the kernel reads its first ITEMS - 16 rows of 64 values without a bound: the caller picks the class by m)
-  if (m <= 64 * (ITEMS - 16) || m > 64 * ITEMS) __builtin_trap();
   const int cap = ctx->num_cu * WG_PER_CU * 4;            // WG_PER_CU workgroups of four wavefronts per CU, several rounds
   const int need = (n + 3) / 4;
   const int grid = need < cap ? need : cap;
@@ -1681,12 +1678,16 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
   // 0.123 vs 0.202); the workgroup kernel stays selectable in the tools/ build as a cross-check
   const bool want_wave = (force && force[0] == 'w') || (!force && m <= 6144);
   if (want_wave && m <= 6144) {
-    if (m <= 1024) launch_wave<16, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 2048) launch_wave<32, 4>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 3072) launch_wave<48, 3>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 4096) launch_wave<64, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else if (m <= 5120) launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
-    else launch_wave<96, 2>(ctx, S, lds, m, n, ignore_zero, flags, med);
+    // (the kernel reads its first ITEMS - 16 rows of 64 values without a bound: the class follows from m, here and only here)
+    const int cls = m <= 1024 ? 16 : ((m + 1023) / 1024) * 16;
+    switch (cls) {
+      case 16: launch_wave<16, 4>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      case 32: launch_wave<32, 4>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      case 48: launch_wave<48, 3>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      case 64: launch_wave<64, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      case 80: launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      default: launch_wave<96, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+    }
   } else if (want_stream) {
 #ifdef PLAIDHIP_DIAG
     static const char* wg_env = getenv("PLAIDHIP_STREAM_WGS");
@@ -1705,8 +1706,21 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
       if (rc != PLAIDHIP_OK) return rc;
       cand = reinterpret_cast<unsigned long long*>(ctx->ws);
     }
-    hipLaunchKernelGGL((col_medians_stream_kernel<1024>), dim3(grid), dim3(256), 0, ctx->stream, S,
-                       lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
+    // sample size: 512 values up to 32,768 sets, 1,024 beyond (a narrower bracket: 12.5 % instead of 17.6 % of the column
+    // become candidates; measured on 8,192 columns, one box: 50k sets 0.975 -> 0.89 ms, 20k equal, 8k 0.160 -> 0.177: the two
+    // bracket selections cost 30 us per column at 512 values and 50 us at 1,024; 2,048 values lose everywhere)
+#ifdef PLAIDHIP_DIAG
+    static const char* sc_env = getenv("PLAIDHIP_SAMPLE_CHUNKS");
+    const int sc = sc_env ? atoi(sc_env) : (m > 32768 ? 16 : 8);
+#else
+    const int sc = m > 32768 ? 16 : 8;
+#endif
+    if (sc == 16)
+      hipLaunchKernelGGL((col_medians_stream_kernel<1024, 16>), dim3(grid), dim3(256), 0, ctx->stream, S,
+                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
+    else
+      hipLaunchKernelGGL((col_medians_stream_kernel<1024, 8>), dim3(grid), dim3(256), 0, ctx->stream, S,
+                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
   } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 4096) launch_radix<256, 16>(ctx, S, lds, m, n, ignore_zero, flags, med);
