@@ -833,6 +833,61 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 
+// Wave-level scan and reductions on the DPP network (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast 15 and
+// 31 across them: the gfx9 sequence) instead of __shfl_up / __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- a round
+// trip through the LDS crossbar per step, six to twelve of them in a dependent chain per scan or 64-bit reduction, in
+// kernels whose wavefronts have nothing else to issue meanwhile.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+#define PH_DPP_STEPS(STEP) STEP(0x111, 0xf, 0xf) STEP(0x112, 0xf, 0xf) STEP(0x114, 0xf, 0xe) STEP(0x118, 0xf, 0xc) \
+                           STEP(0x142, 0xa, 0xf) STEP(0x143, 0xc, 0xf)
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+#define PH_STEP(C, R, B) v += dpp_u32<C, R, B>(0u, v);
+  PH_DPP_STEPS(PH_STEP)
+#undef PH_STEP
+  return v;
+}
+// reductions: the result of all 64 lanes, wave-uniform (read from lane 63)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define PH_STEP(C, R, B) { const uint32_t t = dpp_u32<C, R, B>(0xffffffffu, v); v = t < v ? t : v; }
+  PH_DPP_STEPS(PH_STEP)
+#undef PH_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define PH_STEP(C, R, B) { const uint32_t t = dpp_u32<C, R, B>(0u, v); v = t > v ? t : v; }
+  PH_DPP_STEPS(PH_STEP)
+#undef PH_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#define PH_STEP(C, R, B)                                                                                  \
+  {                                                                                                        \
+    const uint64_t t = ((uint64_t)dpp_u32<C, R, B>(0xffffffffu, (uint32_t)(v >> 32)) << 32) |             \
+                       dpp_u32<C, R, B>(0xffffffffu, (uint32_t)v);                                         \
+    v = t < v ? t : v;                                                                                     \
+  }
+  PH_DPP_STEPS(PH_STEP)
+#undef PH_STEP
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#define PH_STEP(C, R, B)                                                                                  \
+  {                                                                                                        \
+    const uint64_t t = ((uint64_t)dpp_u32<C, R, B>(0u, (uint32_t)(v >> 32)) << 32) | dpp_u32<C, R, B>(0u, (uint32_t)v); \
+    v = t > v ? t : v;                                                                                     \
+  }
+  PH_DPP_STEPS(PH_STEP)
+#undef PH_STEP
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+}
+#undef PH_DPP_STEPS
+
 // m <= 64 * ITEMS: the same radix selection with ONE WAVEFRONT per column and the keys in its registers (up to 96 per
 // lane): no workgroup barrier anywhere -- a pass is ITEMS LDS atomics per lane into the wavefront's own 256-bin histogram,
 // a scan of the bins by the same wavefront, and wave-uniform results come back through readlane instead of LDS.  Two
@@ -908,13 +963,8 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
       hmx = hx > hmx ? hx : hmx;
       if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled loops from running ahead: registers)
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t a = __shfl_xor(hmn, off, 64), b = __shfl_xor(hmx, off, 64);
-      hmn = a < hmn ? a : hmn;
-      hmx = b > hmx ? b : hmx;
-    }
-    hmn = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmn);
-    hmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hmx);
+    hmn = wave_min_u32(hmn);
+    hmx = wave_max_u32(hmx);
     PH_MSTAMP(0)   // loads + keys + min/max
     double r;
     if (cnt == 0) {
@@ -932,11 +982,8 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
           lmn = (valid && l < lmn) ? l : lmn;
           lmx = (valid && l > lmx) ? l : lmx;
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-          const uint32_t a = __shfl_xor(lmn, off, 64), b = __shfl_xor(lmx, off, 64);
-          lmn = a < lmn ? a : lmn;
-          lmx = b > lmx ? b : lmx;
-        }
+        lmn = wave_min_u32(lmn);
+        lmx = wave_max_u32(lmx);
         lo |= (uint64_t)lmn;
         range = (uint64_t)(lmx - lmn);
       }
@@ -971,11 +1018,7 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
         const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
         *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
-        uint32_t incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t t = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += t;
-        }
+        const uint32_t incl = wave_scan_add_u32(mine);
         uint32_t excl = incl - mine;
         const bool here = mine != 0 && excl <= k && k < incl;
         uint32_t d = 0, hh = h4.x;
@@ -1006,11 +1049,7 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
           f = (d <= range) ? key[j] : f;
           if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)f, off, 64);
-          f = o < f ? o : f;
-        }
-        V = f;
+        V = wave_min_u64(f);
       }
       const uint32_t c_le = (k_lo - k) + count;   // keys <= V
       uint64_t V2 = V;
@@ -1023,11 +1062,7 @@ col_medians_wave_kernel(const double* __restrict__ S, int64_t lds, int32_t m, in
           mn = t < mn ? t : mn;
           if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-          const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mn, off, 64);
-          mn = o < mn ? o : mn;
-        }
-        V2 = mn + V + 1ull;
+        V2 = wave_min_u64(mn) + V + 1ull;
       }
       r = (V2 == V) ? key_to_f64(V) : 0.5 * (key_to_f64(V) + key_to_f64(V2));
     }
@@ -1188,11 +1223,7 @@ __device__ __forceinline__ uint64_t wave_radix_select(const uint64_t (&key)[ITEM
     const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
     *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
-    uint32_t incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
+    const uint32_t incl = wave_scan_add_u32(mine);
     uint32_t excl = incl - mine;
     const bool here = mine != 0 && excl <= k && k < incl;
     uint32_t d = 0, hh = h4.x;
@@ -1217,11 +1248,7 @@ __device__ __forceinline__ uint64_t wave_radix_select(const uint64_t (&key)[ITEM
     const uint64_t d = key[j] - lo;
     f = (d <= range) ? key[j] : f;
   }
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)f, off, 64);
-    f = o < f ? o : f;
-  }
-  return f;
+  return wave_min_u64(f);
 }
 
 // The search interval is [lo, lo + 2^B - 1]; a key K lies inside iff K - lo does not borrow and
@@ -1313,12 +1340,8 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         smn = kk < smn ? kk : smn;
         smx = (valid && kk > smx) ? kk : smx;
       }
-      for (int off = 32; off >= 1; off >>= 1) {
-        const uint64_t a_ = (uint64_t)__shfl_xor((unsigned long long)smn, off, 64);
-        const uint64_t b_ = (uint64_t)__shfl_xor((unsigned long long)smx, off, 64);
-        smn = a_ < smn ? a_ : smn;
-        smx = b_ > smx ? b_ : smx;
-      }
+      smn = wave_min_u64(smn);
+      smx = wave_max_u64(smx);
       const uint32_t mid = ns > 0 ? (ns - 1u) >> 1 : 0u;
       const uint32_t w = (uint32_t)(kSampleSigmas * 0.5f * sqrtf((float)ns)) + 2u;   // kSampleSigmas sigma of a sample quantile's rank
       if (ns >= 256u && mid > w && mid + 1u + w < ns - 1u) {
@@ -1397,12 +1420,8 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
         const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
-        uint32_t incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t t = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += t;
-        }
-        const uint32_t inside = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t incl = wave_scan_add_u32(mine);
+        const uint32_t inside = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (cnt > 0u) {
           k_lo = (cnt - 1u) >> 1;
           k_hi = cnt >> 1;
@@ -1415,9 +1434,9 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
               if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
                 if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
             const int src = (int)__builtin_ctzll(__ballot(owner));
-            const uint32_t dsel = (uint32_t)__shfl((int)((uint32_t)lane * 4u + d), src, 64);
-            k -= (uint32_t)__shfl((int)excl, src, 64);
-            count = (uint32_t)__shfl((int)hh, src, 64);
+            const uint32_t dsel = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 4u + d), src);
+            k -= (uint32_t)__builtin_amdgcn_readlane((int)excl, src);
+            count = (uint32_t)__builtin_amdgcn_readlane((int)hh, src);
             lo = qa + ((uint64_t)dsel << rt.shift);
             B = rt.shift;
             seeded = true;
@@ -1478,11 +1497,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         *reinterpret_cast<uint4*>(&hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
         const uint32_t mine = h4.x + h4.y + h4.z + h4.w;
-        uint32_t incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t t = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += t;
-        }
+        const uint32_t incl = wave_scan_add_u32(mine);
         uint32_t excl = incl - mine;
         const bool owner = mine != 0 && excl <= k && k < incl;
         uint32_t d = 0, hh = h4.x;
@@ -1490,9 +1505,9 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
           if (k >= excl + h4.y) { excl += h4.y; d = 2; hh = h4.z;
             if (k >= excl + h4.z) { excl += h4.z; d = 3; hh = h4.w; } } }
         const int src = (int)__builtin_ctzll(__ballot(owner));   // exactly one lane owns the wanted rank
-        const uint32_t dsel = (uint32_t)__shfl((int)((uint32_t)lane * 4u + d), src, 64);
-        const uint32_t below = (uint32_t)__shfl((int)excl, src, 64);
-        count = (uint32_t)__shfl((int)hh, src, 64);
+        const uint32_t dsel = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 4u + d), src);
+        const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)excl, src);
+        count = (uint32_t)__builtin_amdgcn_readlane((int)hh, src);
         k -= below;
         lo += (uint64_t)dsel << rt.shift;
         B = rt.shift;
@@ -1684,7 +1699,7 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
       case 16: launch_wave<16, 4>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
       case 32: launch_wave<32, 4>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
       case 48: launch_wave<48, 3>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
-      case 64: launch_wave<64, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
+      case 64: launch_wave<64, 3>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
       case 80: launch_wave<80, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
       default: launch_wave<96, 2>(ctx, S, lds, m, n, ignore_zero, flags, med); break;
     }
