@@ -1370,7 +1370,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
         bool list_ok = cand != nullptr;
         const uint32_t trash_bin = 256u + (uint32_t)lane, trash_slot = (uint32_t)CAP + (uint32_t)lane;
         auto classify = [&](auto iz_c) {
-          return [&, iz_c](double v, bool ok) {
+          return [&](double v, bool ok) {
           // (ordered compares are false for a NaN: `lt` and `in` need no validity test of their own)
           // The wave-level masks are built from ballots of SINGLE compares combined with scalar ANDs: the ballot of a
           // combined predicate is materialised by hipcc as v_cndmask + v_cmp per ballot (6 of the 31 vector instructions

@@ -996,6 +996,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   while (c < a.n) {
     bool have; int qi_cur;
     PLAIDHIP_ITEM_MINE(rr, q0, q1, qi_cur, have)
+    (void)qi_cur;
     const int ns = have ? s1 - s0 : 0;
     if (!have) v = 0.0;
     if constexpr (FIXED) {   // one rounding to the fixed-point grid; values outside [0, xmax] (or NaN) are not rank weights
