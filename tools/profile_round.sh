@@ -43,6 +43,7 @@ for m in 1000 3000 5000 6000 8000 20000; do python3 tools/bench_spmm.py --kernel
 python3 tools/bench_spmm.py --kernel step --iters 10 2>&1 | grep "^step" > $out/step_c2.log
 python3 tools/bench_weighted.py > $out/weighted.log 2>&1
 [ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
+[ -x tools/ubench/stream_rw ] && ./tools/ubench/stream_rw 3.2 > $out/ubench_stream_rw.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
