@@ -318,7 +318,7 @@ def run_c2(a, env):
 
     # roofline of the dominant kernel: SURVEY.md 8(d): g*n*b + (4 z + 4 (m+1)) + m*n*b with b = 8
     alg_bytes = g * n * 8 + 4 * z + 4 * (m + 1) + m * n * 8
-    spmm_kernel = "spmm_colpair_f64" if g % 2 == 0 else "spmm_colgather_f64"
+    spmm_kernel = "spmm_colpair_f64"   # (any leading dimension: the 16-byte loads need no 16-byte alignment)
     # every padded membership slot of the plan returns 8 bytes per sample column from LDS
     lds_bytes = float(info["padded_slots"]) * 8.0 * n
     roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes), 2.0 * z * n)

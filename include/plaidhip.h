@@ -140,7 +140,7 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
  * is staged as u16 (four sample columns per 8-byte LDS entry) and summed in integers: exact, order-independent and
  * bit-identical to plaidhip_dev_spmm_dense_f64 on the same input, at a quarter of its LDS bytes per score.  A value
  * whose double is >= 32,768 sets flags[3] (the scores are then meaningless); shapes the kernel does not take
- * (nrow(X) <= 8,192 or > 20,448, odd ldx) run the general kernels.                                                  */
+ * (nrow(X) <= 8,192 or > 20,448) run the general kernels.                                                           */
 int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,
                                 int64_t ldr, int32_t n, int stat, double alpha, const void* alpha_div,
                                 double beta, void* S, int64_t lds, void* flags);

@@ -1879,8 +1879,9 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   //   u16: X holds what colranks returns (half-integers <= nrow): 2x as u16, four columns per LDS entry, integer sums;
   //   fp32: (half-)integers <= 20,448 of any sign are exact in fp32, and so are the four-term fp32 partial sums of the
   //   kernel (< 2^17 with one fractional bit).  The opt-in mixed precision takes the fp32 kernel for any X.
-  const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16 && (ldx & 1) == 0 &&
-                            (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (g_ablate == 0 || g_ablate == 4);
+  // (the 16-byte loads {x[2i], x[2i+1]} of these kernels need no 16-byte alignment: global memory takes dword-aligned
+  //  dwordx4 accesses, so an odd leading dimension -- every other column 8 bytes off -- runs the same kernels)
+  const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16 && (g_ablate == 0 || g_ablate == 4);
   if (x_kind == PLAIDHIP_X_RANKS && ctx->opt_ranks_f32 >= 2 && one_slice_16) {
     SpmmArgs a{};
     a.X = X;
@@ -1898,11 +1899,10 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     return launch_colpair_mixed(ctx, gs, a);
   }
   {
-    // two columns per pass when X allows 16-byte loads of both columns of a pair
+    // two columns per pass
     const int mode = pair_kernel_mode(ctx);
-    const bool aligned = (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6 || g_ablate == 7;
-    if (diag && mode != 0 && aligned && !gs->pair.slices.empty())
+    if (diag && mode != 0 && !gs->pair.slices.empty())
       return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags);
   }
   SpmmArgs a{};

@@ -208,7 +208,8 @@ def test_spmm_sparse_x_scatter_and_gather(pinned_ctx, mode, g, n, m, dens):
 
 @pytest.mark.parametrize("g,n", [(10001, 5), (20001, 3), (333, 2)])
 def test_spmm_pair_kernel_odd_genes_strided(g, n):
-    """device-level call with ldx = g + 1 (even) and odd g: the last gene of the last slice is staged separately"""
+    """device-level call with ldx = g + 1 (even) and odd g: the last gene of the last slice is staged separately;
+    then ldx = g (odd: every other column starts 8 bytes off a 16-byte boundary) through the same kernels"""
     import torch
     import plaid_amd
     from plaid_amd import synth as sy
@@ -235,6 +236,23 @@ def test_spmm_pair_kernel_odd_genes_strided(g, n):
     sizes = np.diff(Gp).astype(float)
     exp = np.stack([np.add.reduceat(X[Gi, j], Gp[:-1]) for j in range(n)]) / (1e-8 + sizes)
     close(S[:, :m], exp)
+    # odd leading dimension, and a base pointer that is only 8-byte aligned
+    buf = torch.zeros(n * g + 1, dtype=torch.float64, device=dev)
+    Xo = buf[1:].view(n, g)
+    Xo.copy_(torch.from_numpy(np.ascontiguousarray(X.T)).to(dev))
+    Sd.fill_(-7.0)
+    torch.cuda.synchronize()
+    ctx.dev_spmm_dense(gs, Xo.data_ptr(), g, n, Sd.data_ptr(), m + 3, "mean", 1.0, 0.0, fl.data_ptr())
+    ctx.synchronize()
+    S2 = Sd.cpu().numpy()
+    assert np.array_equal(S2, S)                               # same kernel, same order of additions: same bits
+    R = torch.empty((n, g), dtype=torch.float64, device=dev)
+    ctx.dev_colranks_dense(Xo.data_ptr(), g, g, n, R.data_ptr(), g, "average", False, 1.0, None)
+    Ss = torch.full((n, m), -7.0, dtype=torch.float64, device=dev)
+    ctx.dev_spmm_ranks(gs, R.data_ptr(), g, n, Ss.data_ptr(), m, "sum", 1.0, 0.0, fl.data_ptr())
+    ctx.synchronize()
+    Rh = R.cpu().numpy().T
+    close(Ss.cpu().numpy(), np.stack([np.add.reduceat(Rh[Gi, j], Gp[:-1]) for j in range(n)]))
     gs.close()
     ctx.close()
 
