@@ -200,6 +200,15 @@ int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const
                                         int32_t g, int32_t n, int ties, int is_signed, double power,
                                         void* R, int64_t ldr, void* colmax);
 
+/* The same dense ranks WITHOUT densifying the column: all zeros of a sparse column tie, so its dense ranks follow from the
+ * ranks among the stored values (the sparse_colranks kernel) and the counts of negative and zero entries -- O(nnz) work plus
+ * one dense write, for any nrow(X) (the densify-and-rank route leaves the fast rank kernel beyond 20,352 rows; a 10x
+ * Genomics matrix has 33,538 or 36,601).  max_col_nnz: the longest column's stored values (<= 20,352, else EUNSUPPORTED);
+ * Rx_scratch: Xp[n] doubles of device scratch.  Results are identical to plaidhip_dev_colranks_csc_dense_f64.          */
+int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx, int32_t g,
+                                           int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
+                                           void* Rx_scratch, void* R, int64_t ldr, void* colmax);
+
 /* normalize_medians() (R/plaid.R:554-575) in three phases so that a sample-sharded host
  * can all-reduce between them:
  *   1. flags  : plaidhip_dev_minflags   (or the SpMM epilogue's `flags`)  -> ignore.zero
@@ -252,6 +261,10 @@ int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int3
 /* replaid.sing body, R/plaid.R:215-217 (dense X; G aligned to X's rows as above)         */
 int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                         const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out);
+/* replaid.sing body for a dgCMatrix X (zeros are ranked: colranks' sparse branch without keep.zero, R/plaid.R:602-609):
+ * X goes to the device as its CSC slots; the reference (and R/plaid.R:215) densify it                                */
+int plaidhip_sing_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g, int32_t n,
+                      const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out);
 /* replaid.ssgsea body, R/plaid.R:245-253, dense X                                        */
 int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                           const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
@@ -278,6 +291,9 @@ int plaidhip_plaid_multi(const int* devices, int ndev, const int32_t* Xp, const 
                          int normalize, double* S_out);
 int plaidhip_sing_multi(const int* devices, int ndev, const double* X, int32_t g, int32_t n, const int32_t* Gp,
                         const int32_t* Gi, int32_t m, double* S_out);
+/* replaid.sing for a dgCMatrix X over several devices (see plaidhip_sing_csc) */
+int plaidhip_sing_csc_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g,
+                            int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out);
 int plaidhip_ssgsea_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                           int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
                           double* S_out);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "plaidhip_dev_colranks_dense_f64": [_vp, _vp, _i64, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
     "plaidhip_dev_colranks_csc_f64": [_vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _vp],
     "plaidhip_dev_colranks_csc_dense_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_colranks_csc_dense_nz_f64": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _int, _int, _f64, _vp, _vp, _i64, _vp],
     "plaidhip_dev_minflags": [_vp, _vp, _i64, _vp],
     "plaidhip_dev_col_medians": [_vp, _vp, _i64, _i32, _i32, _int, _vp, _vp],
     "plaidhip_dev_sum": [_vp, _vp, _i64, _vp],
@@ -75,12 +76,14 @@ SIGNATURES = {
     "plaidhip_colranks_dense": [_vp, _vp, _i32, _i32, _int, _int, _vp],
     "plaidhip_colranks_csc": [_vp, _vp, _vp, _i32, _int, _int, _vp],
     "plaidhip_colranks_csc_dense": [_vp, _vp, _vp, _vp, _i32, _i32, _int, _int, _vp],
+    "plaidhip_sing_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_sing_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_ssgsea_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_ssgsea_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_shard_bounds": [_i64, _int, _int, C.POINTER(_i64), C.POINTER(_i64)],
     "plaidhip_plaid_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
     "plaidhip_sing_multi": [_vp, _int, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
+    "plaidhip_sing_csc_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_ssgsea_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_multi_finalize": [],
     "plaidhip_multi_set_precision": [_int],

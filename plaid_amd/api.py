@@ -214,7 +214,11 @@ def replaid_sing(X, matG, ctx: Context | None = None):
         _message("[plaid] ERROR. No overlapping features.")
         return None
     ctx = ctx or default_context()
-    S = ctx.sing_dense(X.dense(), pat[0], pat[1])
+    if X.is_sparse:                                        # the CSC slots go to the device: no dense X on the host
+        V = X.values
+        S = ctx.sing_csc(V.indptr, V.indices, V.data, X.shape[0], pat[0], pat[1])
+    else:
+        S = ctx.sing_dense(X.values, pat[0], pat[1])
     return NamedMatrix(S, matG.colnames, X.colnames)
 
 

@@ -501,6 +501,26 @@ int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const
                                        static_cast<double*>(R), ldr, static_cast<double*>(colmax));
 }
 
+int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx, int32_t g,
+                                           int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
+                                           void* Rx_scratch, void* R, int64_t ldr, void* colmax) {
+  PH_CTX(ctx);
+  PH_TRY(check_ties(ties));
+  PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense_nz: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
+  PH_REQUIRE(n == 0 || g == 0 || (Xp && R), "colranks_csc_dense_nz: null Xp/R");
+  PH_REQUIRE(max_col_nnz >= 0 && max_col_nnz <= g, "colranks_csc_dense_nz: max_col_nnz=%d outside [0, nrow(X)=%d]", max_col_nnz, g);
+  if (max_col_nnz > max_sparse_rank_column()) {
+    set_error("colranks_csc_dense_nz: a column with %d stored values (at most %d are ranked in one pass: use "
+              "plaidhip_dev_colranks_csc_dense_f64)", max_col_nnz, max_sparse_rank_column());
+    return PLAIDHIP_EUNSUPPORTED;
+  }
+  PH_REQUIRE(max_col_nnz == 0 || Rx_scratch != nullptr, "colranks_csc_dense_nz: null Rx_scratch");
+  return launch_colranks_csc_dense_nz_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
+                                          static_cast<const double*>(Xx), g, n, max_col_nnz, ties, is_signed, power,
+                                          static_cast<double*>(Rx_scratch), static_cast<double*>(R), ldr,
+                                          static_cast<double*>(colmax));
+}
+
 int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags) {
   PH_CTX(ctx);
   PH_REQUIRE(flags != nullptr && count >= 0, "minflags: bad arguments");
@@ -697,6 +717,18 @@ int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int3
   PH_TRY(h2d(ctx, dXp.p, Xp, (size_t)(n + 1) * 4));
   PH_TRY(h2d(ctx, dXi.p, Xi, (size_t)zx * 4));
   PH_TRY(h2d(ctx, dXx.p, Xx, (size_t)zx * 8));
+  // zeros tie: the dense ranks follow from the ranks of the stored values (kernels_rank.hip) unless a column stores
+  // more values than the rank kernel takes in one pass -- then the column is densified and ranked as a dense one
+  const int32_t max_nnz = host_max_col_nnz(Xp, n);
+  if (max_nnz <= max_sparse_rank_column()) {
+    DevBuf dRx;
+    PH_TRY(dRx.alloc((size_t)(zx > 0 ? zx : 1) * 8));
+    PH_TRY(launch_colranks_csc_dense_nz_f64(ctx, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), g, n, max_nnz, ties,
+                                            is_signed, 1.0, dRx.as<double>(), dR.as<double>(), g, nullptr));
+    PH_HIP(hipMemcpyAsync(R_out, dR.p, (size_t)g * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));   // (dRx is released behind this)
+    return PLAIDHIP_OK;
+  }
   PH_TRY(launch_colranks_csc_dense_f64(ctx, dXp.as<int32_t>(), dXi.as<int32_t>(), dXx.as<double>(), g, n, ties,
                                        is_signed, 1.0, dR.as<double>(), g, nullptr));
   PH_HIP(hipMemcpyAsync(R_out, dR.p, (size_t)g * n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -709,6 +741,18 @@ int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   PH_CTX(ctx);
   // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
   return run_sharded(&ctx, 1, 1, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
+}
+
+// replaid.sing for a dgCMatrix X: colranks(X, ties.method = "min") ranks the zeros too (sparse branch without keep.zero,
+// R/plaid.R:602-609), / nrow(X) - 0.5, plaid(normalize = FALSE) (:215-217).  The reference densifies X to rank it; here
+// the CSC slots go to the device as they are, the dense min-ranks are built per panel of columns from the ranks of the
+// stored values (zeros tie), and the rank crossprod runs on each panel (multi.cpp: shard_worker): neither the host nor
+// the PCIe link sees a dense X.
+int plaidhip_sing_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g, int32_t n,
+                      const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+  PH_CTX(ctx);
+  PH_REQUIRE(Xp != nullptr, "sing_csc: null Xp");
+  return run_sharded(&ctx, 1, 1, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
 }
 
 int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
@@ -736,7 +780,7 @@ namespace {
 
 // uploads X (dense when Xp == nullptr, else CSC) and produces the dense average ranks on the device
 struct RankedInput {
-  DevBuf dX, dXp, dXi, dR, dsmall;
+  DevBuf dX, dXp, dXi, dR, dRx, dsmall;
   double* R = nullptr;
   double* d_colmax = nullptr;
   double* d_gmax = nullptr;     // device scalar max(rX)
@@ -763,8 +807,16 @@ int dense_average_ranks(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi,
     PH_TRY(h2d(ctx, ri.dXp.p, Xp, (size_t)(n + 1) * 4));
     PH_TRY(h2d(ctx, ri.dXi.p, Xi, (size_t)zx * 4));
     PH_TRY(h2d(ctx, ri.dX.p, X_or_x, (size_t)zx * 8));
-    PH_TRY(launch_colranks_csc_dense_f64(ctx, ri.dXp.as<int32_t>(), ri.dXi.as<int32_t>(), ri.dX.as<double>(), g, n,
-                                         PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.R, g, ri.d_colmax));
+    // zeros tie: dense ranks from the ranks of the stored values (any nrow(X)) unless a column stores too many
+    const int32_t max_nnz = host_max_col_nnz(Xp, n);
+    if (max_nnz <= max_sparse_rank_column()) {
+      PH_TRY(ri.dRx.alloc((size_t)(zx > 0 ? zx : 1) * 8));
+      PH_TRY(launch_colranks_csc_dense_nz_f64(ctx, ri.dXp.as<int32_t>(), ri.dXi.as<int32_t>(), ri.dX.as<double>(), g, n, max_nnz,
+                                              PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.dRx.as<double>(), ri.R, g, ri.d_colmax));
+    } else {
+      PH_TRY(launch_colranks_csc_dense_f64(ctx, ri.dXp.as<int32_t>(), ri.dXi.as<int32_t>(), ri.dX.as<double>(), g, n,
+                                           PLAIDHIP_TIES_AVERAGE, 0, 1.0, ri.R, g, ri.d_colmax));
+    }
   }
   PH_TRY(launch_max(ctx, ri.d_colmax, n, ri.d_gmax));
   return PLAIDHIP_OK;

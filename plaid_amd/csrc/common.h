@@ -261,6 +261,12 @@ int32_t host_max_col_nnz(const int32_t* Xp, int32_t n);   // longest column of a
 int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                                   int32_t g, int32_t n, int ties, int is_signed, double power, double* R,
                                   int64_t ldr, double* colmax);
+// dense ranks of CSC columns from the ranks of their stored values (zeros tie): any number of rows, every column at most
+// max_sparse_rank_column() stored values; Rx_scratch: Xp[n] doubles
+int launch_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g,
+                                     int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
+                                     double* Rx_scratch, double* R, int64_t ldr, double* colmax);
+int max_sparse_rank_column();
 // kernels_norm.hip
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags);
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,

@@ -440,6 +440,100 @@ int launch_colranks_csc_dense_f64(plaidhip_ctx* ctx, const int32_t* Xp, const in
   return launch_ranks(ctx, Xx, 0, g, Xp, n, g, ties, is_signed, power, R, ldr, colmax, Xi);
 }
 
+// ---- dense ranks of a sparse column WITHOUT densifying it --------------------------------------------------------------
+// colranks(X sparse, keep.zero = FALSE) (R/plaid.R:602-609) ranks the zeros too and returns a dense matrix.  All implicit
+// zeros tie, so the dense ranks follow from the ranks among the STORED values (nnz per column, the fast CSC path) and
+// three counts: with z implicit zeros, e0 stored zeros and `neg` stored negatives,
+//     stored v > 0 : rank_nz + z      stored v < 0 : rank_nz      stored v == 0 : rank_nz + z * {min 0, average 1/2, max 1}
+//     implicit zero: lb = neg, ub = neg + e0 + z  ->  lb + 1 | (lb + 1 + ub) / 2 | ub
+// (signed: rank(|x|) puts every stored non-zero above the z zeros, the zeros themselves give sign(0) * rank = 0).
+// The kernel writes the zero rank over the whole column and then the stored entries' ranks over their rows: O(nnz) work
+// and one dense write, for ANY number of rows -- densify-and-rank is a 20,000-key sort per column and leaves the fast
+// rank kernel beyond 20,352 rows (a 10x Genomics matrix has 33,538 or 36,601).
+__global__ void __launch_bounds__(256)
+expand_sparse_ranks_kernel(const int32_t* __restrict__ Xp, const int32_t* __restrict__ Xi, const double* __restrict__ Xx,
+                           const double* __restrict__ Rx, int32_t g, int32_t n, int ties, int is_signed, double power,
+                           int pow_q4, double* __restrict__ R, int64_t ldr, double* __restrict__ colmax) {
+  // the power as the bucket kernel applies it: by square roots when 4 * power is a small integer, pow() otherwise
+  auto powr = [&](double r) { return pow_q4 > 0 ? pow_quarters(r, pow_q4) : PH_POW(r, power); };
+  __shared__ uint32_t s_cnt[2];
+  __shared__ double s_max[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const int q0 = Xp[c], q1 = Xp[c + 1];
+    const double z = (double)(g - (q1 - q0));
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t neg = 0, e0 = 0;
+    for (int q = q0 + tid; q < q1; q += 256) {
+      const double v = Xx[q];
+      neg += (v < 0.0) ? 1u : 0u;
+      e0 += (v == 0.0) ? 1u : 0u;
+    }
+    neg = wave_incl_scan_u32(neg);
+    e0 = wave_incl_scan_u32(e0);
+    if (lane == 63) { atomicAdd(&s_cnt[0], neg); atomicAdd(&s_cnt[1], e0); }
+    __syncthreads();
+    const double lb0 = (double)s_cnt[0], ub0 = lb0 + (double)s_cnt[1] + z;
+    double r0 = (ties == PLAIDHIP_TIES_MIN) ? lb0 + 1.0 : ((ties == PLAIDHIP_TIES_MAX) ? ub0 : 0.5 * (lb0 + 1.0 + ub0));
+    if (is_signed) r0 = 0.0;
+    else if (power != 1.0) r0 = powr(r0);
+    const double t0 = (ties == PLAIDHIP_TIES_MIN) ? 0.0 : ((ties == PLAIDHIP_TIES_MAX) ? 1.0 : 0.5);
+    double* rc = R + (int64_t)c * ldr;
+    for (int i = tid; i < g; i += 256) __builtin_nontemporal_store(r0, rc + i);
+    __syncthreads();   // the column is filled (this workgroup's stores are performed) before single rows are overwritten
+    double vmax = (z > 0.0 && !is_signed) ? r0 : ((z > 0.0) ? 0.0 : -INFINITY);
+    for (int q = q0 + tid; q < q1; q += 256) {
+      const double v = Xx[q], rn = Rx[q];
+      double r;
+      if (is_signed) {
+        const double mag = fabs(rn) + z;                    // rank of |v| > 0 among all rows
+        double pm = (power != 1.0) ? powr(mag) : mag;
+        r = (v == 0.0) ? 0.0 : ((v < 0.0) ? -pm : pm);
+        if (v != v) { r = nan; pm = -INFINITY; }
+        if (v == 0.0) pm = 0.0;
+        vmax = pm > vmax ? pm : vmax;
+      } else {
+        r = rn + z * ((v > 0.0) ? 1.0 : ((v == 0.0) ? t0 : 0.0));
+        if (power != 1.0) r = powr(r);
+        if (v != v) r = nan;
+        vmax = (r > vmax) ? r : vmax;                       // (false for a NaN)
+      }
+      rc[Xi[q]] = r;
+    }
+    if (colmax != nullptr) {
+      vmax = wave_max_f64_dpp(vmax);
+      if (lane == 63) s_max[wave] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        double v = s_max[0];
+        for (int w = 1; w < 4; ++w) v = s_max[w] > v ? s_max[w] : v;
+        colmax[c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dense ranks from CSC through the ranks of the stored values (Rx_scratch: Xp[n] doubles); every column must have at most
+// kMaxBucketKeys stored values (the caller states the longest, as for launch_colranks_csc_f64)
+int launch_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g,
+                                     int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
+                                     double* Rx_scratch, double* R, int64_t ldr, double* colmax) {
+  if (n == 0 || g == 0) return PLAIDHIP_OK;
+  const int rc = launch_ranks(ctx, Xx, 0, 0, Xp, n, max_col_nnz, ties, is_signed, 1.0, Rx_scratch, 0, nullptr);
+  if (rc != PLAIDHIP_OK) return rc;
+  const int cap = ctx->num_cu * 8;
+  const double q4 = power * 4.0;
+  const int pow_q4 = (power != 1.0 && q4 >= 1.0 && q4 <= 16.0 && q4 == (double)(int)q4) ? (int)q4 : 0;
+  hipLaunchKernelGGL(expand_sparse_ranks_kernel, dim3(n < cap ? n : cap), dim3(256), 0, ctx->stream, Xp, Xi, Xx, Rx_scratch,
+                     g, n, ties, is_signed, power, pow_q4, R, ldr, colmax);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+int max_sparse_rank_column() { return kMaxBucketKeys; }
+
 // stream-ordered: the caller states the longest column (include/plaidhip.h), nothing is read back
 int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n, int32_t max_col_nnz,
                             int ties, int is_signed, double power, double* Rx, double* colmax) {

@@ -312,11 +312,32 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       PH_TRY(dXp.alloc((size_t)(nloc + 1) * 4));
       PH_TRY(dXi.alloc((size_t)zx * 4));
       PH_TRY(dX.alloc((size_t)zx * 8));
-      if (ranks) PH_TRY(dR.alloc((size_t)zx * 8));
+      // replaid.sing ranks the zeros too (colranks' sparse branch without keep.zero, R/plaid.R:602-609: a dense rank
+      // matrix): built panel by panel from the ranks of the stored values, each panel multiplied at once
+      int64_t panel = ((int64_t)2 << 30) / (ldg * 8);
+      panel = std::min<int64_t>(std::max<int64_t>(panel & ~(int64_t)1, 2), nloc);
+      if (c.method == 1) PH_TRY(dR.alloc((size_t)(panel * ldg + zx) * 8));   // a panel of dense ranks | ranks of the stored values
+      else if (ranks) PH_TRY(dR.alloc((size_t)zx * 8));
       PH_HIP(hipMemcpyAsync(dXp.p, ploc.data(), (size_t)(nloc + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
       PH_TRY(upload_pipelined(ctx, dXi.as<char>(), 1, reinterpret_cast<const char*>(c.Xi + z0), 1, zx * 4, nullptr));
       PH_TRY(upload_pipelined(ctx, dX.as<char>(), 1, reinterpret_cast<const char*>(c.X + z0), 1, zx * 8, nullptr));
-      if (ranks)   // sparse_colranks: the stored values among themselves (R/plaid.R:600-601, 631-650)
+      if (c.method == 1) {
+        double* dRd = dR.as<double>();
+        double* dRx = dRd + panel * ldg;
+        const bool by_stored = max_nnz <= max_sparse_rank_column();
+        for (int64_t c0 = 0; c0 < nloc; c0 += panel) {
+          const int32_t nc = (int32_t)std::min<int64_t>(panel, nloc - c0);
+          const int32_t* xp = dXp.as<int32_t>() + c0;          // (absolute offsets into the shard's @i / @x)
+          if (by_stored)
+            PH_TRY(launch_colranks_csc_dense_nz_f64(ctx, xp, dXi.as<int32_t>(), dX.as<double>(), g, nc, max_nnz,
+                                                    PLAIDHIP_TIES_MIN, 0, 1.0, dRx, dRd, ldg, nullptr));
+          else   // a column with more stored values than one pass ranks: densify and rank
+            PH_TRY(launch_colranks_csc_dense_f64(ctx, xp, dXi.as<int32_t>(), dX.as<double>(), g, nc, PLAIDHIP_TIES_MIN, 0, 1.0,
+                                                 dRd, ldg, nullptr));
+          PH_TRY(launch_spmm_dense_f64(ctx, gs, dRd, ldg, nc, PLAIDHIP_STAT_MEAN, 1.0 / (double)g, nullptr, -0.5,   // R/plaid.R:216
+                                       dS.as<double>() + c0 * m, m, d_flags, PLAIDHIP_X_RANKS));
+        }
+      } else if (ranks)   // sparse_colranks: the stored values among themselves (R/plaid.R:600-601, 631-650)
         PH_TRY(launch_colranks_csc_f64(ctx, dXp.as<int32_t>(), dX.as<double>(), nloc, max_nnz,
                                        c.method == 1 ? PLAIDHIP_TIES_MIN : PLAIDHIP_TIES_AVERAGE, 0,
                                        c.method == 2 ? 1.0 + c.alpha : 1.0, dR.as<double>(), c.method == 2 ? d_colmax : nullptr));
@@ -351,6 +372,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     if (ctx->debug_fail_crossprod) { set_error("injected failure in the crossprod phase (test hook)"); return PLAIDHIP_EHIP; }
     if (nloc == 0) return PLAIDHIP_OK;
     if (c.method == 0 && !sparse) return PLAIDHIP_OK;
+    if (c.method == 1 && sparse) return PLAIDHIP_OK;   // done panel by panel above
     double a = 1.0, b = 0.0;
     int stat = c.stat;
     if (c.method == 1) { a = 1.0 / (double)g; b = -0.5; stat = PLAIDHIP_STAT_MEAN; }       // R/plaid.R:216
@@ -544,6 +566,14 @@ int plaidhip_sing_multi(const int* devices, int ndev, const double* X, int32_t g
   std::vector<plaidhip_ctx*> ctxs;
   PH_TRY(multi_contexts(devices, ndev, ctxs));
   return run_sharded(ctxs.data(), ndev, 1, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
+}
+
+int plaidhip_sing_csc_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g,
+                            int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+  PH_REQUIRE(Xp != nullptr, "sing_csc_multi: null Xp");
+  std::vector<plaidhip_ctx*> ctxs;
+  PH_TRY(multi_contexts(devices, ndev, ctxs));
+  return run_sharded(ctxs.data(), ndev, 1, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
 }
 
 int plaidhip_ssgsea_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x, int32_t g,

@@ -164,6 +164,13 @@ class Context:
         check(self.lib.plaidhip_dev_colranks_csc_f64(self.handle, Xp, Xx, n, int(max_col_nnz), TIES[ties], int(signed),
                                                      power, Rx, colmax))
 
+    def dev_colranks_csc_dense_nz(self, Xp: int, Xi: int, Xx: int, g: int, n: int, max_col_nnz: int, Rx_scratch: int, R: int,
+                                  ldr: int, ties="average", signed=False, power=1.0, colmax: int | None = None):
+        """dense ranks of CSC columns (zeros ranked) from the ranks of the stored values: any nrow(X); Rx_scratch: Xp[n]
+        doubles; every column at most 20,352 stored values"""
+        check(self.lib.plaidhip_dev_colranks_csc_dense_nz_f64(self.handle, Xp, Xi, Xx, int(g), int(n), int(max_col_nnz),
+                                                              TIES[ties], int(signed), power, Rx_scratch, R, int(ldr), colmax))
+
     def dev_minflags(self, S: int, count: int, flags: int):
         check(self.lib.plaidhip_dev_minflags(self.handle, S, count, flags))
 
@@ -226,6 +233,18 @@ class Context:
         S = np.empty((m, n), dtype=np.float64, order="F")
         check(self.lib.plaidhip_crossprod_weighted_csc(self.handle, _np_ptr(Wp), _np_ptr(Wi), _np_ptr(Wx), int(g), m,
                                                        _np_ptr(Yp), _np_ptr(Yi), _np_ptr(Yx), n, _np_ptr(S)))
+        return S
+
+    def sing_csc(self, Xp, Xi, Xx, g: int, Gp, Gi) -> np.ndarray:
+        """replaid.sing for a dgCMatrix X (zeros are ranked, R/plaid.R:215-217 with colranks' sparse branch :602-609)"""
+        Xp, Xi = _as_i32(Xp), _as_i32(Xi)
+        Xx = np.ascontiguousarray(Xx, dtype=np.float64)
+        n = len(Xp) - 1
+        Gp, Gi = _as_i32(Gp), _as_i32(Gi)
+        m = len(Gp) - 1
+        S = np.empty((m, n), dtype=np.float64, order="F")
+        check(self.lib.plaidhip_sing_csc(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n, _np_ptr(Gp),
+                                         _np_ptr(Gi), m, _np_ptr(S)))
         return S
 
     def normalize_medians(self, S, ignore_zero=None):

@@ -173,10 +173,18 @@ replaid.sing <- function(X, matG) {
   pat <- .aligned_pattern(X, matG)
   if (is.null(pat)) { message("[plaid] ERROR. No overlapping features."); return(NULL) }
   .session()
-  D <- as.matrix(X); storage.mode(D) <- "double"
   dev <- .devices()
-  S <- if (length(dev) > 1L) .Call("R_plaidhip_sing_multi", dev, D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
-       else .Call("R_plaidhip_sing_dense", D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+  if (inherits(X, "CsparseMatrix")) {
+    ## the reference densifies a sparse X to rank its zeros (R/plaid.R:602-609); here the slots go to the device(s)
+    X <- methods::as(X, "generalMatrix")
+    S <- if (length(dev) > 1L) .Call("R_plaidhip_sing_csc_multi", dev, X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi,
+                                     PACKAGE = "plaidhip")
+         else .Call("R_plaidhip_sing_csc", X@p, X@i, as.double(X@x), nrow(X), pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+  } else {
+    D <- as.matrix(X); storage.mode(D) <- "double"
+    S <- if (length(dev) > 1L) .Call("R_plaidhip_sing_multi", dev, D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+         else .Call("R_plaidhip_sing_dense", D, pat$Gp, pat$Gi, PACKAGE = "plaidhip")
+  }
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }

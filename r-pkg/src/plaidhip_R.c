@@ -81,6 +81,16 @@ SEXP R_plaidhip_crossprod_weighted_csc(SEXP Wp, SEXP Wi, SEXP Wx, SEXP Yp, SEXP 
   return S;
 }
 
+/* replaid.sing for a dgCMatrix: slots @p, @i, @x and nrow (no as.matrix(X) on the host) */
+SEXP R_plaidhip_sing_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi) {
+  const int n = LENGTH(Xp) - 1, m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_sing_csc(ctx(), INTEGER(Xp), INTEGER(Xi), REAL(Xx), Rf_asInteger(g), n, INTEGER(Gp), INTEGER(Gi), m,
+                          REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
 /* normalize_medians(x, ignore.zero): ignore_zero = NA (NULL in R) / FALSE / TRUE */
 SEXP R_plaidhip_normalize_medians(SEXP x, SEXP ignore_zero) {
   const int m = Rf_nrows(x), n = Rf_ncols(x);
@@ -154,6 +164,15 @@ SEXP R_plaidhip_plaid_multi(SEXP devices, SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEX
   SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
   check(plaidhip_plaid_multi(INTEGER(devices), LENGTH(devices), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g),
                              nn, INTEGER(Gp), INTEGER(Gi), m, Rf_asInteger(stat), Rf_asLogical(normalize), REAL(S)));
+  UNPROTECT(1);
+  return S;
+}
+
+SEXP R_plaidhip_sing_csc_multi(SEXP devices, SEXP Xp, SEXP Xi, SEXP Xx, SEXP g, SEXP Gp, SEXP Gi) {
+  const int n = LENGTH(Xp) - 1, m = LENGTH(Gp) - 1;
+  SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, n));
+  check(plaidhip_sing_csc_multi(INTEGER(devices), LENGTH(devices), INTEGER(Xp), INTEGER(Xi), REAL(Xx), Rf_asInteger(g), n,
+                                INTEGER(Gp), INTEGER(Gi), m, REAL(S)));
   UNPROTECT(1);
   return S;
 }
@@ -291,6 +310,8 @@ static const R_CallMethodDef call_methods[] = {
     {"R_plaidhip_plaid_csc", (DL_FUNC)&R_plaidhip_plaid_csc, 8},
     {"R_plaidhip_crossprod_weighted_dense", (DL_FUNC)&R_plaidhip_crossprod_weighted_dense, 4},
     {"R_plaidhip_crossprod_weighted_csc", (DL_FUNC)&R_plaidhip_crossprod_weighted_csc, 7},
+    {"R_plaidhip_sing_csc", (DL_FUNC)&R_plaidhip_sing_csc, 6},
+    {"R_plaidhip_sing_csc_multi", (DL_FUNC)&R_plaidhip_sing_csc_multi, 7},
     {"R_plaidhip_normalize_medians", (DL_FUNC)&R_plaidhip_normalize_medians, 2},
     {"R_plaidhip_colranks_dense", (DL_FUNC)&R_plaidhip_colranks_dense, 3},
     {"R_plaidhip_colranks_csc", (DL_FUNC)&R_plaidhip_colranks_csc, 4},

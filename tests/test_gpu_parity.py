@@ -1043,6 +1043,8 @@ def test_multi_device_engine_with_several_shards_on_one_gpu(hip_ctx, nshards):
         rc, S = run(2, None, Gp, Gi, alpha=0.25, Xcsc=Xs)
         assert rc == 0
         close(S, _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
+        rc, S = run(1, None, Gp, Gi, Xcsc=Xs)                          # replaid.sing on CSC: zeros ranked, integer sums
+        assert rc == 0 and np.array_equal(S, hip_ctx.sing_dense(Xs.toarray(), Gp, Gi))
     # a failing shard: every worker still reaches every rendezvous, the call reports the failure
     X = sy.dense_columns(g, 0, 37)
     for fail in (0, nshards - 1):

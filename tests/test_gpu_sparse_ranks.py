@@ -1,0 +1,117 @@
+"""Dense ranks of sparse columns WITHOUT densifying them (colranks(X sparse, keep.zero = FALSE), R/plaid.R:602-609: zeros
+are ranked, dense result) and replaid.sing on a dgCMatrix (R/plaid.R:213-219).  All zeros of a column tie, so its dense
+ranks follow from the ranks of the stored values; the oracle ranks the densified matrix.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-9
+
+
+def _sparse_matrix(rng, g, n, dens):
+    X = np.round(rng.normal(0.5, 2.0, size=(g, n)), 1)          # negatives, heavy ties
+    X[rng.random(X.shape) >= dens] = 0.0
+    if n > 3:
+        X[:, 1] = 0.0                                            # an empty column
+        X[:, 2] = np.abs(X[:, 2])                                # no negatives
+        X[: g // 3, 3] = -1.5                                    # many tied negatives
+    Xs = sp.csc_matrix(X)
+    if Xs.nnz > 10:
+        Xs.data[::23] = 0.0                                      # stored zeros stay stored
+    return Xs
+
+
+@pytest.mark.parametrize("g,n,dens", [(300, 9, 0.2), (7728, 7, 0.1), (20352, 5, 0.05), (25000, 6, 0.08), (36601, 5, 0.06),
+                                      (70000, 3, 0.03), (50, 4, 1.0)])
+def test_colranks_csc_dense_any_number_of_rows(hip_ctx, g, n, dens):
+    """the host entry picks the stored-values route (every column here stores <= 20,352 values): ranks must equal the dense
+    ranks of the densified matrix bit for bit, for every ties method, signed or not, beyond the 20,352-row limit of the
+    rank kernel too"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(g + n)
+    Xs = _sparse_matrix(rng, g, n, dens)
+    X = Xs.toarray()
+    for tm in ("average", "min", "max"):
+        for signed in (False, True):
+            got = hip_ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, tm, signed)
+            assert np.array_equal(got, c_oracle.colranks_dense(X, tm, signed)), (tm, signed)
+
+
+def test_colranks_csc_dense_nz_device_entry_power_colmax_and_nan(hip_ctx):
+    """device-level entry: ldr > g, fused power (by square roots and by pow), column maxima, NaN among the stored values,
+    and the refusal of a column with more stored values than one pass ranks"""
+    import torch
+    import plaid_amd
+    from oracle import c_oracle
+    rng = np.random.default_rng(8)
+    g, n, ldr = 27001, 6, 27004
+    Xs = _sparse_matrix(rng, g, n, 0.07)
+    X = Xs.toarray()
+    dev = torch.device("cuda", 0)
+    Xp = torch.from_numpy(Xs.indptr.astype(np.int32)).to(dev)
+    Xi = torch.from_numpy(Xs.indices.astype(np.int32)).to(dev)
+    Xx = torch.from_numpy(Xs.data.astype(np.float64)).to(dev)
+    Rx = torch.empty(Xs.nnz, dtype=torch.float64, device=dev)
+    max_nnz = int(np.diff(Xs.indptr).max())
+    for power in (1.0, 1.25, 1.3):
+        for tm in ("average", "min"):
+            R = torch.full((n, ldr), -7.0, dtype=torch.float64, device=dev)
+            cm = torch.empty(n, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            hip_ctx.dev_colranks_csc_dense_nz(Xp.data_ptr(), Xi.data_ptr(), Xx.data_ptr(), g, n, max_nnz, Rx.data_ptr(),
+                                              R.data_ptr(), ldr, tm, False, power, cm.data_ptr())
+            hip_ctx.synchronize()
+            Rh = R.cpu().numpy()
+            assert np.all(Rh[:, g:] == -7.0)
+            with np.errstate(invalid="ignore"):
+                exp = c_oracle.colranks_dense(X, tm, False) ** power
+            np.testing.assert_allclose(Rh[:, :g].T, exp, rtol=1e-13, atol=0)
+            np.testing.assert_allclose(cm.cpu().numpy(), np.nanmax(exp, axis=0), rtol=1e-13)
+    # NaN among the stored values: set aside (NaN rank), the others ranked among themselves -- as the dense kernel does
+    # (pinned by test_colranks_nan_and_negzero); the plain-C oracle takes NaN-free vectors only
+    Xs.data[5] = np.nan
+    Xs.data[Xs.indptr[4] + 1] = np.nan
+    for tm in ("average", "min", "max"):
+        for signed in (False, True):
+            got = hip_ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, tm, signed)
+            assert np.array_equal(got, hip_ctx.colranks_dense(Xs.toarray(), tm, signed), equal_nan=True), (tm, signed)
+    assert np.isnan(got).sum() == 2
+    with pytest.raises(plaid_amd.PlaidHipError):
+        hip_ctx.dev_colranks_csc_dense_nz(Xp.data_ptr(), Xi.data_ptr(), Xx.data_ptr(), g, n, 20353, Rx.data_ptr(), R.data_ptr(),
+                                          ldr, "min", False, 1.0, None)
+
+
+def test_colranks_csc_dense_long_columns_still_take_the_densify_route(hip_ctx):
+    """a column with more than 20,352 stored values: the host entry densifies and ranks it as before"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(3)
+    g, n = 24000, 3
+    X = np.round(rng.normal(size=(g, n)), 2)
+    X[rng.random(X.shape) < 0.05] = 0.0
+    Xs = sp.csc_matrix(X)
+    assert np.diff(Xs.indptr).max() > 20352
+    assert np.array_equal(hip_ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, "min", False),
+                          c_oracle.colranks_dense(X, "min", False))
+
+
+@pytest.mark.parametrize("g,n,m", [(900, 17, 31), (33538, 40, 120), (20000, 300, 60)])
+def test_replaid_sing_on_a_sparse_matrix(hip_ctx, g, n, m):
+    """replaid.sing with a dgCMatrix X through the R-like API: the CSC slots go to the device (plaidhip_sing_csc); scores
+    equal those of the dense route and of the oracle (which densifies, as the reference does)"""
+    import plaid_amd
+    from oracle import plaid_oracle as po
+    rng = np.random.default_rng(g)
+    X = np.round(rng.gamma(2.0, 1.5, size=(g, n)), 1)
+    X[rng.random(X.shape) < 0.92] = 0.0
+    rn = [f"g{k}" for k in range(g)]
+    Gd = sp.random(g, m, density=min(0.5, 60.0 / g), format="csc", random_state=np.random.RandomState(5))
+    Gd.data[:] = 1.0
+    Xn = plaid_amd.NamedMatrix(sp.csc_matrix(X), rn, [f"s{k}" for k in range(n)])
+    Xd = plaid_amd.NamedMatrix(X, rn, Xn.colnames)
+    Gn = plaid_amd.NamedMatrix(Gd, rn, [f"set{k}" for k in range(m)])
+    got = plaid_amd.replaid_sing(Xn, Gn)
+    assert got.rownames == Gn.colnames and got.colnames == Xn.colnames
+    np.testing.assert_allclose(got.values, po.replaid_sing(X, rn, Gd, rn), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got.values, plaid_amd.replaid_sing(Xd, Gn).values, rtol=1e-12, atol=1e-13)
