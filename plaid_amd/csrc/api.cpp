@@ -324,6 +324,7 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   for (plaidhip_ctx::cached_geneset& e : ctx->gs_cache) plaidhip_geneset_destroy(e.gs);
   ctx->gs_cache.clear();
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->rank_scratch) hipFree(ctx->rank_scratch);
   for (int k = 0; k < plaidhip_ctx::kHostBufs; ++k)
     if (ctx->hbuf[k]) hipFree(ctx->hbuf[k]);
   for (int t = 0; t < plaidhip_ctx::kFeeders; ++t) {

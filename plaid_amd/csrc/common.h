@@ -68,6 +68,8 @@ struct plaidhip_ctx {
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
   int opt_scatter_fixed = 1;   // scatter kernel: u64 fixed-point accumulators for inputs declared bounded (rank weights)
   int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
+  void* rank_scratch = nullptr;   // value-partitioned ranking of columns beyond the LDS (kernels_rank.hip), grown on demand
+  size_t rank_scratch_bytes = 0;
   int debug_fail_crossprod = 0;   // test hook (plaidhip_debug_sharded_on_one_device): this context's shard fails in the crossprod phase
   // pinned staging of the pipelined host uploads (multi.cpp): kFeeders feeder threads x 2 buffers, their streams
   static constexpr int kFeeders = 4;

@@ -428,9 +428,320 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
                         dscratch, fb_grid, ws_off, fb_list, fb_count);
 }
 
+// ---- dense columns beyond the LDS: rank by value partition --------------------------------------------------------------
+// The bucket ranker takes columns of at most kMaxBucketKeys (20,352) keys -- what fits the CU's LDS; longer columns fell to
+// the sorting network on a global scratch (2.4-3.4e9 keys/s against 7.6e10).  A longer column is cut BY VALUE instead:
+// K - 1 splitters (quantiles of a 1,024-key sample, duplicates dropped) define up to K open intervals and as many
+// single-value classes {t_i}; the keys of an open interval go to a scratch segment together with their row numbers,
+// every segment is ranked by the bucket ranker like a CSC column (launch_ranks), and the rank inside the segment plus
+// the number of keys in the classes below is the rank in the column -- exactly, for every ties method.  A key equal to a
+// splitter needs no ranking at all (lb = #keys below, ub = lb + #equal): a value that makes up a large part of the column
+// (the zeros of a dense single-cell matrix) is almost surely a sample quantile and costs two counters.  An open interval
+// that still holds more than kMaxBucketKeys keys sends the column to the network kernel (device-side list).
+constexpr int kPartMax = 16;                  // open intervals per column at most
+constexpr int kPartTarget = 12288;            // keys per open interval aimed at (slack for the sample's error)
+struct PartMeta {
+  uint64_t t[kPartMax];                       // distinct splitter keys, ascending
+  int32_t less[kPartMax], eq[kPartMax];       // #keys < t_j, #keys == t_j
+  int32_t open[kPartMax + 1];                 // sizes of the open intervals (-inf, t_0), (t_0, t_1), ..., (t_{p-1}, +inf)
+  int32_t p, fallback;
+  double smax;                                // largest value written for the single-value classes
+};
+
+__device__ __forceinline__ uint64_t part_key(double x, int is_signed) { return f64_to_key(is_signed ? fabs(x) : x); }
+
+__global__ void __launch_bounds__(1024)
+rank_part_count_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, int32_t n, int is_signed, int K,
+                       PartMeta* __restrict__ meta, int32_t* __restrict__ col_open, int32_t* __restrict__ fb_count,
+                       int32_t* __restrict__ fb_list, int32_t col0) {
+  __shared__ uint64_t skeys[1024];
+  __shared__ uint64_t s_t[kPartMax];
+  __shared__ uint32_t s_less[kPartMax], s_eq[kPartMax], s_nan;
+  __shared__ int s_p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const double* xc = X + (int64_t)c * ldx;
+    skeys[tid] = part_key(xc[((int64_t)tid * g) >> 10], is_signed);
+    if (tid < kPartMax) { s_less[tid] = 0; s_eq[tid] = 0; }
+    if (tid == 0) s_nan = 0;
+    bitonic_sort_lds(skeys, 1024);            // starts and ends with a barrier; NaN keys (all ones) sort last
+    if (tid == 0) {
+      int ns = 0;
+      for (int b = 512; b >= 1; b >>= 1) ns += (skeys[ns + b - 1] != ~0ull) ? b : 0;   // number of non-NaN sample keys
+      if (ns < 1024 && skeys[ns] != ~0ull) ++ns;
+      int p = 0;
+      for (int i = 1; i < K && ns > 0; ++i) {
+        const uint64_t q = skeys[((int64_t)i * ns) / K];
+        if (p == 0 || q != s_t[p - 1]) s_t[p++] = q;
+      }
+      s_p = p;
+    }
+    __syncthreads();
+    const int p = s_p;
+    uint32_t less[kPartMax], eq[kPartMax], nnan = 0;
+#pragma unroll
+    for (int j = 0; j < kPartMax; ++j) { less[j] = 0; eq[j] = 0; }
+    for (int i = tid; i < g; i += 1024) {
+      const uint64_t k = part_key(xc[i], is_signed);
+      nnan += (k == ~0ull) ? 1u : 0u;
+#pragma unroll
+      for (int j = 0; j < kPartMax; ++j)
+        if (j < p) {
+          const uint64_t t = s_t[j];
+          less[j] += (k < t) ? 1u : 0u;
+          eq[j] += (k == t) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPartMax; ++j)
+      if (j < p) {
+        const uint32_t a = wave_incl_scan_u32(less[j]), b = wave_incl_scan_u32(eq[j]);
+        if (lane == 63) { atomicAdd(&s_less[j], a); atomicAdd(&s_eq[j], b); }
+      }
+    nnan = wave_incl_scan_u32(nnan);
+    if (lane == 63) atomicAdd(&s_nan, nnan);
+    __syncthreads();
+    if (tid == 0) {
+      PartMeta& mt = meta[c];
+      const int32_t nvalid = g - (int32_t)s_nan;
+      int32_t total = 0, worst = 0;
+      for (int a = 0; a <= p; ++a) {
+        const int32_t below = (a == 0) ? 0 : (int32_t)(s_less[a - 1] + s_eq[a - 1]);      // keys <= t_{a-1}
+        const int32_t upto = (a == p) ? nvalid : (int32_t)s_less[a];                      // keys <  t_a
+        const int32_t sz = upto - below;
+        mt.open[a] = sz;
+        total += sz;
+        worst = sz > worst ? sz : worst;
+      }
+      for (int a = p + 1; a <= kPartMax; ++a) mt.open[a] = 0;
+      for (int j = 0; j < kPartMax; ++j) { mt.t[j] = j < p ? s_t[j] : ~0ull; mt.less[j] = (int32_t)s_less[j]; mt.eq[j] = (int32_t)s_eq[j]; }
+      mt.p = p;
+      mt.smax = -INFINITY;
+      const int fb = worst > kMaxBucketKeys ? 1 : 0;
+      mt.fallback = fb;
+      col_open[c] = fb ? 0 : total;
+      if (fb) fb_list[atomicAdd(fb_count, 1)] = col0 + c;
+    }
+    __syncthreads();
+  }
+}
+
+// column bases (exclusive scan of the open-interval totals) and the CSR pointer array of all segments: PS per column
+__global__ void __launch_bounds__(1024)
+rank_part_scan_kernel(const PartMeta* __restrict__ meta, const int32_t* __restrict__ col_open, int32_t n, int PS,
+                      int32_t* __restrict__ seg_ptr) {
+  __shared__ int32_t s_sum[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int c0 = tid * per, c1 = (c0 + per < n) ? c0 + per : n;
+  int32_t sum = 0;
+  for (int c = c0; c < c1; ++c) sum += col_open[c];
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int32_t v = (tid >= off) ? s_sum[tid - off] : 0;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  int32_t run = s_sum[tid] - sum;
+  for (int c = c0; c < c1; ++c) {
+    const PartMeta& mt = meta[c];
+    for (int a = 0; a < PS; ++a) {
+      seg_ptr[(int64_t)c * PS + a] = run;
+      if (!mt.fallback && a <= mt.p) run += mt.open[a];
+    }
+  }
+  if (tid == 1023) seg_ptr[(int64_t)n * PS] = s_sum[1023];
+}
+
+__device__ __forceinline__ double part_power(double r, double power, int pow_q4) {
+  return power == 1.0 ? r : (pow_q4 > 0 ? pow_quarters(r, pow_q4) : PH_POW(r, power));
+}
+
+// single-value classes and NaN go straight to R; the keys of the open intervals to their segments (value + row)
+__global__ void __launch_bounds__(1024)
+rank_part_scatter_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, int32_t n, int ties, int is_signed,
+                         double power, int pow_q4, PartMeta* __restrict__ meta, const int32_t* __restrict__ seg_ptr,
+                         int PS, double* __restrict__ Vs, int32_t* __restrict__ Is, double* __restrict__ R, int64_t ldr) {
+  __shared__ uint32_t s_cur[kPartMax + 1];
+  __shared__ double s_max[16];
+  __shared__ PartMeta mt;                      // this column's splitters and counts (the global copy is written below)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    if (meta[c].fallback) continue;            // (uniform: the whole column is ranked by the network kernel)
+    if (tid < (int)(sizeof(PartMeta) / 4)) reinterpret_cast<uint32_t*>(&mt)[tid] = reinterpret_cast<const uint32_t*>(&meta[c])[tid];
+    if (tid <= kPartMax) s_cur[tid] = 0;
+    __syncthreads();
+    const int p = mt.p;
+    const double* xc = X + (int64_t)c * ldx;
+    double* rc = R + (int64_t)c * ldr;
+    const int32_t* sp = seg_ptr + (int64_t)c * PS;
+    double vmax = -INFINITY;
+    for (int i0 = 0; i0 < g; i0 += 1024) {
+      const int i = i0 + tid;
+      const bool in = i < g;
+      const double x0 = in ? xc[i] : 0.0;
+      const uint64_t k = part_key(x0, is_signed);
+      int a = 0;
+      bool e = false;
+#pragma unroll
+      for (int j = 0; j < kPartMax; ++j)
+        if (j < p) {
+          const uint64_t t = mt.t[j];
+          a += (t < k) ? 1 : 0;
+          e = e || (t == k);
+        }
+      const bool isnan_ = k == ~0ull;
+      if (in && isnan_) rc[i] = __longlong_as_double(0x7ff8000000000000ll);
+      if (in && !isnan_ && e) {
+        const uint32_t lb = (uint32_t)mt.less[a], ub = lb + (uint32_t)mt.eq[a];
+        double r = part_power(rank_from_bounds(lb, ub, ties), power, pow_q4);
+        vmax = r > vmax ? r : vmax;
+        if (is_signed) r *= sign_of(x0);
+        rc[i] = r;
+      }
+      const bool open = in && !isnan_ && !e;
+      for (int cls = 0; cls <= p; ++cls) {
+        const unsigned long long m = __ballot(open && a == cls);
+        if (m != 0ull) {
+          const int leader = __builtin_ctzll(m);
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(&s_cur[cls], (uint32_t)__popcll(m));
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+          if (open && a == cls) {
+            const int64_t q = (int64_t)sp[cls] + base +
+                              __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            Vs[q] = x0;
+            Is[q] = i;
+          }
+        }
+      }
+    }
+    vmax = wave_max_f64_dpp(vmax);
+    if (lane == 63) s_max[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_max[0];
+      for (int w = 1; w < 16; ++w) v = s_max[w] > v ? s_max[w] : v;
+      meta[c].smax = v;
+    }
+    __syncthreads();
+  }
+}
+
+// rank inside the segment + keys in the classes below = rank in the column; back to the rows
+__global__ void __launch_bounds__(1024)
+rank_part_finish_kernel(int32_t n, int is_signed, double power, int pow_q4, const PartMeta* __restrict__ meta,
+                        const int32_t* __restrict__ seg_ptr, int PS, const double* __restrict__ Rseg,
+                        const int32_t* __restrict__ Is, double* __restrict__ R, int64_t ldr, double* __restrict__ colmax) {
+  __shared__ double s_max[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const PartMeta& mt = meta[c];
+    if (mt.fallback) continue;
+    double* rc = R + (int64_t)c * ldr;
+    const int32_t* sp = seg_ptr + (int64_t)c * PS;
+    double vmax = -INFINITY;
+    for (int a = 0; a <= mt.p; ++a) {
+      const double off = (a == 0) ? 0.0 : (double)(mt.less[a - 1] + mt.eq[a - 1]);
+      const int q1 = sp[a + 1];
+      for (int q = sp[a] + tid; q < q1; q += 1024) {
+        const double rs = Rseg[q];
+        double r;
+        if (is_signed) {
+          const double mag = (rs != 0.0) ? part_power(fabs(rs) + off, power, pow_q4) : 0.0;
+          vmax = mag > vmax ? mag : vmax;
+          r = rs < 0.0 ? -mag : mag;
+        } else {
+          r = part_power(rs + off, power, pow_q4);
+          vmax = r > vmax ? r : vmax;
+        }
+        rc[Is[q]] = r;
+      }
+    }
+    if (colmax != nullptr) {
+      vmax = wave_max_f64_dpp(vmax);
+      if (lane == 63) s_max[wave] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        double v = mt.smax;
+        for (int w = 0; w < 16; ++w) v = s_max[w] > v ? s_max[w] : v;
+        colmax[c] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static int launch_colranks_dense_partitioned(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n, int ties,
+                                             int is_signed, double power, double* R, int64_t ldr, double* colmax) {
+  const int K = (g + kPartTarget - 1) / kPartTarget;
+  const int PS = K + 1;                       // segments per column in the pointer array (the last one stays empty)
+  const double q4 = power * 4.0;
+  const int pow_q4 = (power != 1.0 && q4 >= 1.0 && q4 <= 16.0 && q4 == (double)(int)q4) ? (int)q4 : 0;
+  // scratch per column: segment values (8 g) + rows (4 g) + segment ranks (8 g) + metadata; panels of <= 2 GiB
+  const size_t per_col = (size_t)g * 20 + sizeof(PartMeta) + (size_t)PS * 4 + 8;
+  int64_t panel = (int64_t)(((size_t)2 << 30) / per_col);
+  panel = panel < 1 ? 1 : (panel > n ? n : panel);
+  const size_t a8 = ((size_t)panel * g * 8 + 255) & ~(size_t)255, a4 = ((size_t)panel * g * 4 + 255) & ~(size_t)255;
+  const size_t am = ((size_t)panel * sizeof(PartMeta) + 255) & ~(size_t)255;
+  const size_t asp = (((size_t)panel * PS + 1) * 4 + 255) & ~(size_t)255, aco = ((size_t)panel * 4 + 255) & ~(size_t)255;
+  const size_t afb = ((size_t)n * 4 + 16 + 255) & ~(size_t)255;
+  const size_t need = 2 * a8 + a4 + am + asp + aco + afb;
+  if (ctx->rank_scratch_bytes < need) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->rank_scratch) PH_HIP(hipFree(ctx->rank_scratch));
+    ctx->rank_scratch = nullptr;
+    ctx->rank_scratch_bytes = 0;
+    PH_HIP(hipMalloc(&ctx->rank_scratch, need));
+    ctx->rank_scratch_bytes = need;
+  }
+  char* base = static_cast<char*>(ctx->rank_scratch);
+  double* Vs = reinterpret_cast<double*>(base);
+  double* Rseg = reinterpret_cast<double*>(base + a8);
+  int32_t* Is = reinterpret_cast<int32_t*>(base + 2 * a8);
+  PartMeta* meta = reinterpret_cast<PartMeta*>(base + 2 * a8 + a4);
+  int32_t* seg_ptr = reinterpret_cast<int32_t*>(base + 2 * a8 + a4 + am);
+  int32_t* col_open = reinterpret_cast<int32_t*>(base + 2 * a8 + a4 + am + asp);
+  int32_t* fb_count = reinterpret_cast<int32_t*>(base + 2 * a8 + a4 + am + asp + aco);
+  int32_t* fb_list = fb_count + 4;
+  PH_HIP(hipMemsetAsync(fb_count, 0, 16, ctx->stream));
+  for (int64_t c0 = 0; c0 < n; c0 += panel) {
+    const int32_t nc = (int32_t)((n - c0) < panel ? (n - c0) : panel);
+    const double* Xc = X + c0 * ldx;
+    double* Rc = R + c0 * ldr;
+    const int grid = nc < 2 * ctx->num_cu ? nc : 2 * ctx->num_cu;
+    hipLaunchKernelGGL(rank_part_count_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, nc, is_signed, K, meta,
+                       col_open, fb_count, fb_list, (int32_t)c0);
+    hipLaunchKernelGGL(rank_part_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, meta, col_open, nc, PS, seg_ptr);
+    hipLaunchKernelGGL(rank_part_scatter_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, nc, ties, is_signed, power,
+                       pow_q4, meta, seg_ptr, PS, Vs, Is, Rc, ldr);
+    PH_HIP(hipGetLastError());
+    // every segment is a CSC column of at most kMaxBucketKeys values: the bucket ranker (its own clustered-values fallback
+    // included); signed ranks come back with their sign
+    const int rc = launch_ranks(ctx, Vs, 0, 0, seg_ptr, nc * PS, kMaxBucketKeys, ties, is_signed, 1.0, Rseg, 0, nullptr);
+    if (rc != PLAIDHIP_OK) return rc;
+    hipLaunchKernelGGL(rank_part_finish_kernel, dim3(grid), dim3(1024), 0, ctx->stream, nc, is_signed, power, pow_q4, meta,
+                       seg_ptr, PS, Rseg, Is, Rc, ldr, colmax != nullptr ? colmax + c0 : nullptr);
+    PH_HIP(hipGetLastError());
+  }
+  // columns with an over-full open interval (heavy clusters the sample did not isolate): the sorting network on a global
+  // scratch, as before; a persistent grid reads the device-side list
+  const int fb_grid = n < ctx->num_cu ? n : ctx->num_cu;
+  const int64_t stride = ((int64_t)g + 1) & ~1ll;
+  const int rcw = ensure_workspace(ctx, (size_t)(n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu) * (size_t)stride * 8);
+  if (rcw != PLAIDHIP_OK) return rcw;
+  return launch_network(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax, nullptr, nullptr, fb_grid, 0,
+                        fb_list, fb_count);
+}
+
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
                               int ties, int is_signed, double power, double* R, int64_t ldr,
                               double* colmax) {
+  // columns beyond the bucket ranker's LDS: cut by value into segments it takes (above), unless the context pins a kernel
+  if (g > kMaxBucketKeys && (g + kPartTarget - 1) / kPartTarget <= kPartMax && ctx->opt_rank_kernel != 1)
+    return launch_colranks_dense_partitioned(ctx, X, ldx, g, n, ties, is_signed, power, R, ldr, colmax);
   return launch_ranks(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax);
 }
 

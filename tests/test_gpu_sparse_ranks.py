@@ -115,3 +115,79 @@ def test_replaid_sing_on_a_sparse_matrix(hip_ctx, g, n, m):
     assert got.rownames == Gn.colnames and got.colnames == Xn.colnames
     np.testing.assert_allclose(got.values, po.replaid_sing(X, rn, Gd, rn), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(got.values, plaid_amd.replaid_sing(Xd, Gn).values, rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------- dense columns beyond the LDS: value-partitioned ranking
+def _long_columns(rng, g, n, kind):
+    if kind == "normal":
+        X = rng.normal(8.0, 2.0, size=(g, n))
+    elif kind == "ties":
+        X = np.round(rng.normal(0.0, 3.0, size=(g, n)), 1)                  # ~200 distinct values
+    elif kind == "zeros":                                                     # a dense single-cell matrix: 94 % zeros
+        X = np.where(rng.random((g, n)) < 0.06, np.round(rng.gamma(2.0, 1.5, size=(g, n)), 1), 0.0)
+    elif kind == "cluster":                                                   # 70 % of the keys inside one narrow interval
+        X = rng.normal(0.0, 1.0, size=(g, n))                                 # that no sample quantile isolates: fallback
+        sel = rng.random((g, n)) < 0.7
+        X[sel] = 5.0 + 1e-9 * rng.random(int(sel.sum()))
+    elif kind == "constant":
+        X = np.full((g, n), 2.5)
+    elif kind == "adversarial":                                               # the 1,024 sampled rows hold the small values:
+        X = 100.0 + rng.random((g, n))                                        # every splitter lies below the bulk, whose open
+        rows = (np.arange(1024, dtype=np.int64) * g) >> 10                    # interval is far too long -> device-side fallback
+        X[rows, :] = rng.random((1024, n))
+        X[:, n - 1] = rng.normal(size=g)                                      # (and one ordinary column next to them)
+    else:
+        raise ValueError(kind)
+    return X
+
+
+@pytest.mark.parametrize("g,kind", [(20353, "normal"), (25000, "ties"), (33538, "zeros"), (36601, "normal"), (60000, "ties"),
+                                    (61000, "cluster"), (150000, "normal"), (40000, "constant"), (33000, "zeros"),
+                                    (45000, "adversarial")])
+def test_colranks_dense_long_columns_by_value_partition(hip_ctx, g, kind):
+    """columns longer than the bucket ranker's 20,352 keys are cut by value into segments it takes: ranks equal the
+    oracle's bit for bit -- every ties method, signed, with a heavy single value (zeros), with clustered values that send
+    the column to the sorting-network fallback, and for a constant column"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(g)
+    n = 5 if g < 100000 else 2
+    X = _long_columns(rng, g, n, kind)
+    if kind != "constant":
+        X[::7, 0] *= -1.0
+    for tm in ("average", "min", "max"):
+        for signed in (False, True):
+            assert np.array_equal(hip_ctx.colranks_dense(X, tm, signed), c_oracle.colranks_dense(X, tm, signed)), (tm, signed)
+
+
+def test_colranks_dense_long_columns_power_colmax_nan_and_strides(hip_ctx):
+    """device-level entry on 30,001-row columns: leading dimensions larger than the column, fused power, column maxima,
+    NaN entries (set aside), and more columns than workgroups in flight"""
+    import torch
+    from oracle import c_oracle
+    rng = np.random.default_rng(12)
+    g, n, ldx, ldr = 30001, 700, 30004, 30002
+    X = np.round(rng.normal(1.0, 2.0, size=(g, n)), 2)
+    X[rng.random(X.shape) < 0.3] = 0.0
+    dev = torch.device("cuda", 0)
+    Xd = torch.zeros((n, ldx), dtype=torch.float64, device=dev)
+    Xd[:, :g] = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+    for power, tm, signed in ((1.0, "min", False), (1.25, "average", False), (1.3, "max", False), (1.25, "average", True)):
+        R = torch.full((n, ldr), -7.0, dtype=torch.float64, device=dev)
+        cm = torch.empty(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        hip_ctx.dev_colranks_dense(Xd.data_ptr(), ldx, g, n, R.data_ptr(), ldr, tm, signed, power, cm.data_ptr())
+        hip_ctx.synchronize()
+        Rh = R.cpu().numpy()
+        assert np.all(Rh[:, g:] == -7.0)
+        base = c_oracle.colranks_dense(X, tm, signed)
+        exp = np.sign(base) * np.abs(base) ** power
+        np.testing.assert_allclose(Rh[:, :g].T, exp, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(cm.cpu().numpy(), np.abs(exp).max(axis=0), rtol=1e-13)
+    Xn = X[:, :4].copy()
+    Xn[17, 0] = np.nan
+    Xn[::1000, 2] = np.nan
+    got = hip_ctx.colranks_dense(Xn, "average", False)
+    assert np.array_equal(np.isnan(got), np.isnan(Xn))
+    for c in range(4):
+        ok = ~np.isnan(Xn[:, c])
+        assert np.array_equal(got[ok, c], c_oracle.colranks_dense(Xn[ok, c:c + 1], "average", False)[:, 0])
