@@ -451,17 +451,19 @@ struct PartMeta {
 __device__ __forceinline__ uint64_t part_key(double x, int is_signed) { return f64_to_key(is_signed ? fabs(x) : x); }
 
 __global__ void __launch_bounds__(1024)
-rank_part_count_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, int32_t n, int is_signed, int K,
-                       PartMeta* __restrict__ meta, int32_t* __restrict__ col_open, int32_t* __restrict__ fb_count,
-                       int32_t* __restrict__ fb_list, int32_t col0) {
+rank_part_count_kernel(const double* __restrict__ X, int64_t ldx, int32_t g_dense, const int32_t* __restrict__ Xp, int32_t n,
+                       int is_signed, int K, PartMeta* __restrict__ meta, int32_t* __restrict__ col_open,
+                       int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_list, int32_t col0) {
   __shared__ uint64_t skeys[1024];
   __shared__ uint64_t s_t[kPartMax];
   __shared__ uint32_t s_less[kPartMax], s_eq[kPartMax], s_nan;
   __shared__ int s_p;
   const int tid = threadIdx.x, lane = tid & 63;
   for (int c = blockIdx.x; c < n; c += gridDim.x) {
-    const double* xc = X + (int64_t)c * ldx;
-    skeys[tid] = part_key(xc[((int64_t)tid * g) >> 10], is_signed);
+    // a dense column, or the stored values of a CSC column (sparse_colranks: any length, also 0)
+    const double* xc = Xp != nullptr ? X + Xp[c] : X + (int64_t)c * ldx;
+    const int32_t g = Xp != nullptr ? Xp[c + 1] - Xp[c] : g_dense;
+    skeys[tid] = g > 0 ? part_key(xc[((int64_t)tid * g) >> 10], is_signed) : ~0ull;
     if (tid < kPartMax) { s_less[tid] = 0; s_eq[tid] = 0; }
     if (tid == 0) s_nan = 0;
     bitonic_sort_lds(skeys, 1024);            // starts and ends with a barrier; NaN keys (all ones) sort last
@@ -561,9 +563,10 @@ __device__ __forceinline__ double part_power(double r, double power, int pow_q4)
 
 // single-value classes and NaN go straight to R; the keys of the open intervals to their segments (value + row)
 __global__ void __launch_bounds__(1024)
-rank_part_scatter_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, int32_t n, int ties, int is_signed,
-                         double power, int pow_q4, PartMeta* __restrict__ meta, const int32_t* __restrict__ seg_ptr,
-                         int PS, double* __restrict__ Vs, int32_t* __restrict__ Is, double* __restrict__ R, int64_t ldr) {
+rank_part_scatter_kernel(const double* __restrict__ X, int64_t ldx, int32_t g_dense, const int32_t* __restrict__ Xp, int32_t n,
+                         int ties, int is_signed, double power, int pow_q4, PartMeta* __restrict__ meta,
+                         const int32_t* __restrict__ seg_ptr, int PS, double* __restrict__ Vs, int32_t* __restrict__ Is,
+                         double* __restrict__ R, int64_t ldr) {
   __shared__ uint32_t s_cur[kPartMax + 1];
   __shared__ double s_max[16];
   __shared__ PartMeta mt;                      // this column's splitters and counts (the global copy is written below)
@@ -574,10 +577,11 @@ rank_part_scatter_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, i
     if (tid <= kPartMax) s_cur[tid] = 0;
     __syncthreads();
     const int p = mt.p;
-    const double* xc = X + (int64_t)c * ldx;
-    double* rc = R + (int64_t)c * ldr;
+    const double* xc = Xp != nullptr ? X + Xp[c] : X + (int64_t)c * ldx;
+    double* rc = Xp != nullptr ? R + Xp[c] : R + (int64_t)c * ldr;
+    const int32_t g = Xp != nullptr ? Xp[c + 1] - Xp[c] : g_dense;
     const int32_t* sp = seg_ptr + (int64_t)c * PS;
-    double vmax = -INFINITY;
+    double vmax = Xp != nullptr ? 0.0 : -INFINITY;   // (sparse ranks: the implicit zeros, as in the bucket kernel)
     for (int i0 = 0; i0 < g; i0 += 1024) {
       const int i = i0 + tid;
       const bool in = i < g;
@@ -632,15 +636,16 @@ rank_part_scatter_kernel(const double* __restrict__ X, int64_t ldx, int32_t g, i
 
 // rank inside the segment + keys in the classes below = rank in the column; back to the rows
 __global__ void __launch_bounds__(1024)
-rank_part_finish_kernel(int32_t n, int is_signed, double power, int pow_q4, const PartMeta* __restrict__ meta,
-                        const int32_t* __restrict__ seg_ptr, int PS, const double* __restrict__ Rseg,
-                        const int32_t* __restrict__ Is, double* __restrict__ R, int64_t ldr, double* __restrict__ colmax) {
+rank_part_finish_kernel(int32_t n, const int32_t* __restrict__ Xp, int is_signed, double power, int pow_q4,
+                        const PartMeta* __restrict__ meta, const int32_t* __restrict__ seg_ptr, int PS,
+                        const double* __restrict__ Rseg, const int32_t* __restrict__ Is, double* __restrict__ R, int64_t ldr,
+                        double* __restrict__ colmax) {
   __shared__ double s_max[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = blockIdx.x; c < n; c += gridDim.x) {
     const PartMeta& mt = meta[c];
     if (mt.fallback) continue;
-    double* rc = R + (int64_t)c * ldr;
+    double* rc = Xp != nullptr ? R + Xp[c] : R + (int64_t)c * ldr;
     const int32_t* sp = seg_ptr + (int64_t)c * PS;
     double vmax = -INFINITY;
     for (int a = 0; a <= mt.p; ++a) {
@@ -674,8 +679,10 @@ rank_part_finish_kernel(int32_t n, int is_signed, double power, int pow_q4, cons
   }
 }
 
-static int launch_colranks_dense_partitioned(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n, int ties,
-                                             int is_signed, double power, double* R, int64_t ldr, double* colmax) {
+// X dense (Xp == nullptr: n columns of g rows, leading dimensions ldx / ldr) or the stored values of CSC columns (Xp: n + 1
+// device pointers, g = the longest column; the ranks go to R + Xp[c])
+static int launch_colranks_partitioned(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, const int32_t* Xp, int32_t n,
+                                       int ties, int is_signed, double power, double* R, int64_t ldr, double* colmax) {
   const int K = (g + kPartTarget - 1) / kPartTarget;
   const int PS = K + 1;                       // segments per column in the pointer array (the last one stays empty)
   const double q4 = power * 4.0;
@@ -709,20 +716,21 @@ static int launch_colranks_dense_partitioned(plaidhip_ctx* ctx, const double* X,
   PH_HIP(hipMemsetAsync(fb_count, 0, 16, ctx->stream));
   for (int64_t c0 = 0; c0 < n; c0 += panel) {
     const int32_t nc = (int32_t)((n - c0) < panel ? (n - c0) : panel);
-    const double* Xc = X + c0 * ldx;
-    double* Rc = R + c0 * ldr;
+    const double* Xc = Xp != nullptr ? X : X + c0 * ldx;        // (CSC: the pointers are absolute offsets into @x and R)
+    double* Rc = Xp != nullptr ? R : R + c0 * ldr;
+    const int32_t* Xpc = Xp != nullptr ? Xp + c0 : nullptr;
     const int grid = nc < 2 * ctx->num_cu ? nc : 2 * ctx->num_cu;
-    hipLaunchKernelGGL(rank_part_count_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, nc, is_signed, K, meta,
+    hipLaunchKernelGGL(rank_part_count_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, Xpc, nc, is_signed, K, meta,
                        col_open, fb_count, fb_list, (int32_t)c0);
     hipLaunchKernelGGL(rank_part_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, meta, col_open, nc, PS, seg_ptr);
-    hipLaunchKernelGGL(rank_part_scatter_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, nc, ties, is_signed, power,
-                       pow_q4, meta, seg_ptr, PS, Vs, Is, Rc, ldr);
+    hipLaunchKernelGGL(rank_part_scatter_kernel, dim3(grid), dim3(1024), 0, ctx->stream, Xc, ldx, g, Xpc, nc, ties, is_signed,
+                       power, pow_q4, meta, seg_ptr, PS, Vs, Is, Rc, ldr);
     PH_HIP(hipGetLastError());
     // every segment is a CSC column of at most kMaxBucketKeys values: the bucket ranker (its own clustered-values fallback
     // included); signed ranks come back with their sign
     const int rc = launch_ranks(ctx, Vs, 0, 0, seg_ptr, nc * PS, kMaxBucketKeys, ties, is_signed, 1.0, Rseg, 0, nullptr);
     if (rc != PLAIDHIP_OK) return rc;
-    hipLaunchKernelGGL(rank_part_finish_kernel, dim3(grid), dim3(1024), 0, ctx->stream, nc, is_signed, power, pow_q4, meta,
+    hipLaunchKernelGGL(rank_part_finish_kernel, dim3(grid), dim3(1024), 0, ctx->stream, nc, Xpc, is_signed, power, pow_q4, meta,
                        seg_ptr, PS, Rseg, Is, Rc, ldr, colmax != nullptr ? colmax + c0 : nullptr);
     PH_HIP(hipGetLastError());
   }
@@ -732,8 +740,8 @@ static int launch_colranks_dense_partitioned(plaidhip_ctx* ctx, const double* X,
   const int64_t stride = ((int64_t)g + 1) & ~1ll;
   const int rcw = ensure_workspace(ctx, (size_t)(n < 2 * ctx->num_cu ? n : 2 * ctx->num_cu) * (size_t)stride * 8);
   if (rcw != PLAIDHIP_OK) return rcw;
-  return launch_network(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax, nullptr, nullptr, fb_grid, 0,
-                        fb_list, fb_count);
+  return launch_network(ctx, X, ldx, Xp != nullptr ? 0 : g, Xp, n, g, ties, is_signed, power, R, ldr, colmax, nullptr, nullptr,
+                        fb_grid, 0, fb_list, fb_count);
 }
 
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
@@ -741,7 +749,7 @@ int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, i
                               double* colmax) {
   // columns beyond the bucket ranker's LDS: cut by value into segments it takes (above), unless the context pins a kernel
   if (g > kMaxBucketKeys && (g + kPartTarget - 1) / kPartTarget <= kPartMax && ctx->opt_rank_kernel != 1)
-    return launch_colranks_dense_partitioned(ctx, X, ldx, g, n, ties, is_signed, power, R, ldr, colmax);
+    return launch_colranks_partitioned(ctx, X, ldx, g, nullptr, n, ties, is_signed, power, R, ldr, colmax);
   return launch_ranks(ctx, X, ldx, g, nullptr, n, g, ties, is_signed, power, R, ldr, colmax);
 }
 
@@ -848,6 +856,9 @@ int max_sparse_rank_column() { return kMaxBucketKeys; }
 // stream-ordered: the caller states the longest column (include/plaidhip.h), nothing is read back
 int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n, int32_t max_col_nnz,
                             int ties, int is_signed, double power, double* Rx, double* colmax) {
+  // columns with more stored values than the bucket ranker's LDS holds: cut by value (launch_colranks_partitioned)
+  if (n > 0 && max_col_nnz > kMaxBucketKeys && (max_col_nnz + kPartTarget - 1) / kPartTarget <= kPartMax && ctx->opt_rank_kernel != 1)
+    return launch_colranks_partitioned(ctx, Xx, 0, max_col_nnz, Xp, n, ties, is_signed, power, Rx, 0, colmax);
   return launch_ranks(ctx, Xx, 0, 0, Xp, n, max_col_nnz, ties, is_signed, power, Rx, 0, colmax);
 }
 

@@ -191,3 +191,24 @@ def test_colranks_dense_long_columns_power_colmax_nan_and_strides(hip_ctx):
     for c in range(4):
         ok = ~np.isnan(Xn[:, c])
         assert np.array_equal(got[ok, c], c_oracle.colranks_dense(Xn[ok, c:c + 1], "average", False)[:, 0])
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_sparse_colranks_columns_with_more_stored_values_than_the_lds_holds(hip_ctx, signed):
+    """sparse_colranks() (R/plaid.R:631-650) on a dgCMatrix whose columns store 25,000-45,000 values (a dense-ish matrix kept
+    in sparse form) next to a short and an empty column: the value-partitioned route on CSC columns, bit-exact"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(31)
+    g = 60000
+    lens = [45000, 0, 300, 25000, 20353, 33333]
+    cols, vals = [], []
+    for k in lens:
+        cols.append(np.sort(rng.choice(g, size=k, replace=False)))
+        v = np.round(rng.normal(0.0, 3.0, size=k), 1)
+        v[v == 0.0] = 0.5
+        vals.append(v)
+    Xp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    Xx = np.concatenate(vals)
+    for tm in ("average", "min", "max"):
+        got = hip_ctx.colranks_csc(Xp, Xx, tm, signed)
+        assert np.array_equal(got, c_oracle.sparse_colranks(Xp, Xx, tm, signed)), tm
