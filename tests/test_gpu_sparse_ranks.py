@@ -212,3 +212,33 @@ def test_sparse_colranks_columns_with_more_stored_values_than_the_lds_holds(hip_
     for tm in ("average", "min", "max"):
         got = hip_ctx.colranks_csc(Xp, Xx, tm, signed)
         assert np.array_equal(got, c_oracle.sparse_colranks(Xp, Xx, tm, signed)), tm
+
+
+def test_colranks_dense_long_columns_several_scratch_panels(pinned_ctx):
+    """more columns than one 2-GiB scratch panel of the value-partitioned route holds (60,000 rows: 1,789 columns per
+    panel): bit-identical to the sorting-network route (rank_kernel = network), which the shorter tests pin to the oracle"""
+    import torch
+    g, n = 60000, 2100
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    X = torch.round(torch.randn((n, g), dtype=torch.float64, device=dev, generator=gen) * 50) / 10      # ties
+    X[:, ::3] = 0.0
+    R1 = torch.empty_like(X)
+    R2 = torch.empty_like(X)
+    c1 = torch.empty(n, dtype=torch.float64, device=dev)
+    c2 = torch.empty(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx = pinned_ctx()
+    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R1.data_ptr(), g, "average", False, 1.25, c1.data_ptr())
+    ctx.set_option("rank_kernel", "network")
+    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R2.data_ptr(), g, "average", False, 1.25, c2.data_ptr())
+    ctx.synchronize()
+    # (the network kernel raises to the power with pow(), the bucket ranker by square roots: a few ulp)
+    assert torch.allclose(R1, R2, rtol=1e-13, atol=0) and torch.allclose(c1, c2, rtol=1e-13, atol=0)
+    ctx.set_option("rank_kernel", "auto")
+    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R1.data_ptr(), g, "min", True, 1.0, None)
+    ctx.set_option("rank_kernel", "network")
+    ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R2.data_ptr(), g, "min", True, 1.0, None)
+    ctx.synchronize()
+    assert torch.equal(R1, R2)
