@@ -108,6 +108,28 @@ class HipPhaseEngine:
             self.ctx.dev_max(colmax.data_ptr(), X.n, gmax.data_ptr())
         return Rx, gmax
 
+    def colranks_csc_dense(self, X: CscShard, ties="average", signed=False, power=1.0, rows=None):
+        """colranks(X sparse, keep.zero = FALSE) of the shard (R/plaid.R:602-609): the zeros are ranked, dense (cells, genes)
+        result, built from the ranks of the stored values (any number of genes); columns with more than 20,352 stored
+        values take the densify-and-rank entry.  `rows`: columns [lo, hi) of the shard (a panel)"""
+        self._same_stream()
+        t = self.torch
+        lo, hi = (0, X.n) if rows is None else rows
+        n = hi - lo
+        ld = X.g + (X.g & 1)
+        R = t.empty((n, ld), dtype=t.float64, device=self.device)
+        if n == 0:
+            return R
+        p = X.p[lo:hi + 1]
+        if X.max_col_nnz <= 20352:
+            Rx = t.empty(max(X.nnz, 1), dtype=t.float64, device=self.device)
+            self.ctx.dev_colranks_csc_dense_nz(p.data_ptr(), X.i.data_ptr(), X.x.data_ptr(), X.g, n, X.max_col_nnz,
+                                               Rx.data_ptr(), R.data_ptr(), ld, ties, signed, power)
+        else:
+            self.ctx.dev_colranks_csc_dense(p.data_ptr(), X.i.data_ptr(), X.x.data_ptr(), X.g, n, R.data_ptr(), ld, ties,
+                                            signed, power)
+        return R
+
     def new_flags(self):
         return self.torch.zeros(4, dtype=self.torch.int32, device=self.device)
 
@@ -212,6 +234,21 @@ def sharded_sing(engine, X_local, group=None):
     """replaid.sing (R/plaid.R:213-219): no cross-shard coupling at all."""
     R, _ = engine.colranks(X_local, "min")
     return sharded_plaid(engine, R, "mean", False, 1.0 / X_local.shape[1], -0.5, None, group, x_is_ranks=True)
+
+
+def sharded_sing_csc(engine, X_local: "CscShard", group=None, panel_bytes: int = 2 << 30):
+    """replaid.sing on a dgCMatrix shard: colranks(X, ties.method = "min") ranks the zeros too (R/plaid.R:602-609), so the
+    rank matrix is dense -- built panel by panel from the ranks of the stored values and multiplied at once; the shard
+    itself never exists densely.  No cross-shard coupling."""
+    import torch
+    g, n = X_local.g, X_local.n
+    panel = max(2, (panel_bytes // max(1, (g + (g & 1)) * 8)) & ~1)
+    out = []
+    for lo in range(0, max(n, 1), panel):
+        hi = min(n, lo + panel)
+        R = engine.colranks_csc_dense(X_local, "min", rows=(lo, hi))
+        out.append(engine.spmm(R, "mean", 1.0 / g, -0.5, None, None, ranks=True))
+    return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
 
 def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):

@@ -242,3 +242,33 @@ def test_colranks_dense_long_columns_several_scratch_panels(pinned_ctx):
     ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R2.data_ptr(), g, "min", True, 1.0, None)
     ctx.synchronize()
     assert torch.equal(R1, R2)
+
+
+def test_sharded_sing_csc_hip_phase_engine():
+    """the torch.distributed form (plaid_amd/sharded.py) of replaid.sing on a CSC shard, single process: panels of dense
+    min-ranks from the stored values + the exact rank crossprod; equals the host entry's scores bit for bit"""
+    import torch
+    import plaid_amd
+    from plaid_amd import sharded, synth as sy
+    from oracle import plaid_oracle as po
+    g, n, m = 24001, 37, 90
+    rng = np.random.default_rng(2)
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=300)
+    X = np.round(rng.gamma(2.0, 1.5, size=(g, n)), 1)
+    X[rng.random(X.shape) < 0.9] = 0.0
+    Xs = sp.csc_matrix(X)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    eng = sharded.HipPhaseEngine(ctx, gs, dev)
+    shard = sharded.CscShard.from_scipy(Xs, 0, n, device=dev)
+    with torch.cuda.stream(stream):
+        S = sharded.sharded_sing_csc(eng, shard, panel_bytes=10 * (g + 1) * 8)      # 4 panels of 10 cells
+    torch.cuda.synchronize()
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    np.testing.assert_allclose(S.cpu().numpy().T, po.replaid_sing(X, rn, G, rn), rtol=RTOL, atol=ATOL)
+    assert np.array_equal(S.cpu().numpy().T, ctx.sing_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi))
+    gs.close()
+    ctx.close()

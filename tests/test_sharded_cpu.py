@@ -30,7 +30,7 @@ class OraclePhaseEngine:
         return torch.zeros(4, dtype=torch.int32)
 
     def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False):
-        Xn = X.numpy().T                                        # g x n_local
+        Xn = X.numpy().T[:self.g]                               # g x n_local (a padded leading dimension is cut off)
         raw = np.asarray(self.G.T @ Xn)
         w = 1.0 / (1e-8 + self.k) if stat == "mean" else np.ones_like(self.k)
         a = alpha / float(alpha_div.item()) if alpha_div is not None else alpha
@@ -62,6 +62,16 @@ class OraclePhaseEngine:
         xx = (X.x if values is None else values).numpy()
         Xs = sp.csc_matrix((xx, X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))
         return self._epilogue(np.asarray((self.G.T @ Xs).todense()), stat, alpha, beta, alpha_div, flags)
+
+    def colranks_csc_dense(self, X, ties="average", signed=False, power=1.0, rows=None):
+        lo, hi = (0, X.n) if rows is None else rows
+        Xs = sp.csc_matrix((X.x.numpy(), X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))[:, lo:hi]
+        R = po.colranks(Xs.toarray(), signed=signed, ties_method=ties) if hi > lo else np.zeros((self.g, 0))
+        R = R ** power if power != 1.0 else R
+        ld = self.g + (self.g & 1)
+        out = np.zeros((hi - lo, ld))
+        out[:, :self.g] = R.T
+        return torch.from_numpy(out)
 
     def sparse_colranks(self, X, ties="average", signed=False, power=1.0):
         Xs = sp.csc_matrix((X.x.numpy(), X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))
@@ -112,6 +122,7 @@ def _worker(rank, world, port, n, case, out_path):
         shard = sharded.CscShard.from_scipy(sp.csc_matrix(Xz), lo, hi)
         res["plaid_csc"] = sharded.sharded_plaid_csc(eng, shard)
         res["ssgsea_csc"] = sharded.sharded_ssgsea_csc(eng, shard, alpha=0.25)
+        res["sing_csc"] = sharded.sharded_sing_csc(eng, shard, panel_bytes=2 * g * 8 * 2)   # panels of 4 cells
         full = {k: sharded.gather_scores(v, n, dst=0) for k, v in res.items()}
         # the gathers that complete at config 5's size: slabs of a few rows, to the host (one shared matrix, every rank
         # writes its rows) and to the device with an fp32 cast; and the refusals, raised on EVERY rank before any transfer
@@ -160,6 +171,7 @@ def test_sharded_equals_unsharded_gloo(tmp_path, n, case):
     Xs = sp.csc_matrix(Xz)
     np.testing.assert_allclose(got["plaid_csc"], po.plaid(Xs, rn, G, rn), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(got["ssgsea_csc"], po.replaid_ssgsea(Xs, rn, G, rn, alpha=0.25), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(got["sing_csc"], po.replaid_sing(Xz, rn, G, rn), rtol=1e-10, atol=1e-12)   # zeros ranked
 
 
 def test_csc_shard_bookkeeping():
