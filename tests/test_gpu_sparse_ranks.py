@@ -272,3 +272,32 @@ def test_sharded_sing_csc_hip_phase_engine():
     assert np.array_equal(S.cpu().numpy().T, ctx.sing_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi))
     gs.close()
     ctx.close()
+
+
+def test_colranks_dense_long_columns_extreme_values(pinned_ctx):
+    """+-inf, +-0, denormals, the largest and smallest doubles, values one ulp apart, an all-NaN column and a column with a
+    single non-NaN entry in 26,000-row columns: the value-partitioned route equals the sorting-network route bit for bit
+    (NaN positions included), and the oracle on the NaN-free columns"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    g, n = 26000, 6
+    X = rng.normal(size=(g, n))
+    special = np.array([np.inf, -np.inf, 0.0, -0.0, 5e-324, -5e-324, 1.7976931348623157e308, -1.7976931348623157e308,
+                        1.0, np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0), 2.2250738585072014e-308])
+    X[rng.choice(g, size=4000, replace=False), 0] = rng.choice(special, size=4000)
+    X[:, 1] = rng.choice(special, size=g)                        # only 12 distinct values (+-0 tie)
+    X[:, 2] = np.nan
+    X[:, 3] = np.nan
+    X[777, 3] = -3.5
+    X[::5, 4] = np.nan
+    ctx = pinned_ctx()
+    for tm in ("average", "min", "max"):
+        for signed in (False, True):
+            ctx.set_option("rank_kernel", "auto")
+            with np.errstate(all="ignore"):
+                a = ctx.colranks_dense(X, tm, signed)
+                ctx.set_option("rank_kernel", "network")
+                b = ctx.colranks_dense(X, tm, signed)
+            assert np.array_equal(a, b, equal_nan=True), (tm, signed)
+            assert np.array_equal(np.isnan(a), np.isnan(X))
+            assert np.array_equal(a[:, [0, 1, 5]], c_oracle.colranks_dense(X[:, [0, 1, 5]], tm, signed)), (tm, signed)
