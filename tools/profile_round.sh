@@ -42,6 +42,8 @@ python3 tools/bench_spmm.py --kernel medians --samples 8192 --sets 50000 --iters
 for m in 1000 3000 5000 6000 8000 20000; do python3 tools/bench_spmm.py --kernel medians --samples 10000 --sets $m --iters 10 2>&1 | grep "^medians" >> $out/medians_sizes.log; done
 python3 tools/bench_spmm.py --kernel step --iters 10 2>&1 | grep "^step" > $out/step_c2.log
 python3 tools/bench_weighted.py > $out/weighted.log 2>&1
+python3 tools/bench_rank_long.py > $out/rank_long.log 2>&1
+python3 tools/bench_sparse_sing.py > $out/sparse_sing.log 2>&1
 [ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
 [ -x tools/ubench/stream_rw ] && ./tools/ubench/stream_rw 3.2 > $out/ubench_stream_rw.log 2>&1
 python3 - "$out" <<'PY'
