@@ -402,13 +402,19 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
                     pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
                     evs[k & 1] = torch.cuda.Event()
                     evs[k & 1].record(side)
-            # the move into the shared matrix takes first-touch page faults (fresh shm pages) and is a plain memcpy: four
-            # threads per rank (numpy releases the GIL while it copies)
+            # the move into the shared matrix takes first-touch page faults (fresh shm pages) and is a plain memcpy: several
+            # threads per rank (numpy releases the GIL while it copies) -- the host's cores divided among the ranks,
+            # between 4 and 16 (measured on a 256-thread host, 8 GB, one rank: 4 threads 5.3 GB/s)
             from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(4)
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 4
+            nthr = int(os.environ.get("PLAIDHIP_GATHER_THREADS", max(4, min(16, ncpu // max(1, world)))))
+            pool = ThreadPoolExecutor(nthr)
 
             def move(dst_rows, src_arr):
-                k4 = max(1, (src_arr.shape[0] + 3) // 4)
+                k4 = max(1, (src_arr.shape[0] + nthr - 1) // nthr)
                 futs = [pool.submit(lambda a=a: mm.__setitem__(slice(dst_rows + a, dst_rows + min(src_arr.shape[0], a + k4)),
                                                                src_arr[a:a + k4]))
                         for a in range(0, src_arr.shape[0], k4)]
