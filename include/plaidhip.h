@@ -147,7 +147,9 @@ int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
 /* same with X as CSC (dgCMatrix) -- sparse branch of Matrix::crossprod at R/plaid.R:107.
  * `nnz`: number of stored values of X when the caller knows it (Xp[n] on the host), else -1.  It picks
  * the kernel: sparse-aware scatter below 12.5 % stored values, column gather above; with -1 both are
- * enqueued and the one that does not apply returns at once (the value is then read on the device). */
+ * enqueued and the one that does not apply returns at once (the value is then read on the device).
+ * When every stored value is finite and >= 0 (decided on the device, nnz >= 0 required) the scatter kernel sums in u64
+ * fixed point: the scores then do not depend on the order in which its LDS atomics arrive (bit-identical from run to run). */
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                               const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                               const void* alpha_div, double beta, void* S, int64_t lds, void* flags);

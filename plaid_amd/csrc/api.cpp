@@ -313,6 +313,17 @@ int plaidhip_init(int device, void* stream, plaidhip_ctx** out) {
     if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     ctx->own_stream = true;
   }
+  {
+    void* sel = nullptr;   // two doubles the sparse crossprod decides its accumulator format from (allocated here: a launch
+                           // inside a stream capture must not allocate)
+    hipError_t e = hipMalloc(&sel, 64);
+    if (e != hipSuccess) {
+      if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    }
+    ctx->d_sel = static_cast<double*>(sel);
+  }
   *out = ctx;
   return PLAIDHIP_OK;
 }
@@ -325,6 +336,7 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   ctx->gs_cache.clear();
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->rank_scratch) hipFree(ctx->rank_scratch);
+  if (ctx->d_sel) hipFree(ctx->d_sel);
   for (int k = 0; k < plaidhip_ctx::kHostBufs; ++k)
     if (ctx->hbuf[k]) hipFree(ctx->hbuf[k]);
   for (int t = 0; t < plaidhip_ctx::kFeeders; ++t) {

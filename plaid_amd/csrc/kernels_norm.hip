@@ -635,6 +635,35 @@ minmax_final_kernel(const double* __restrict__ part, int nb, double* out) {
   if (threadIdx.x == 0) { out[0] = omn; out[1] = omx; }
 }
 
+// {0 if every value is finite and >= 0, else -1; max}: what decides whether a sparse crossprod may sum in fixed point
+__global__ void __launch_bounds__(1024)
+nonneg_range_partial_kernel(const double* __restrict__ v, int64_t count, double* __restrict__ part) {
+  __shared__ double s_mn[1024], s_mx[1024];
+  double mn = 0.0, mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 1024) {
+    const double x = v[i];
+    const bool ok = (x >= 0.0) && (x < INFINITY);      // false for NaN, negatives and +inf
+    mn = ok ? mn : -1.0;
+    mx = x > mx ? x : mx;
+  }
+  double omn, omx;
+  block_minmax_1024(mn, mx, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) { part[blockIdx.x] = omn; part[gridDim.x + blockIdx.x] = omx; }
+}
+
+int launch_nonneg_range(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
+  int64_t nb64 = (count + 8 * 1024 - 1) / (8 * 1024);
+  const int cap = ctx->num_cu * 2;
+  const int nb = nb64 < 1 ? 1 : (nb64 > cap ? cap : (int)nb64);
+  int rc = ensure_workspace(ctx, (size_t)nb * 2 * sizeof(double));
+  if (rc != PLAIDHIP_OK) return rc;
+  double* part = reinterpret_cast<double*>(ctx->ws);
+  hipLaunchKernelGGL(nonneg_range_partial_kernel, dim3(nb), dim3(1024), 0, ctx->stream, v, count, part);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nb, out);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar) {
   if (count == 0) return PLAIDHIP_OK;
   int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);

@@ -704,6 +704,10 @@ struct ScatterArgs {
   const double* xmax_dev;
   double xmax_host;
   int32_t kbits;
+  // choice on the device between the fixed-point and the fp64 launch of the same call: sel[0] >= 0 <=> every stored value is
+  // finite and >= 0 (launch_nonneg_range); sel_want 1: run only then, 2: run only otherwise, 0: run
+  const double* sel;
+  int32_t sel_want;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
 };
 
@@ -739,6 +743,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* acc = reinterpret_cast<double*>(smem_raw);
   if (a.dense_cells != 0 && (int64_t)a.Xp[a.n] * 8 >= a.dense_cells) return;   // the gather kernel takes this input
+  if (a.sel_want != 0 && ((a.sel_want == 1) != (a.sel[0] >= 0.0))) return;      // the other accumulator format takes it
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
@@ -1074,10 +1079,17 @@ static int sparse_mode(const plaidhip_ctx* ctx) { return ctx->opt_sparse_kernel;
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
-                                bool auto_select, bool bounded, const double* xmax_dev, double xmax_host) {
+                                bool auto_select, bool bounded, const double* xmax_dev, double xmax_host, int64_t nnz) {
   const plaidhip_scatter_plan& sp = gs->scatter;
   ScatterArgs a{};
   const bool fixed = bounded && ctx->opt_scatter_fixed != 0;
+  // not declared bounded, but the stored values may still all be finite and >= 0 (expression values, counts): one sweep
+  // over them decides on the device, both launches are enqueued and the one that does not apply returns at once
+  const bool try_fixed = !bounded && ctx->opt_scatter_fixed != 0 && nnz > 0 && ctx->d_sel != nullptr;
+  if (try_fixed) {
+    const int rc = launch_nonneg_range(ctx, Xx, nnz, ctx->d_sel);
+    if (rc != PLAIDHIP_OK) return rc;
+  }
   a.chunk_major = ctx->opt_scatter_order;
   a.xmax_dev = xmax_dev;
   a.xmax_host = xmax_host;
@@ -1134,8 +1146,19 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > n) grid = n;
-  if (fixed) hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  else hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  if (fixed) {
+    hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (try_fixed) {
+    a.sel = ctx->d_sel;
+    a.sel_want = 1;
+    a.xmax_dev = ctx->d_sel + 1;
+    hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+    a.sel_want = 2;
+    a.xmax_dev = nullptr;
+    hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+  }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }
@@ -1925,7 +1948,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
     if (sm == 0 && nnz >= 0) sm = (nnz * 8 < (int64_t)gs->g * n) ? 1 : 2;
     if (sm != 2) {
       const int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0,
-                                                 bounded, xmax_dev, xmax_host);
+                                                 bounded, xmax_dev, xmax_host, nnz);
       if (rc != PLAIDHIP_OK || sm == 1) return rc;
     }
     return launch_colpair(ctx, gs, nullptr, 0, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, sm == 0);

@@ -852,6 +852,66 @@ def test_scatter_kernel_fixed_point_sums_are_reproducible_and_match_fp64(pinned_
     ctx.close()
 
 
+def test_scatter_kernel_picks_fixed_point_sums_for_nonnegative_values_on_the_device():
+    """plaidhip_dev_spmm_csc_f64 (plaid() on a dgCMatrix): nobody declares the values bounded, so a sweep over the stored
+    values decides on the device -- all finite and >= 0: u64 fixed-point accumulators (bit-identical between runs and item
+    orders, within 1e-13 of the fp64 sums); a negative value, a NaN or an Inf anywhere: fp64 accumulators, with IEEE
+    propagation where the oracle has it"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    from oracle import c_oracle
+    g, m, n = 20000, 9000, 400
+    Gp, Gi = sy.geneset_csc(g, m)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    assert Xx.min() >= 0.0
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    ctx.set_option("spmm_sparse_kernel", "scatter")
+
+    def run(xx, fixed, order):
+        ctx.set_option("scatter_fixed", fixed)
+        ctx.set_option("scatter_order", order)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        fl = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.dev_spmm_csc(gs, dp.data_ptr(), di.data_ptr(), xx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0, fl.data_ptr(),
+                         None, nnz=len(Xx))
+        return S, fl
+
+    with torch.cuda.stream(stream):
+        dp, di, dx = (torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (Xp.astype(np.int32), Xi.astype(np.int32), Xx))
+        a1, f1 = run(dx, "on", "chunk")
+        a2, _ = run(dx, "on", "chunk")
+        a3, _ = run(dx, "on", "column")
+        b1, _ = run(dx, "off", "chunk")
+        xneg = dx.clone(); xneg[7] = -1.25
+        c1, fneg = run(xneg, "on", "chunk")
+        c2, _ = run(xneg, "off", "chunk")
+        xnan = dx.clone(); xnan[11] = float("nan"); xnan[13] = float("inf")
+        d1, fnan = run(xnan, "on", "chunk")
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(a1, a3)                 # fixed point: no dependence on the arrival order
+    assert int(f1[3]) == 0 and int(fneg[3]) == 0 and int(fnan[3]) == 0
+    assert float((a1 - b1).abs().max()) < 1e-13
+    exp = c_oracle.crossprod_csc(Xp.astype(np.int32), Xi, Xx, g, Gp, Gi, "mean", threads=8)
+    np.testing.assert_allclose(a1.cpu().numpy().T, exp, rtol=0, atol=1e-13)
+    assert float((c1 - c2).abs().max()) < 1e-12                          # fp64 accumulators either way
+    xn = Xx.copy(); xn[7] = -1.25
+    np.testing.assert_allclose(c1.cpu().numpy().T, c_oracle.crossprod_csc(Xp.astype(np.int32), Xi, xn, g, Gp, Gi, "mean", threads=8),
+                               rtol=0, atol=1e-12)
+    xq = Xx.copy(); xq[11] = np.nan; xq[13] = np.inf
+    with np.errstate(all="ignore"):
+        expq = c_oracle.crossprod_csc(Xp.astype(np.int32), Xi, xq, g, Gp, Gi, "mean", threads=8)
+    got = d1.cpu().numpy().T
+    assert np.array_equal(np.isnan(got), np.isnan(expq)) and np.array_equal(np.isinf(got), np.isinf(expq))
+    ok = np.isfinite(expq)
+    np.testing.assert_allclose(got[ok], expq[ok], rtol=0, atol=1e-12)
+    gs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("rank_kernel", ["bucket", "network"])
 def test_c4_shape_ssgsea_and_sing_dense_fp64_50k_sets(pinned_ctx, g50k, rank_kernel):
     """config 4 per sample in the default fp64 mode: dense 20k-gene columns (the register-blocked network / the
