@@ -18,7 +18,7 @@ def run_case(ctx, seed):
     from oracle import plaid_oracle as po
     rng = np.random.default_rng(seed)
     out = []
-    g = int(rng.choice([7, 64, 300, 2049, 8193, 10224, 10225, 16001, 20352, 20353, 20448, 20449, 26000]))
+    g = int(rng.choice([7, 64, 300, 2049, 8193, 10224, 10225, 16001, 20352, 20353, 20448, 20449, 26000, 36601, 51000]))
     n = int(rng.integers(1, 9))
     m = int(rng.choice([1, 3, 64, 65, 200, 1500, 3000, 5000, 6100, 21000])) if g >= 2049 else int(rng.integers(1, 80))
     kmax = int(min(g, rng.choice([3, 40, 400])))
@@ -67,6 +67,20 @@ def run_case(ctx, seed):
                 Rs = ctx.colranks_csc(Xs.indptr, Xs.data, tm, False)
                 if not np.array_equal(Rs, po.sparse_colranks(Xs, ties_method=tm).data):
                     out.append(f"{tag}: SPARSE RANK MISMATCH ties={tm}")
+            # dense ranks of the sparse form (zeros ranked: from the ranks of the stored values, or densified when a
+            # column stores too many), signed or not; and replaid.sing on the CSC slots
+            sg = bool(rng.integers(0, 2))
+            Rd = ctx.colranks_csc_dense(Xs.indptr, Xs.indices, Xs.data, g, tm, sg)
+            if not np.array_equal(Rd, po.colranks(X, signed=sg, ties_method=tm)):
+                out.append(f"{tag}: DENSE-FROM-SPARSE RANK MISMATCH ties={tm} signed={sg}")
+            checks.append(("sing_csc", ctx.sing_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi), po.replaid_sing(X, rn, G, rn)))
+        # t(x) %*% y with per-entry weights (chunked_crossprod's general case), y dense and sparse
+        W = sp.csc_matrix((rng.normal(size=len(Gi)), Gi, Gp), shape=(g, m))
+        Y = np.nan_to_num(X, nan=0.5)
+        checks.append(("weighted_dense", ctx.crossprod_weighted(W.indptr, W.indices, W.data, g, Y=Y), po.chunked_crossprod(W, Y)))
+        Ys = sp.csc_matrix(Y)
+        checks.append(("weighted_csc", ctx.crossprod_weighted(W.indptr, W.indices, W.data, g, Yp=Ys.indptr, Yi=Ys.indices, Yx=Ys.data),
+                       po.chunked_crossprod(W, Ys)))
         S = rng.normal(0, 1, size=(m, n))
         S[rng.random(S.shape) < 0.1] = 0.0
         checks.append(("normalize_medians", ctx.normalize_medians(S.copy())[0], po.normalize_medians(S.copy())[0]))
