@@ -53,7 +53,7 @@ enum plaidhip_ignore_zero { /* R/plaid.R:554 `ignore.zero`: NULL / FALSE / TRUE 
 
 /* `flags` arguments are device arrays of 4 uint32 words set to 0/1 by the SpMM epilogue /
  * plaidhip_dev_minflags (the caller zeroes them first): [0] a value < 0 was seen, [1] an exact
- * zero, [2] a NaN, [3] reserved.  0/1 words so that a sample-sharded host can all-reduce(MAX)
+ * zero, [2] a NaN, [3] reserved (never written by the product library).  0/1 words so that a sample-sharded host can all-reduce(MAX)
  * them in place.  min(x, na.rm=TRUE) == 0  <=>  flags[1] && !flags[0]   (R/plaid.R:556-557).
  * The PLAIDHIP_FLAG_* bits are the in-kernel encoding (bit b <-> word b).                    */
 #define PLAIDHIP_FLAG_HAS_NEG 1u
@@ -100,6 +100,13 @@ enum plaidhip_option {
                                           time (chunk, column order) | 0 column after column                              */
 };
 int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value);
+/* Size limits of the kernels a host has to route by (so that no binding repeats them as literals).  Unknown `which`:
+ * PLAIDHIP_EINVAL.                                                                                                   */
+enum plaidhip_limit_id {
+  PLAIDHIP_LIMIT_SPARSE_RANK_COLUMN = 1, /* most stored values of a column plaidhip_dev_colranks_csc_dense_nz_f64 takes     */
+  PLAIDHIP_LIMIT_LDS_GENES = 2           /* most genes the one-slice LDS-resident crossprod kernels take (u16 rank staging) */
+};
+int plaidhip_limit(int which, int64_t* value);
 /* device memory helpers for hosts without a tensor library (R) */
 int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr);
 int plaidhip_free(plaidhip_ctx* ctx, void* dptr);
@@ -138,9 +145,11 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
  * is_signed = 0 (half-integers in [0.5, nrow(X)]), or such ranks after replaid.ucell's max - rank / pmin map: the rank
  * matrix of replaid.sing (R/plaid.R:215-217), replaid.ssgsea(alpha = 0) (:245-253), replaid.ucell (:277-279).  2 * rank
  * is staged as u16 (four sample columns per 8-byte LDS entry) and summed in integers: exact, order-independent and
- * bit-identical to plaidhip_dev_spmm_dense_f64 on the same input, at a quarter of its LDS bytes per score.  A value
- * whose double is >= 32,768 sets flags[3] (the scores are then meaningless); shapes the kernel does not take
- * (nrow(X) <= 8,192 or > 20,448) run the general kernels.                                                           */
+ * bit-identical to plaidhip_dev_spmm_dense_f64 on the same input, at a quarter of its LDS bytes per score.  The launch is
+ * speculative: a value that is not such a rank (NaN -- matrixStats::colRanks keeps NA --, +-Inf, a negative value, a double
+ * >= 32,768) is seen while staging, and the fp64 kernel enqueued right behind it on the same stream then recomputes the
+ * scores (it returns at once otherwise), so the result is plaidhip_dev_spmm_dense_f64's for ANY input, NaN propagation
+ * included.  Shapes the u16 kernel does not take (nrow(X) <= 8,192 or > 20,448) run the general kernels.             */
 int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,
                                 int64_t ldr, int32_t n, int stat, double alpha, const void* alpha_div,
                                 double beta, void* S, int64_t lds, void* flags);
@@ -148,18 +157,23 @@ int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
  * `nnz`: number of stored values of X when the caller knows it (Xp[n] on the host), else -1.  It picks
  * the kernel: sparse-aware scatter below 12.5 % stored values, column gather above; with -1 both are
  * enqueued and the one that does not apply returns at once (the value is then read on the device).
- * When every stored value is finite and >= 0 (decided on the device, nnz >= 0 required) the scatter kernel sums in u64
- * fixed point: the scores then do not depend on the order in which its LDS atomics arrive (bit-identical from run to run). */
+ * nnz is a hint only: what the kernels read is Xx[Xp[0] .. Xp[n]).
+ * The scatter kernel sums in u64 fixed point -- scores that do not depend on the order in which its LDS atomics arrive,
+ * bit-identical from run to run -- when a sweep over the stored values finds them all finite and >= 0 AND their dynamic
+ * range small enough for every score to stay within 2^-40 (9.1e-13) relative of the exact sum: each value is rounded once
+ * to a grid of 2^-(e+1) <= 2^-40 x (smallest stored value > 0).  Anything else (a negative, NaN or infinite value, raw
+ * counts next to values near 1, one huge outlier) takes fp64 atomics.  Decided on the device; both launches are enqueued. */
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                               const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                               const void* alpha_div, double beta, void* S, int64_t lds, void* flags);
 
 /* The sparse crossprod for RANK WEIGHTS: Rx is what plaidhip_dev_colranks_csc_f64 wrote (rank^power of the stored values,
  * so 0 <= Rx <= *rmax, rmax = their maximum on the device -- the max(rX) replaid.ssgsea divides by, R/plaid.R:251: alpha is
- * divided by it as by alpha_div).  Knowing the range, the scatter kernel sums in u64 fixed point: one rounding of each
- * weight to a grid finer than the last bit an fp64 sum keeps, exact integer sums, so the scores do not depend on the order
- * in which the LDS atomics arrive (plaidhip_dev_spmm_csc_f64's do, in their last bits).  A value outside [0, *rmax] sets
- * flags[3].  rmax is required.                                                                                       */
+ * divided by it as by alpha_div).  The fixed-point grid of the scatter kernel then follows *rmax -- the maximum over the
+ * WHOLE matrix, so every shard of a sharded call rounds alike and the scores do not depend on the sharding -- with the same
+ * device-side guard as plaidhip_dev_spmm_csc_f64: a stored value outside [0, *rmax], a NaN (the rank weight of a NaN
+ * input) or too wide a dynamic range takes the fp64 accumulators, which propagate it as the reference does.  rmax is
+ * required.                                                                                                          */
 int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                                     const void* Xi, const void* Rx, int32_t n, int64_t nnz, int stat, double alpha,
                                     const void* rmax, double beta, void* S, int64_t lds, void* flags);
@@ -320,10 +334,12 @@ int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, con
                     double auc_max_rank, double* S_out);
 /* replaid.scse(X, matG, removeLog2, scoreMean), R/plaid.R:155-190.  remove_log2: -1 = NULL (auto:
  * min(X) == 0 && max(X) < 20, :160-161), 0, 1.  score_mean: 0 -> sum statistic, x100 (:180-182);
- * 1 -> mean statistic divided by colMeans(|X|) (:175-177).                                   */
+ * 1 -> mean statistic divided by colMeans(|X|) (:175-177).  removed_log2 (may be NULL): set to 1
+ * when the 2**x transform ran -- the automatic decision is taken on the device; the host prints
+ * the reference's message from it (:164).                                                       */
 int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                  int remove_log2, int score_mean, double* S_out);
+                  int remove_log2, int score_mean, double* S_out, int* removed_log2);
 
 /* replaid.gsva(X, matG, tau, rowtf), R/plaid.R:338-363, dense X: row transform (rowtf = 0: "z",
  * center + scale per gene; 1: "ecdf", the per-gene empirical CDF), signed average ranks per sample,

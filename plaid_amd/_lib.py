@@ -81,6 +81,7 @@ SIGNATURES = {
     "plaidhip_ssgsea_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_ssgsea_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
     "plaidhip_shard_bounds": [_i64, _int, _int, C.POINTER(_i64), C.POINTER(_i64)],
+    "plaidhip_limit": [_int, C.POINTER(_i64)],
     "plaidhip_plaid_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
     "plaidhip_sing_multi": [_vp, _int, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "plaidhip_sing_csc_multi": [_vp, _int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
@@ -89,7 +90,7 @@ SIGNATURES = {
     "plaidhip_multi_set_precision": [_int],
     "plaidhip_ucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _f64, _vp],
     "plaidhip_aucell": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _vp],
-    "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
+    "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp, C.POINTER(_int)],
     "plaidhip_gsva": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _int, _vp],
     "plaidhip_plaid_test": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _int, _int, _vp],
     # host-only GMT text path (gmt.cpp)

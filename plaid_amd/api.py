@@ -280,11 +280,9 @@ def replaid_scse(X, matG, removeLog2=None, scoreMean=False, ctx: Context | None 
         _message("[plaid] ERROR. No overlapping features.")
         return None
     ctx = ctx or default_context()
-    if removeLog2 is None:
-        pass
-    elif removeLog2:
-        _message("[replaid.scse] Converting data to linear scale (removing log2)...")
     S = ctx.scse(X.values, pat[0], pat[1], removeLog2, scoreMean)
+    if ctx.last_scse_removed_log2:        # R/plaid.R:163-164 (removeLog2 = NULL is decided on the device, :160-161)
+        _message("[replaid.scse] Converting data to linear scale (removing log2)...")
     return NamedMatrix(S, matG.colnames, X.colnames)
 
 

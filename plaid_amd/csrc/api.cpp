@@ -316,16 +316,28 @@ int plaidhip_init(int device, void* stream, plaidhip_ctx** out) {
   {
     void* sel = nullptr;   // two doubles the sparse crossprod decides its accumulator format from (allocated here: a launch
                            // inside a stream capture must not allocate)
-    hipError_t e = hipMalloc(&sel, 64);
+    hipError_t e = hipMalloc(&sel, 128);
+    if (e == hipSuccess) e = hipMemset(sel, 0, 128);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       if (ctx->own_stream) hipStreamDestroy(ctx->stream);
       delete ctx;
       return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
     }
     ctx->d_sel = static_cast<double*>(sel);
+    ctx->d_spec = reinterpret_cast<uint32_t*>(static_cast<char*>(sel) + 64);
   }
   *out = ctx;
   return PLAIDHIP_OK;
+}
+
+int plaidhip_limit(int which, int64_t* value) {
+  PH_REQUIRE(value != nullptr, "limit: null value");
+  switch (which) {
+    case PLAIDHIP_LIMIT_SPARSE_RANK_COLUMN: *value = max_sparse_rank_column(); return PLAIDHIP_OK;
+    case PLAIDHIP_LIMIT_LDS_GENES: *value = kMaxLdsGenes; return PLAIDHIP_OK;
+    default: set_error("limit: unknown id %d", which); return PLAIDHIP_EINVAL;
+  }
 }
 
 int plaidhip_finalize(plaidhip_ctx* ctx) {
@@ -903,8 +915,9 @@ int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, con
 
 int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                  int remove_log2, int score_mean, double* S_out) {
+                  int remove_log2, int score_mean, double* S_out, int* removed_log2) {
   PH_CTX(ctx);
+  if (removed_log2 != nullptr) *removed_log2 = remove_log2 > 0 ? 1 : 0;
   PH_TRY(check_host_common(Gp, g, n, m));
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X_or_x && S_out, "scse: null X/S_out");
@@ -946,7 +959,15 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   PH_TRY(launch_affine(ctx, dS.as<double>(), m, m, n, score_mean ? 1.0 : 100.0, d_colsum,
                        score_mean ? 1.0 / (double)g : 1.0, nullptr, 0.0));
   PH_HIP(hipMemcpyAsync(S_out, dS.p, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  double mm[2] = {0.0, 0.0};
+  if (remove_log2 < 0 && removed_log2 != nullptr)
+    PH_HIP(hipMemcpyAsync(mm, d_mm, 16, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
+  if (remove_log2 < 0 && removed_log2 != nullptr) {   // what map_kernel decided from the same two numbers (:160-161)
+    double mn = mm[0], mx = mm[1];
+    if (sparse && nvals < (int64_t)g * n) { mn = mn < 0.0 ? mn : 0.0; mx = mx > 0.0 ? mx : 0.0; }
+    *removed_log2 = (mn == 0.0 && mx < 20.0) ? 1 : 0;
+  }
   return PLAIDHIP_OK;
 }
 

@@ -68,7 +68,9 @@ struct plaidhip_ctx {
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
   int opt_scatter_fixed = 1;   // scatter kernel: u64 fixed-point accumulators for inputs declared bounded (rank weights)
   int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
-  double* d_sel = nullptr;        // {0 or -1, max}: are the stored values of a sparse X all finite and >= 0 (scatter kernel's choice)
+  double* d_sel = nullptr;        // {0 or -1, max, smallest > 0} of the stored values of a sparse X (scatter kernel's choice of accumulators)
+  uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
+  uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
   void* rank_scratch = nullptr;   // value-partitioned ranking of columns beyond the LDS (kernels_rank.hip), grown on demand
   size_t rank_scratch_bytes = 0;
   int debug_fail_crossprod = 0;   // test hook (plaidhip_debug_sharded_on_one_device): this context's shard fails in the crossprod phase
@@ -241,7 +243,7 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
                                 bool auto_select, bool bounded = false, const double* xmax_dev = nullptr, double xmax_host = 0.0,
                                 int64_t nnz = -1);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)
-int launch_nonneg_range(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
+int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, int64_t nnz_hint, double* out);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz /* -1: unknown */, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,

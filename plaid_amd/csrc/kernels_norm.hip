@@ -447,8 +447,10 @@ col_medians_sample_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
       };
       uint64_t v1 = 0, v2 = 0;
       const bool ok1 = resolve(k_lo, v1), ok2 = resolve(k_hi, v2);
-      if ((!ok1 || !ok2) && tid == 0 && flags != nullptr)   // flags[3] (reserved word) counts bracket misses
+#ifdef PLAIDHIP_DIAG
+      if ((!ok1 || !ok2) && tid == 0 && flags != nullptr)   // tools/ build only: flags[3] counts bracket misses
         atomicAdd(const_cast<uint32_t*>(&flags[3]), 1u);
+#endif
       if (!ok1) v1 = radix_select_global(sc, m, ignore_zero, k_lo, hist, hist + 256);   // rare
       if (!ok2) v2 = (k_hi == k_lo) ? v1 : radix_select_global(sc, m, ignore_zero, k_hi, hist, hist + 256);
       r = (v1 == v2) ? key_to_f64(v1) : 0.5 * (key_to_f64(v1) + key_to_f64(v2));
@@ -635,31 +637,58 @@ minmax_final_kernel(const double* __restrict__ part, int nb, double* out) {
   if (threadIdx.x == 0) { out[0] = omn; out[1] = omx; }
 }
 
-// {0 if every value is finite and >= 0, else -1; max}: what decides whether a sparse crossprod may sum in fixed point
+// {0 if every stored value is finite and >= 0, else -1; max; smallest value > 0 (+inf if there is none)} over the stored
+// values Xx[Xp[0] .. Xp[n]) of a dgCMatrix -- the range is read from Xp ON THE DEVICE, so a caller that does not know
+// nnz(X) (or knows it only approximately: a shard of a larger matrix) cannot make the sweep read too much or too little.
+// It decides whether the scatter crossprod may sum in fixed point (kernels_spmm.hip: scatter_fixed_ok).
 __global__ void __launch_bounds__(1024)
-nonneg_range_partial_kernel(const double* __restrict__ v, int64_t count, double* __restrict__ part) {
+nonneg_range_partial_kernel(const double* __restrict__ v, const int32_t* __restrict__ Xp, int32_t n,
+                            double* __restrict__ part) {
   __shared__ double s_mn[1024], s_mx[1024];
-  double mn = 0.0, mx = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 1024) {
+  const int64_t begin = Xp[0], end = Xp[n];
+  double ok = 0.0, mx = 0.0, mnz = INFINITY;
+  for (int64_t i = begin + (int64_t)blockIdx.x * 1024 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 1024) {
     const double x = v[i];
-    const bool ok = (x >= 0.0) && (x < INFINITY);      // false for NaN, negatives and +inf
-    mn = ok ? mn : -1.0;
+    ok = ((x >= 0.0) && (x < INFINITY)) ? ok : -1.0;      // false for NaN, negatives and +inf
     mx = x > mx ? x : mx;
+    mnz = (x > 0.0 && x < mnz) ? x : mnz;
   }
   double omn, omx;
-  block_minmax_1024(mn, mx, s_mn, s_mx, omn, omx);
+  block_minmax_1024(ok, mx, s_mn, s_mx, omn, omx);
   if (threadIdx.x == 0) { part[blockIdx.x] = omn; part[gridDim.x + blockIdx.x] = omx; }
+  __syncthreads();
+  block_minmax_1024(mnz, 0.0, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) part[2 * gridDim.x + blockIdx.x] = omn;
 }
 
-int launch_nonneg_range(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
-  int64_t nb64 = (count + 8 * 1024 - 1) / (8 * 1024);
+__global__ void __launch_bounds__(1024)
+nonneg_range_final_kernel(const double* __restrict__ part, int nb, double* out) {
+  __shared__ double s_mn[1024], s_mx[1024];
+  double ok = 0.0, mx = 0.0, mnz = INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    const double a = part[i], b = part[nb + i], c = part[2 * nb + i];
+    ok = a < ok ? a : ok;
+    mx = b > mx ? b : mx;
+    mnz = c < mnz ? c : mnz;
+  }
+  double omn, omx;
+  block_minmax_1024(ok, mx, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) { out[0] = omn; out[1] = omx; }
+  __syncthreads();
+  block_minmax_1024(mnz, 0.0, s_mn, s_mx, omn, omx);
+  if (threadIdx.x == 0) out[2] = omn;
+}
+
+// nnz_hint only sizes the grid (< 0: unknown); the swept range is Xx[Xp[0] .. Xp[n]) whatever it says
+int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, int64_t nnz_hint, double* out) {
   const int cap = ctx->num_cu * 2;
+  int64_t nb64 = nnz_hint < 0 ? cap : (nnz_hint + 8 * 1024 - 1) / (8 * 1024);
   const int nb = nb64 < 1 ? 1 : (nb64 > cap ? cap : (int)nb64);
-  int rc = ensure_workspace(ctx, (size_t)nb * 2 * sizeof(double));
+  int rc = ensure_workspace(ctx, (size_t)nb * 3 * sizeof(double));
   if (rc != PLAIDHIP_OK) return rc;
   double* part = reinterpret_cast<double*>(ctx->ws);
-  hipLaunchKernelGGL(nonneg_range_partial_kernel, dim3(nb), dim3(1024), 0, ctx->stream, v, count, part);
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nb, out);
+  hipLaunchKernelGGL(nonneg_range_partial_kernel, dim3(nb), dim3(1024), 0, ctx->stream, Xx, Xp, n, part);
+  hipLaunchKernelGGL(nonneg_range_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nb, out);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }

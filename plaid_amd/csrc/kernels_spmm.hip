@@ -66,8 +66,34 @@ struct SpmmArgs {
   double* S;
   int64_t lds;
   uint32_t* flags;
+  // speculative launch + guarded fallback (see spec_guard): the u16 quad kernel is exact only for rank inputs, so it
+  // publishes its flag words to spec[1..3] and stores spec_gen in spec[0] when it staged a value that is not a rank
+  // (NaN / Inf / negative / fractional part other than .5 is impossible to see, but 2x >= 2^16 is); the fp64 launch
+  // enqueued behind it runs only then.  null: unconditional launch.
+  uint32_t* spec;
+  uint32_t spec_gen;
   unsigned long long* dbg;   // ABLATE==4 only: per (workgroup, wave) {stage, gather, tail-wait, total} cycles
 };
+
+// Fallback side of a speculative launch (the kernel enqueued right behind it on the same stream).  Returns true when this
+// launch has nothing to do: the speculative kernel's input was what it assumed -- its private flag words are merged into
+// the caller's (one thread) and the launch returns at once.  Otherwise the private words are dropped (the speculative
+// scores are overwritten by this launch, which publishes its own flags).
+__device__ __forceinline__ bool spec_guard(uint32_t* spec, uint32_t gen, uint32_t* flags) {
+  if (spec == nullptr) return false;
+  const bool bad = __hip_atomic_load(&spec[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const uint32_t w = __hip_atomic_load(&spec[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w != 0u) {
+        if (!bad && flags != nullptr) __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&spec[1 + b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  return !bad;
+}
 
 __device__ __forceinline__ void publish_flags(uint32_t f, uint32_t* flags) {
   // flags[0..2] = has_neg / has_zero / has_nan as 0/1 words (element-wise MAX all-reducible).
@@ -117,6 +143,7 @@ __device__ __forceinline__ double lds_at(uint32_t byte_off) {
 template <bool CSC_X, int BLOCK, int ABLATE = 0>
 __global__ void __launch_bounds__(BLOCK)
 spmm_colgather_f64(SpmmArgs a) {
+  if (spec_guard(a.spec, a.spec_gen, a.flags)) return;
   // f64x2 registers per thread holding the prefetched next column
   constexpr int ITEMS2 = (BLOCK == 1024) ? 10 : (BLOCK == 512 ? 20 : 4);
   static_assert(BLOCK * ITEMS2 * 2 >= (BLOCK == 256 ? 2048 : kMaxLdsGenes), "prefetch span");
@@ -385,6 +412,8 @@ struct SpmmPairArgs {
   double* S;
   int64_t lds;
   uint32_t* flags;
+  uint32_t* spec;            // guarded fallback of a speculative launch (SpmmArgs::spec), null: unconditional
+  uint32_t spec_gen;
   unsigned long long* dbg;   // STAMP only
 };
 
@@ -408,8 +437,9 @@ template <bool STAMP, int ABL = 0, bool CSC_X = false>
 __global__ void __launch_bounds__(1024)
 spmm_colpair_f64(SpmmPairArgs a) {
   constexpr int BLOCK = 1024;
+  if (spec_guard(a.spec, a.spec_gen, a.flags)) return;
   if constexpr (CSC_X) {
-    if (a.sparse_cells != 0 && (int64_t)a.Xp[a.n] * 8 < a.sparse_cells) return;
+    if (a.sparse_cells != 0 && ((int64_t)a.Xp[a.n] - a.Xp[0]) * 8 < a.sparse_cells) return;
   }
   unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
   if constexpr (STAMP) t_all0 = __builtin_amdgcn_s_memtime();
@@ -699,13 +729,15 @@ struct ScatterArgs {
   uint32_t* flags;
   int32_t chunk_major;       // item order: 0 (column, chunk, round) | 1 (chunk, column, round): every workgroup is on the
                              // same chunk of sets at the same time, so the id lists in use are one chunk's (a third of them)
-  // FIXED (u64 fixed-point accumulators, for inputs known to lie in [0, xmax]: rank weights): xmax on the device
-  // (the max(rX) the caller also divides by) or, when null, on the host; kbits = bits of the largest set size
+  // Choice ON THE DEVICE between the fixed-point (FIXED) and the fp64 launch of the same call (scatter_fixed_ok): both are
+  // enqueued, the one that does not apply returns at once.  sel = {0 or -1, max, smallest value > 0} of the stored values
+  // (launch_nonneg_range, swept right before); sel_want 1: run only if fixed point applies, 2: only otherwise, 0: run (fp64).
+  // bounded: the caller declares the values to lie in [0, xmax] (rank weights; xmax = max(rX) of the WHOLE matrix, on the
+  // device or, when xmax_dev is null, on the host) -- the grid then follows that xmax, the same for every shard of a call;
+  // otherwise it follows the swept maximum.  kbits = bits of the largest set size.
   const double* xmax_dev;
   double xmax_host;
-  int32_t kbits;
-  // choice on the device between the fixed-point and the fp64 launch of the same call: sel[0] >= 0 <=> every stored value is
-  // finite and >= 0 (launch_nonneg_range); sel_want 1: run only then, 2: run only otherwise, 0: run
+  int32_t kbits, bounded;
   const double* sel;
   int32_t sel_want;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
@@ -732,18 +764,46 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 }
 
 // FIXED: the accumulators are u64 fixed-point numbers (ds_add_u64: 6.0 cycles per wave-instruction against 8.05 for
-// ds_add_f64, tools/ubench/lds_atomics.hip).  For inputs in [0, xmax] -- the rank weights rank^(1 + alpha) of
-// replaid.ssgsea, xmax = max(rX) -- the scale 2^e is chosen so that the largest possible sum (the largest set size x xmax)
-// stays below 2^63; a value is rounded ONCE to that grid (2^-e is at most half an ulp of xmax / 2^(kbits): finer than the
-// last bit the fp64 sum would keep), the integer sums are exact, so the score does not depend on the order in which the
-// LDS atomics arrive: bit-reproducible from run to run, which the fp64 atomics are not.
+// ds_add_f64, tools/ubench/lds_atomics.hip).  For stored values in [0, xmax] the scale 2^e is chosen so that the largest
+// possible sum (the largest set size x xmax) stays below 2^63; every value is rounded ONCE to that grid, the integer sums
+// are exact, so a score does not depend on the order in which the LDS atomics arrive: bit-reproducible from run to run,
+// which the fp64 atomics are not.
+// What the rounding costs, rigorously: a stored value v > 0 moves by at most 2^-(e+1) and contributes at least
+// min_nz = the smallest stored value > 0 to any sum it is part of (all terms are >= 0), so EVERY score is within
+// 2^-(e+1) / min_nz relative of the exact sum.  Fixed point is used only when that bound is <= 2^-40 (9.1e-13), i.e. when
+// the dynamic range xmax / min_nz of the input is below ~2^(23 - kbits); raw counts next to values near 1, one huge outlier,
+// xmax >= 2^1000, a negative, NaN or infinite stored value, or (bounded callers) a value above the declared xmax all take
+// the fp64 accumulators instead.  The predicate is evaluated on the device by both launches of a call (one of them
+// returns at once); nothing about it is left to the caller.
+__device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded, const double* xmax_dev, double xmax_host,
+                                                 int kbits, int& e_out, double& xmax_out) {
+  const double seen_ok = sel[0], seen_max = sel[1], min_nz = sel[2];
+  const double xmax = bounded ? ((xmax_dev != nullptr) ? *xmax_dev : xmax_host) : seen_max;
+  bool ok = seen_ok >= 0.0 && xmax >= 0.0 && xmax < 0x1p1000 && seen_max <= xmax;   // (false for a NaN xmax)
+  int q = 0;
+  if (xmax > 0.0 && xmax < 0x1p1000) (void)frexp(xmax, &q);     // xmax < 2^q
+  const int e = 63 - q - kbits;
+  if (min_nz < INFINITY) {
+    int qm = 0;
+    (void)frexp(min_nz, &qm);                                    // min_nz >= 2^(qm - 1)
+    ok = ok && (qm - 1 + e + 1 >= 40);                           // 2^-(e+1) / min_nz <= 2^-40
+  }
+  e_out = e;
+  xmax_out = xmax;
+  return ok;
+}
 template <bool FIXED>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
 spmm_scatter_csc_f64(ScatterArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* acc = reinterpret_cast<double*>(smem_raw);
-  if (a.dense_cells != 0 && (int64_t)a.Xp[a.n] * 8 >= a.dense_cells) return;   // the gather kernel takes this input
-  if (a.sel_want != 0 && ((a.sel_want == 1) != (a.sel[0] >= 0.0))) return;      // the other accumulator format takes it
+  if (a.dense_cells != 0 && ((int64_t)a.Xp[a.n] - a.Xp[0]) * 8 >= a.dense_cells) return;   // the gather kernel takes this input
+  int fx_e = 0;
+  double fx_xmax = 0.0;
+  if (a.sel_want != 0) {   // the other accumulator format takes it
+    const bool fixed_ok = scatter_fixed_ok(a.sel, a.bounded, a.xmax_dev, a.xmax_host, a.kbits, fx_e, fx_xmax);
+    if ((a.sel_want == 1) != fixed_ok) return;
+  }
   {
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     if ((uint32_t)(uintptr_t)((lds_u8*)smem_raw) != 0u) __builtin_trap();
@@ -754,15 +814,10 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   uint32_t f = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  double fx_scale = 1.0, fx_inv = 1.0, fx_max = 0.0;
-  uint32_t fx_bad = 0;
-  if constexpr (FIXED) {
-    fx_max = (a.xmax_dev != nullptr) ? *a.xmax_dev : a.xmax_host;
-    int q = 0;
-    if (fx_max > 0.0 && fx_max < 1e300) (void)frexp(fx_max, &q);     // xmax < 2^q
-    const int e = 63 - q - a.kbits;
-    fx_scale = ldexp(1.0, e);
-    fx_inv = ldexp(1.0, -e);
+  double fx_scale = 1.0, fx_inv = 1.0;
+  if constexpr (FIXED) {   // (only ever launched with sel_want == 1: every stored value lies in [0, xmax] and is finite)
+    fx_scale = ldexp(1.0, fx_e);
+    fx_inv = ldexp(1.0, -fx_e);
   }
   for (int i = tid; i < a.ch + kScatterTrash; i += 1024) acc[i] = 0.0;   // (all-zero bits: 0 in either number format)
   __syncthreads();
@@ -1004,10 +1059,8 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     (void)qi_cur;
     const int ns = have ? s1 - s0 : 0;
     if (!have) v = 0.0;
-    if constexpr (FIXED) {   // one rounding to the fixed-point grid; values outside [0, xmax] (or NaN) are not rank weights
-      fx_bad |= (v >= 0.0 && v <= fx_max) ? 0u : 1u;
+    if constexpr (FIXED)   // one rounding to the fixed-point grid
       v = __longlong_as_double((long long)__double2ull_rn(v * fx_scale));
-    }
     const bool n1_loads = c1 < a.n, n2_loads = c2 < a.n && q12 > q02;
     // requests for the items behind this one (before the walk's own loads: vmcnt retires in order)
     if (n1_loads) PLAIDHIP_ASM_LOAD_SEG(a.seg + (int64_t)chunk1 * a.g + gene1);
@@ -1059,11 +1112,6 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_WALK_SEGMENTS
 #undef PLAIDHIP_CHUNK_EPILOGUE
 #undef PLAIDHIP_EPI_PREFETCH
-  if constexpr (FIXED) {   // an input outside [0, xmax]: the scores are meaningless, say so (flags[3])
-    for (int off = 32; off >= 1; off >>= 1) fx_bad |= __shfl_xor(fx_bad, off, 64);
-    if (a.flags != nullptr && lane == 0 && fx_bad != 0u)
-      __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   publish_flags(f, a.flags);
 #undef PLAIDHIP_ADD_AT
 #undef PLAIDHIP_SCATTER2
@@ -1082,18 +1130,21 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
                                 bool auto_select, bool bounded, const double* xmax_dev, double xmax_host, int64_t nnz) {
   const plaidhip_scatter_plan& sp = gs->scatter;
   ScatterArgs a{};
-  const bool fixed = bounded && ctx->opt_scatter_fixed != 0;
-  // not declared bounded, but the stored values may still all be finite and >= 0 (expression values, counts): one sweep
-  // over them decides on the device, both launches are enqueued and the one that does not apply returns at once
-  const bool try_fixed = !bounded && ctx->opt_scatter_fixed != 0 && nnz > 0 && ctx->d_sel != nullptr;
+  // One sweep over the stored values ({all finite and >= 0, max, smallest > 0}; its range comes from Xp on the device, `nnz`
+  // only sizes its grid) decides ON THE DEVICE between the fixed-point and the fp64 accumulators (scatter_fixed_ok): both
+  // launches are enqueued and the one that does not apply returns at once.  Callers that declare the values bounded (rank
+  // weights) get the grid of THEIR xmax -- the same on every shard of a sharded call -- but the sweep still decides
+  // whether fixed point is safe (a NaN rank weight, e.g., takes the fp64 kernel and propagates as in the reference).
+  const bool try_fixed = ctx->opt_scatter_fixed != 0 && ctx->d_sel != nullptr;
   if (try_fixed) {
-    const int rc = launch_nonneg_range(ctx, Xx, nnz, ctx->d_sel);
+    const int rc = launch_nonneg_range(ctx, Xx, Xp, n, nnz, ctx->d_sel);
     if (rc != PLAIDHIP_OK) return rc;
   }
   a.chunk_major = ctx->opt_scatter_order;
   a.xmax_dev = xmax_dev;
   a.xmax_host = xmax_host;
   a.kbits = sp.kbits;
+  a.bounded = bounded ? 1 : 0;
   a.Xp = Xp;
   a.Xi = Xi;
   a.Xx = Xx;
@@ -1146,15 +1197,11 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > n) grid = n;
-  if (fixed) {
-    hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (try_fixed) {
+  if (try_fixed) {
     a.sel = ctx->d_sel;
     a.sel_want = 1;
-    a.xmax_dev = ctx->d_sel + 1;
     hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
     a.sel_want = 2;
-    a.xmax_dev = nullptr;
     hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   } else {
     hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
@@ -1428,7 +1475,12 @@ __device__ __forceinline__ uint32_t add_hi16(uint32_t acc, uint32_t v) {   // ac
   asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(acc), "v"(v));
   return r;
 }
-__device__ __forceinline__ uint32_t twice_as_u32(double x) { return (uint32_t)__double2loint(x + 0x1p51); }
+// (the high word of x + 2^51 is 0x43200000 exactly when 0 <= x < 2^31: NaN, +-Inf, negatives and huge values differ)
+__device__ __forceinline__ uint32_t twice_as_u32(double x, uint32_t& not_a_rank) {
+  const double y = x + 0x1p51;
+  not_a_rank |= (uint32_t)__double2hiint(y) ^ 0x43200000u;
+  return (uint32_t)__double2loint(y);
+}
 
 struct SpmmQuadArgs {
   SpmmArgs s;
@@ -1450,7 +1502,7 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t f = 0, chk = 0;
+  uint32_t f = 0, chk = 0, chkh = 0;
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
   const int ch_begin = ((cptr_i32)a.wave_chunk_off)[wave];
@@ -1487,8 +1539,8 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
   if (k * BLOCK < g2) {                                                                                              \
     const int i_ = tid_o + k * BLOCK;                                                                                \
     if (i_ < g2) {                                                                                                   \
-      const uint32_t a0_ = twice_as_u32(ra.x), b0_ = twice_as_u32(rb.x), c0v_ = twice_as_u32(rc.x), d0_ = twice_as_u32(rd.x); \
-      const uint32_t a1_ = twice_as_u32(ra.y), b1_ = twice_as_u32(rb.y), c1v_ = twice_as_u32(rc.y), d1_ = twice_as_u32(rd.y); \
+      const uint32_t a0_ = twice_as_u32(ra.x, chkh), b0_ = twice_as_u32(rb.x, chkh), c0v_ = twice_as_u32(rc.x, chkh), d0_ = twice_as_u32(rd.x, chkh); \
+      const uint32_t a1_ = twice_as_u32(ra.y, chkh), b1_ = twice_as_u32(rb.y, chkh), c1v_ = twice_as_u32(rc.y, chkh), d1_ = twice_as_u32(rd.y, chkh); \
       chk |= (a0_ | b0_) | (c0v_ | d0_) | (a1_ | b1_) | (c1v_ | d1_);                                                \
       ent4[i_] = u32x4{a0_ | (b0_ << 16), c0v_ | (d0_ << 16), a1_ | (b1_ << 16), c1v_ | (d1_ << 16)};                \
     }                                                                                                                \
@@ -1533,8 +1585,8 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
         PLAIDHIP_ST_F64(9, pa3, pb3, pc3, pd3)
         if ((a.g & 1) && tid_o == 0) {
           const int64_t gl = a.g - 1;
-          const uint32_t va = twice_as_u32(reinterpret_cast<const double*>(xa_)[gl]), vb = twice_as_u32(reinterpret_cast<const double*>(xb_)[gl]);
-          const uint32_t vc = twice_as_u32(reinterpret_cast<const double*>(xc_)[gl]), vd = twice_as_u32(reinterpret_cast<const double*>(xd_)[gl]);
+          const uint32_t va = twice_as_u32(reinterpret_cast<const double*>(xa_)[gl], chkh), vb = twice_as_u32(reinterpret_cast<const double*>(xb_)[gl], chkh);
+          const uint32_t vc = twice_as_u32(reinterpret_cast<const double*>(xc_)[gl], chkh), vd = twice_as_u32(reinterpret_cast<const double*>(xd_)[gl], chkh);
           chk |= (va | vb) | (vc | vd);
           ent[gl] = u32x2{va | (vb << 16), vc | (vd << 16)};
         }
@@ -1678,11 +1730,12 @@ spmm_colquad_u16(SpmmQuadArgs qa_) {
       d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
     }
   }
-  // a value that is not a rank (2x does not fit 16 bits) was staged: the scores are wrong, say so (flags[3])
+  // a value that is not a rank was staged (2x does not fit 16 bits, NaN, +-Inf, negative): these scores are wrong, and the
+  // fp64 launch enqueued behind this one replaces them (spec_guard); the flag words of this launch go to spec[1..3]
+  chk = (chk >> 16) | chkh;
   for (int off = 32; off >= 1; off >>= 1) chk |= __shfl_xor(chk, off, 64);
-  if (a.flags != nullptr && lane == 0 && (chk >> 16) != 0u)
-    __hip_atomic_store(&a.flags[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  publish_flags(f, a.flags);
+  if (lane == 0 && chk != 0u) __hip_atomic_store(&a.spec[0], a.spec_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  publish_flags(f, a.spec + 1);
 #undef PLAIDHIP_PREFETCH
 #undef PLAIDHIP_QCOLS
 #undef PLAIDHIP_LD_F64
@@ -1737,7 +1790,7 @@ static int pair_kernel_mode(const plaidhip_ctx* ctx) {
 static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx,
                           const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t n,
                           int stat, double alpha, const double* alpha_div, double beta, double* S, int64_t lds,
-                          uint32_t* flags, bool auto_select = false) {
+                          uint32_t* flags, bool auto_select = false, uint32_t* spec = nullptr, uint32_t spec_gen = 0) {
   const plaidhip_pair_plan& pl = gs->pair;
   int32_t gmax = 0;
   for (const plaidhip_pair_slice& sl : pl.slices) gmax = sl.gs > gmax ? sl.gs : gmax;
@@ -1768,6 +1821,8 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.S = S;
   a.lds = lds;
   a.flags = flags;
+  a.spec = spec;
+  a.spec_gen = spec_gen;
   int per_cu = (int)(kLdsBytes / smem);
   if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
@@ -1905,15 +1960,25 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   // (the 16-byte loads {x[2i], x[2i+1]} of these kernels need no 16-byte alignment: global memory takes dword-aligned
   //  dwordx4 accesses, so an odd leading dimension -- every other column 8 bytes off -- runs the same kernels)
   const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16 && (g_ablate == 0 || g_ablate == 4);
-  if (x_kind == PLAIDHIP_X_RANKS && ctx->opt_ranks_f32 >= 2 && one_slice_16) {
+  uint32_t* spec = nullptr;
+  uint32_t spec_gen = 0;
+  if (x_kind == PLAIDHIP_X_RANKS && ctx->opt_ranks_f32 >= 2 && one_slice_16 && ctx->d_spec != nullptr) {
+    // speculative: exact and bit-identical to the fp64 kernels IF every value is a rank.  A value that is not (NaN ranks
+    // of NaN inputs, matrixStats keeps NA; anything a device-API caller passes) is seen while staging, and the fp64
+    // kernel enqueued right behind then recomputes the scores -- it returns at once otherwise (spec_guard).
     SpmmArgs a{};
     a.X = X;
     a.ldx = ldx;
     fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
-    return launch_colquad(ctx, gs, a);
+    if (++ctx->spec_gen == 0u) ctx->spec_gen = 1u;
+    a.spec = spec = ctx->d_spec;
+    a.spec_gen = spec_gen = ctx->spec_gen;
+    const int rc = launch_colquad(ctx, gs, a);
+    if (rc != PLAIDHIP_OK) return rc;
+    x_kind = PLAIDHIP_X_ANY;   // (the fallback is the plain fp64 route)
   }
   const bool x_exact_in_f32 = x_kind != PLAIDHIP_X_ANY && ctx->opt_ranks_f32 >= 1;
-  if ((ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && one_slice_16) {
+  if (spec == nullptr && (ctx->precision == PLAIDHIP_PRECISION_MIXED || x_exact_in_f32) && one_slice_16) {
     // fp32 operand staging; one gene slice and the 1024-thread schedule only
     SpmmArgs a{};
     a.X = X;
@@ -1926,12 +1991,15 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     const int mode = pair_kernel_mode(ctx);
     const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6 || g_ablate == 7;
     if (diag && mode != 0 && !gs->pair.slices.empty())
-      return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags);
+      return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags, false,
+                            spec, spec_gen);
   }
   SpmmArgs a{};
   a.X = X;
   a.ldx = ldx;
   fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
+  a.spec = spec;
+  a.spec_gen = spec_gen;
   return launch_colgather<false>(ctx, gs, a);
 }
 

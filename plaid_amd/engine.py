@@ -93,6 +93,12 @@ class Context:
         code, values = _lib.OPTIONS[name]
         check(self.lib.plaidhip_set_option(self.handle, code, values[value] if isinstance(value, str) else int(value)))
 
+    def limit(self, name: str) -> int:
+        """size limits a host routes by (plaidhip_limit): "sparse_rank_column", "lds_genes" """
+        v = C.c_int64(0)
+        check(self.lib.plaidhip_limit({"sparse_rank_column": 1, "lds_genes": 2}[name], C.byref(v)))
+        return int(v.value)
+
     def close(self):
         if self.handle:
             self.lib.plaidhip_finalize(self.handle)
@@ -351,8 +357,10 @@ def _scse(self, X, Gp, Gi, remove_log2=None, score_mean=False):
     m = len(Gp) - 1
     S = np.empty((m, n), dtype=np.float64, order="F")
     rl = -1 if remove_log2 is None else int(bool(remove_log2))
+    removed = C.c_int(0)
     check(self.lib.plaidhip_scse(self.handle, xp, xi, xv, g, n, _np_ptr(Gp), _np_ptr(Gi), m, rl,
-                                 int(bool(score_mean)), _np_ptr(S)))
+                                 int(bool(score_mean)), _np_ptr(S), C.byref(removed)))
+    self.last_scse_removed_log2 = bool(removed.value)   # the automatic decision is taken on the device (R/plaid.R:160-161)
     return S
 
 

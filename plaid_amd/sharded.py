@@ -121,7 +121,7 @@ class HipPhaseEngine:
         if n == 0:
             return R
         p = X.p[lo:hi + 1]
-        if X.max_col_nnz <= 20352:
+        if X.max_col_nnz <= self.ctx.limit("sparse_rank_column"):
             Rx = t.empty(max(X.nnz, 1), dtype=t.float64, device=self.device)
             self.ctx.dev_colranks_csc_dense_nz(p.data_ptr(), X.i.data_ptr(), X.x.data_ptr(), X.g, n, X.max_col_nnz,
                                                Rx.data_ptr(), R.data_ptr(), ld, ties, signed, power)

@@ -245,6 +245,9 @@ replaid.scse <- function(X, matG, removeLog2 = NULL, scoreMean = FALSE) {
   S <- .Call("R_plaidhip_scse", xa[[1]], xa[[2]], xa[[3]], nrow(X), ncol(X), pat$Gp, pat$Gi,
              if (is.null(removeLog2)) NA else as.logical(removeLog2), as.logical(scoreMean),
              PACKAGE = "plaidhip")
+  if (isTRUE(attr(S, "removedLog2")))   ## R/plaid.R:163-164 (the NULL case is decided on the device)
+    message("[replaid.scse] Converting data to linear scale (removing log2)...")
+  attr(S, "removedLog2") <- NULL
   dimnames(S) <- list(colnames(matG), colnames(X))
   S
 }

@@ -216,8 +216,11 @@ SEXP R_plaidhip_scse(SEXP Xp, SEXP Xi, SEXP Xv, SEXP g, SEXP n, SEXP Gp, SEXP Gi
   const int m = LENGTH(Gp) - 1, nn = Rf_asInteger(n);
   const int rl = Rf_asLogical(remove_log2);
   SEXP S = PROTECT(Rf_allocMatrix(REALSXP, m, nn));
+  int removed = 0;
   check(plaidhip_scse(ctx(), int_or_null(Xp), int_or_null(Xi), REAL(Xv), Rf_asInteger(g), nn, INTEGER(Gp),
-                      INTEGER(Gi), m, rl == NA_LOGICAL ? -1 : rl, Rf_asLogical(score_mean), REAL(S)));
+                      INTEGER(Gi), m, rl == NA_LOGICAL ? -1 : rl, Rf_asLogical(score_mean), REAL(S), &removed));
+  /* whether 2**x ran (decided on the device when removeLog2 = NULL): the R wrapper prints R/plaid.R:164's message */
+  Rf_setAttrib(S, Rf_install("removedLog2"), Rf_ScalarLogical(removed));
   UNPROTECT(1);
   return S;
 }

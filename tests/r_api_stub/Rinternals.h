@@ -47,6 +47,9 @@ Rboolean Rf_isNull(SEXP);
 SEXP Rf_allocVector(SEXPTYPE, R_xlen_t);
 SEXP Rf_allocMatrix(SEXPTYPE, int, int);
 SEXP Rf_duplicate(SEXP);
+SEXP Rf_ScalarLogical(int);
+SEXP Rf_install(const char*);
+SEXP Rf_setAttrib(SEXP, SEXP, SEXP);
 SEXP Rf_mkCharLenCE(const char*, int, cetype_t);
 const char* Rf_translateCharUTF8(SEXP);
 #if defined(__GNUC__)

@@ -518,6 +518,44 @@ def test_plaid_test_fixture_matches_oracle_and_vignette(pbmc, golden_dir, metap)
         assert res2.rownames[:6] == list(kat)
         for k, nm in enumerate(kat):
             np.testing.assert_allclose(res2.values[k, 1:4], kat[nm], rtol=2e-6)
+        # html:864-869: q.meta (BH over the 50 sets, R/plaid.R:463), incl. the tied pair
+        np.testing.assert_allclose(res2.values[:6, 4], [1.934024e-05, 1.195384e-03, 1.394918e-03, 1.864818e-02,
+                                                        3.032190e-02, 3.032190e-02], rtol=2e-6)
+        assert res2.values[4, 4] == res2.values[5, 4]
+
+
+def test_scse_on_the_fixture_takes_the_remove_log2_branch_and_says_so(pbmc, golden_dir, capsys):
+    """doc/plaid-vignette.html:920-921 (replaid.scse on the bundled matrix removes the log2): with removeLog2 = NULL the
+    decision of R/plaid.R:160-161 is taken ON THE DEVICE (min / max of the stored values and the implicit zeros); it must be
+    TRUE on the fixture, the message of :164 must be printed, and the scores must equal the explicit removeLog2 = TRUE run
+    and the oracle"""
+    import os
+    import plaid_amd
+    Xn, e = _pbmc_named(pbmc)
+    d = pbmc[0]
+    matG = plaid_amd.gmt2mat(plaid_amd.read_gmt(os.path.join(golden_dir, "hallmarks.gmt")))
+    capsys.readouterr()
+    auto = plaid_amd.replaid_scse(Xn, matG)
+    msg = capsys.readouterr()
+    assert "[replaid.scse] Converting data to linear scale (removing log2)..." in (msg.err + msg.out)
+    forced = plaid_amd.replaid_scse(Xn, matG, removeLog2=True)
+    assert np.array_equal(auto.values, forced.values)
+    capsys.readouterr()
+    plain = plaid_amd.replaid_scse(Xn, matG, removeLog2=False)
+    msg = capsys.readouterr()
+    assert "removing log2" not in (msg.err + msg.out)
+    assert np.abs(plain.values - auto.values).max() > 1e-3
+    po = _oracle()
+    close(auto.values, po.replaid_scse(Xn.values, list(d["rownames"]), sp.csc_matrix(matG.values), matG.rownames))
+    # not log-scale data (a value >= 20): the automatic rule leaves X alone, and says nothing
+    X2 = Xn.values.copy()
+    X2.data = X2.data.copy()
+    X2.data[0] = 25.0
+    capsys.readouterr()
+    a2 = plaid_amd.replaid_scse(plaid_amd.NamedMatrix(X2, Xn.rownames, Xn.colnames), matG)
+    msg = capsys.readouterr()
+    assert "removing log2" not in (msg.err + msg.out)
+    close(a2.values, po.replaid_scse(X2, list(d["rownames"]), sp.csc_matrix(matG.values), matG.rownames, remove_log2=False))
 
 
 def test_plaid_test_synthetic_and_errors(hip_ctx):
@@ -655,13 +693,29 @@ def test_rank_crossprod_u16_staging_is_bit_identical_to_fp64(g, n, m, ties):
             torch.cuda.synchronize()
             assert torch.equal(S1, S2), (stat, float((S1 - S2).abs().max()))
             assert torch.equal(f1, f2) and int(f1[3]) == 0
-        # not a rank matrix: flagged, never silently wrong
-        f1.zero_()
-        ctx.dev_spmm_ranks(gs, Xd.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0, 0.0, f1.data_ptr())
-        Xd[0, 1] = 70000.0
-        ctx.dev_spmm_ranks(gs, Xd.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0, 0.0, f1.data_ptr())
+        # not a rank matrix (arbitrary doubles; a value past the u16 range; NaN, Inf and negative "ranks"): the staging sees
+        # it and the fp64 launch enqueued behind the speculative one recomputes -- equal to the fp64 route, flags included
+        bads = [None, 70000.0, float("nan"), float("inf"), -3.0]
+        for bi, bad in enumerate(bads):
+            Xb = Xd.clone() if bad is None else R.clone()
+            if bad is not None:
+                Xb[n - 1, (7 * bi) % g] = bad
+                if n > 1:
+                    Xb[0, g - 1] = bad
+            f1.zero_(); f2.zero_()
+            ctx.dev_spmm_ranks(gs, Xb.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0, 0.0, f1.data_ptr())
+            ctx.dev_spmm_dense(gs, Xb.data_ptr(), ldg, n, S2.data_ptr(), m, "mean", 1.0, 0.0, f2.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(torch.nan_to_num(S1, nan=-7.0), torch.nan_to_num(S2, nan=-7.0)), bad
+            assert torch.equal(torch.isnan(S1), torch.isnan(S2)) and torch.equal(f1, f2), (bad, f1, f2)
+        # and a clean rank matrix afterwards takes the u16 kernel alone again (its private flag words were reset)
+        f1.zero_(); f2.zero_()
+        ctx.dev_spmm_ranks(gs, R.data_ptr(), ldg, n, S1.data_ptr(), m, "mean", 1.0 / g, -0.5, f1.data_ptr())
+        ctx.dev_spmm_dense(gs, R.data_ptr(), ldg, n, S2.data_ptr(), m, "mean", 1.0 / g, -0.5, f2.data_ptr())
+        ctx.dev_spmm_dense(gs, R.data_ptr(), ldg, n, S2.data_ptr(), m, "sum", 1.0, 0.0, f2.data_ptr())
     torch.cuda.synchronize()
-    assert int(f1[3]) == 1
+    assert torch.equal(f1[:3], torch.tensor([1, 0, 0], dtype=torch.int32, device=dev)) or g < 3   # sing scores < 0 exist
+    assert int(f1[3]) == 0
     from oracle import c_oracle
     Ro = c_oracle.colranks_dense(X, ties)
     close(S2.cpu().numpy().T, c_oracle.crossprod_dense(Ro, Gp, Gi, "sum", 4))
@@ -802,7 +856,8 @@ def test_scatter_kernel_many_columns_per_workgroup(pinned_ctx):
 def test_scatter_kernel_fixed_point_sums_are_reproducible_and_match_fp64(pinned_ctx):
     """plaidhip_dev_spmm_csc_ranks_f64: rank weights in [0, max(rX)] summed in u64 fixed point by the scatter kernel --
     bit-identical between two runs and between the two item orders (integer sums do not depend on the arrival order of
-    the LDS atomics), within 1e-13 relative of the fp64-atomic sums and of the oracle; an input outside [0, rmax] is flagged"""
+    the LDS atomics), within 1e-13 relative of the fp64-atomic sums and of the oracle; an input outside [0, rmax] or a NaN
+    weight is seen by the sweep on the device and takes the fp64 accumulators (IEEE propagation, as in the reference)"""
     import torch
     import plaid_amd
     from plaid_amd import synth as sy
@@ -837,17 +892,107 @@ def test_scatter_kernel_fixed_point_sums_are_reproducible_and_match_fp64(pinned_
         assert torch.equal(outs["fx_chunk"], outs["fx_chunk2"]) and torch.equal(outs["fx_chunk"], outs["fx_col"])
         for key in ("f64_chunk", "f64_col"):
             assert float((outs[key] - outs["fx_chunk"]).abs().max()) < 1e-13
-        # a value above rmax: flagged
-        Rx2 = Rx.clone()
-        Rx2[5] = 2.0 * float(gmax[0])
+        # a value above rmax / a NaN weight: not fixed-point material -- the fp64 launch of the same call takes it
         ctx.set_option("scatter_fixed", "on")
-        ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx2.data_ptr(), n, S.data_ptr(), m, gmax.data_ptr(), "mean",
-                               1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+        for bad in (2.0 * float(gmax[0]), float("nan")):
+            Rx2 = Rx.clone()
+            Rx2[5] = bad
+            S2 = torch.empty((n, m), dtype=torch.float64, device=dev)
+            ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx2.data_ptr(), n, S2.data_ptr(), m, gmax.data_ptr(), "mean",
+                                   1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+            ctx.set_option("scatter_fixed", "off")
+            S3 = torch.empty((n, m), dtype=torch.float64, device=dev)
+            ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx2.data_ptr(), n, S3.data_ptr(), m, gmax.data_ptr(), "mean",
+                                   1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+            ctx.set_option("scatter_fixed", "on")
+            torch.cuda.synchronize()
+            gene5 = int(Xi[5])
+            hit = np.zeros(m, dtype=bool)
+            hit[[j for j in range(m) if gene5 in Gi[Gp[j]:Gp[j + 1]]]] = True
+            a2, a3 = S2.cpu().numpy(), S3.cpu().numpy()
+            col0 = a2[0]          # stored value 5 belongs to sample column 0
+            assert Xp[1] > 5
+            if bad != bad:
+                assert np.isnan(col0[hit]).all() and not np.isnan(col0[~hit]).any() and not np.isnan(a2[1:]).any()
+            np.testing.assert_allclose(a2, a3, rtol=0, atol=1e-13, equal_nan=True)
+            assert hit.any()
     torch.cuda.synchronize()
-    assert int(flags[3]) == 1
+    assert int(flags[3]) == 0
     from oracle import fullsize
     _, raw_o = fullsize.ssgsea_csc_raw(Xp.astype(np.int32), Xi, Xx, g, Gp, Gi, alpha, float(gmax[0]))
     np.testing.assert_allclose(outs["fx_chunk"].cpu().numpy().T, raw_o, rtol=0, atol=1e-13)
+    gs.close()
+    ctx.close()
+
+
+def test_rank_pipelines_propagate_nan_like_the_fp64_route(hip_ctx, pinned_ctx):
+    """NaN in X: matrixStats::colRanks keeps NA and Matrix::crossprod carries it into every set that holds the gene.  The
+    default (u16 integer staging of the ranks) must give what the fp64 kernels give: replaid.sing dense and dgCMatrix,
+    replaid.ucell, replaid.ssgsea(alpha = 0)"""
+    from plaid_amd import synth as sy
+    g, n, m = 12000, 9, 300
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=300)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    X[17, 2] = np.nan
+    X[g - 1, 8] = np.nan
+    X[5, 0] = np.inf                     # a legal value: ranks last
+    ref = pinned_ctx(ranks_f32=0)
+    for name, call in (("sing", lambda c: c.sing_dense(X, Gp, Gi)), ("ssgsea0", lambda c: c.ssgsea_dense(X, Gp, Gi, 0.0))):
+        a, b = call(hip_ctx), call(ref)
+        assert np.isnan(b).any(), name
+        assert np.array_equal(np.isnan(a), np.isnan(b)), name
+        assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0)), name
+    # which sets: exactly those that hold the gene, in that sample
+    S = hip_ctx.sing_dense(X, Gp, Gi)
+    has17 = np.array([17 in Gi[Gp[j]:Gp[j + 1]] for j in range(m)])
+    assert np.array_equal(np.isnan(S[:, 2]), has17) and not np.isnan(S[:, [0, 1, 3, 4, 5, 6, 7]]).any()
+    # dgCMatrix input with a stored NaN
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    Xx = Xx.copy()
+    Xx[3] = np.nan
+    a = hip_ctx.sing_csc(Xp.astype(np.int32), Xi, Xx, g, Gp, Gi)
+    b = ref.sing_csc(Xp.astype(np.int32), Xi, Xx, g, Gp, Gi)
+    assert np.isnan(b).any() and np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
+
+
+def test_scatter_kernel_keeps_fp64_sums_for_a_wide_dynamic_range():
+    """plaid() on a dgCMatrix whose stored values span many orders of magnitude (raw counts up to 1e6 next to values near
+    1; one 1e15 outlier): the fixed-point grid follows the maximum, so small values would lose their relative precision --
+    the device-side guard (every score within 2^-40 of the exact sum, or fp64 atomics) must keep such input on the fp64
+    accumulators.  Checked against the oracle at 1e-12 relative on every score, which a 2^-4 grid could not meet."""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    from oracle import c_oracle
+    g, m, n = 20000, 3000, 64
+    Gp, Gi = sy.geneset_csc(g, m)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    ctx.set_option("spmm_sparse_kernel", "scatter")
+    rng = np.random.default_rng(5)
+    cases = {"counts": np.where(rng.random(len(Xx)) < 0.01, 1e6 * rng.random(len(Xx)), Xx),
+             "outlier": Xx.copy(), "tiny": Xx * np.where(rng.random(len(Xx)) < 0.5, 1e-9, 1.0),
+             "huge": Xx * 1e301, "zeros": np.where(rng.random(len(Xx)) < 0.3, 0.0, Xx)}
+    cases["outlier"][len(Xx) // 2] = 1e15
+    with torch.cuda.stream(stream):
+        dp, di = (torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (Xp.astype(np.int32), Xi.astype(np.int32)))
+        for name, xx in cases.items():
+            dx = torch.from_numpy(np.ascontiguousarray(xx)).to(dev)
+            S = torch.empty((n, m), dtype=torch.float64, device=dev)
+            fl = torch.zeros(4, dtype=torch.int32, device=dev)
+            ctx.dev_spmm_csc(gs, dp.data_ptr(), di.data_ptr(), dx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0, fl.data_ptr(),
+                             None, nnz=-1)
+            torch.cuda.synchronize()
+            with np.errstate(all="ignore"):
+                exp = c_oracle.crossprod_csc(Xp.astype(np.int32), Xi, xx, g, Gp, Gi, "mean", threads=8)
+            got = S.cpu().numpy().T
+            ok = exp != 0
+            assert np.array_equal(got == 0, exp == 0), name
+            assert float(np.max(np.abs(got[ok] / exp[ok] - 1.0))) < 1e-12, name
     gs.close()
     ctx.close()
 
@@ -1105,6 +1250,29 @@ def test_multi_device_engine_with_several_shards_on_one_gpu(hip_ctx, nshards):
         close(S, _oracle().replaid_ssgsea(Xs, rn, G, rn, alpha=0.25))
         rc, S = run(1, None, Gp, Gi, Xcsc=Xs)                          # replaid.sing on CSC: zeros ranked, integer sums
         assert rc == 0 and np.array_equal(S, hip_ctx.sing_dense(Xs.toarray(), Gp, Gi))
+    # shards of very different density, a NaN / a negative value in the LAST stored entries of a shard (what decides the
+    # accumulator format is swept over exactly the shard's stored values, whatever the whole matrix's density says)
+    n = 4 * nshards + 1
+    dens = np.where(np.arange(n) % 3 == 0, 0.11, 0.01)
+    rng = np.random.default_rng(nshards)
+    cols = [np.sort(rng.choice(g, int(g * d), replace=False)).astype(np.int32) for d in dens]
+    Xp = np.concatenate([[0], np.cumsum([len(c_) for c_ in cols])]).astype(np.int32)
+    Xi = np.concatenate(cols)
+    lo_hi = [plaid_amd.shard_bounds(n, nshards, k) for k in range(nshards)]
+    for bad in (np.nan, -2.5):
+        Xx = np.round(rng.gamma(2.0, 1.0, len(Xi)), 1) + 0.1
+        for k in range(nshards):                      # last stored value of every shard's last column
+            lo, hi = lo_hi[k]
+            if hi > lo:
+                Xx[Xp[hi] - 1] = bad
+        Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, n))
+        rc, S = run(0, None, Gp, Gi, Xcsc=Xs, normalize=0)
+        assert rc == 0
+        with np.errstate(all="ignore"):
+            exp = _oracle().plaid(Xs, rn, G, rn, normalize=False)
+        assert np.array_equal(np.isnan(S), np.isnan(exp)), bad
+        ok = ~np.isnan(exp)
+        np.testing.assert_allclose(S[ok], exp[ok], rtol=1e-10, atol=1e-12)
     # a failing shard: every worker still reaches every rendezvous, the call reports the failure
     X = sy.dense_columns(g, 0, 37)
     for fail in (0, nshards - 1):

@@ -21,6 +21,9 @@ KAT = {
     "HALLMARK_G2M_CHECKPOINT": (0.012385507, 6.049535e-02, 3.638628e-03),
 }
 KAT_ORDER = list(KAT)
+# doc/plaid-vignette.html:864-869: q.meta = p.adjust(p.meta, "fdr") over all 50 sets (R/plaid.R:463) -- pins the BH step,
+# incl. the tie 3.032190e-02 of ranks 5 and 6 (the cumulative minimum from the largest p downwards)
+QMETA = [1.934024e-05, 1.195384e-03, 1.394918e-03, 1.864818e-02, 3.032190e-02, 3.032190e-02]
 
 
 def _load(pbmc, golden_dir):
@@ -57,6 +60,21 @@ def test_vignette_pvalues(pbmc, golden_dir):
         np.testing.assert_allclose(res["p.meta"][k], p_meta, rtol=2e-6)
     top6 = [gcn[k] for k in np.argsort(res["p.meta"])[:6]]
     assert top6 == KAT_ORDER
+    for nm, q in zip(KAT_ORDER, QMETA):                              # html:864-869
+        np.testing.assert_allclose(res["q.meta"][idx[nm]], q, rtol=2e-6)
+    assert res["q.meta"][idx[KAT_ORDER[4]]] == res["q.meta"][idx[KAT_ORDER[5]]]   # the BH tie, exactly
+
+
+def test_scse_on_the_fixture_removes_log2(pbmc, golden_dir):
+    """doc/plaid-vignette.html:920-921: the vignette runs replaid.scse(X, matG, removeLog2=TRUE, ...) on this very matrix and
+    the function reports that it removes the log2.  The automatic rule of R/plaid.R:160-161 (min(X) == 0 && max(X) < 20)
+    must come to the same decision on it: the fixture is log-scale data with implicit zeros."""
+    d, e, X, D, grn, gcn = _load(pbmc, golden_dir)
+    rn = list(d["rownames"])
+    assert X.nnz < X.shape[0] * X.shape[1] and X.data.min() > 0 and X.data.max() < 20
+    auto = po.replaid_scse(X, rn, D, grn, remove_log2=None)
+    np.testing.assert_array_equal(auto, po.replaid_scse(X, rn, D, grn, remove_log2=True))
+    assert np.abs(auto - po.replaid_scse(X, rn, D, grn, remove_log2=False)).max() > 1e-3
 
 
 def test_wrong_median_rule_breaks_the_pin(pbmc, golden_dir):
