@@ -155,6 +155,10 @@ struct plaidhip_scatter_plan {
   double* d_w = nullptr;   // per set 1/(1e-8 + size)
   double* d_k = nullptr;   // per set size
   double* d_kw = nullptr;  // {size, 1/(1e-8 + size)} interleaved: one 16-byte load per set in the scatter kernel's epilogue
+#ifdef PLAIDHIP_KEEP_HOST_PLANS
+  std::vector<int32_t> h_seg;    // host-only tools build (tools/plan_probe): the uploaded plan, for its checker
+  std::vector<uint16_t> h_ids;
+#endif
 };
 
 struct plaidhip_geneset {

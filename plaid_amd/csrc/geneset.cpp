@@ -735,6 +735,10 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     }
     if ((rc = upload(ctx, seg, &sp.d_seg)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, ids, &sp.d_ids)) != PLAIDHIP_OK) goto fail;
+#ifdef PLAIDHIP_KEEP_HOST_PLANS   // host-only tools (tools/plan_probe): the checker below reads the plan back
+    sp.h_seg = seg;
+    sp.h_ids = ids;
+#endif
     if ((rc = upload(ctx, w, &sp.d_w)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, k, &sp.d_k)) != PLAIDHIP_OK) goto fail;
     {
@@ -842,3 +846,56 @@ extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_
   out[4] = wrong;
   return PLAIDHIP_OK;
 }
+
+#ifdef PLAIDHIP_KEEP_HOST_PLANS
+// Test hook of the host-only tools build: checks the scatter plan (gene-major id segments per chunk of sets) against the
+// pattern.  out[0] = chunks, out[1] = segments, out[2] = memberships found (each exactly once, in the list of its gene and
+// chunk), out[3] = wrong / repeated / out-of-chunk ids, out[4] = LDS atomic wave-instructions over all lists (what a
+// stored value of that gene costs), out[5] = ids that share their 8-byte bank (id mod 16) with an earlier id of the same
+// 16-lane group of an instruction (each costs one more 2-cycle pass of that group).
+extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int64_t out[8]) {
+  PH_REQUIRE(gs && out, "scatter_plan_check: null argument");
+  const plaidhip_scatter_plan& sp = gs->scatter;
+  const int32_t g = gs->g, m = gs->m;
+  const int32_t* Gp = gs->h_Gp.data();
+  const int32_t* Gi = gs->h_Gi.data();
+  std::vector<uint8_t> seen((size_t)gs->z, 0);
+  int64_t found = 0, wrong = 0, instr = 0, coll = 0;
+  for (int32_t ch = 0; ch < sp.nch; ++ch)
+    for (int32_t gene = 0; gene < g; ++gene) {
+      const size_t cell = (size_t)ch * g + gene;
+      for (int32_t sgm = sp.h_seg[cell]; sgm < sp.h_seg[cell + 1]; ++sgm) {
+        const uint16_t* base = sp.h_ids.data() + (size_t)sgm * 128;
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1 && base[1] == 0xffffu) {     // an empty second instruction: every high half carries the mark
+            for (int l = 0; l < 64; ++l) if (base[2 * l + 1] != 0xffffu) ++wrong;
+            continue;
+          }
+          ++instr;
+          for (int quarter = 0; quarter < 4; ++quarter) {
+            uint32_t banks = 0;
+            for (int l = 0; l < 16; ++l) {
+              const uint16_t id = base[2 * (16 * quarter + l) + half];
+              if (banks & (1u << (id & 15))) ++coll;
+              banks |= 1u << (id & 15);
+              if (id >= sp.ch) { if (id >= sp.ch + kScatterTrash) ++wrong; continue; }   // a trash accumulator
+              const int32_t j = ch * sp.ch + id;
+              if (j >= m) { ++wrong; continue; }
+              const int32_t* lo = std::lower_bound(Gi + Gp[j], Gi + Gp[j + 1], gene);
+              if (lo == Gi + Gp[j + 1] || *lo != gene || seen[lo - Gi]) { ++wrong; continue; }
+              seen[lo - Gi] = 1;
+              ++found;
+            }
+          }
+        }
+      }
+    }
+  out[0] = sp.nch;
+  out[1] = sp.nseg;
+  out[2] = found;
+  out[3] = wrong;
+  out[4] = instr;
+  out[5] = coll;
+  return PLAIDHIP_OK;
+}
+#endif

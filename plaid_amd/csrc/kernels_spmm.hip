@@ -68,7 +68,7 @@ struct SpmmArgs {
   uint32_t* flags;
   // speculative launch + guarded fallback (see spec_guard): the u16 quad kernel is exact only for rank inputs, so it
   // publishes its flag words to spec[1..3] and stores spec_gen in spec[0] when it staged a value that is not a rank
-  // (NaN / Inf / negative / fractional part other than .5 is impossible to see, but 2x >= 2^16 is); the fp64 launch
+  // (NaN / Inf / negative / not a multiple of 1/2 / 2x >= 2^16); the fp64 launch
   // enqueued behind it runs only then.  null: unconditional launch.
   uint32_t* spec;
   uint32_t spec_gen;
@@ -1475,10 +1475,13 @@ __device__ __forceinline__ uint32_t add_hi16(uint32_t acc, uint32_t v) {   // ac
   asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(acc), "v"(v));
   return r;
 }
-// (the high word of x + 2^51 is 0x43200000 exactly when 0 <= x < 2^31: NaN, +-Inf, negatives and huge values differ)
+// Two tests say whether x was a rank: the high word of x + 2^51 is 0x43200000 exactly when 0 <= x < 2^31 (NaN, +-Inf,
+// negatives and huge values differ), and (x + 2^51) - 2^51 == x exactly when x is a multiple of 1/2 (the sum rounds to the
+// grid of halves; the difference is exact).  (The wave's sticky IEEE "inexact" status bit would give the second test for
+// free, but gfx950 does not record it with the exception masked: tools/ubench/inexact_flag.hip.)
 __device__ __forceinline__ uint32_t twice_as_u32(double x, uint32_t& not_a_rank) {
   const double y = x + 0x1p51;
-  not_a_rank |= (uint32_t)__double2hiint(y) ^ 0x43200000u;
+  not_a_rank |= ((uint32_t)__double2hiint(y) ^ 0x43200000u) | ((y - 0x1p51 != x) ? 1u : 0u);
   return (uint32_t)__double2loint(y);
 }
 

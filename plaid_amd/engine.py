@@ -54,7 +54,7 @@ class Geneset:
         buf = (C.c_int64 * 8)()
         check(self.ctx.lib.plaidhip_geneset_info(self.handle, buf))
         return {"g": buf[0], "m": buf[1], "z": buf[2], "padded_slots": buf[3], "tiles": buf[4],
-                "gene_slices": buf[5], "waves": buf[6]}
+                "gene_slices": buf[5], "waves": buf[6], "padded_slots_pair": buf[7]}
 
     def close(self):
         if self.handle:

@@ -40,6 +40,77 @@ def geneset_csc(g: int, m: int, seed: int = SEED_G, kmin: int = 15, kmax: int = 
     return Gp.astype(np.int32), Gi
 
 
+def geneset_csc_real(g: int, m: int, seed: int = SEED_G + 7, hubs: str = "scattered", all_genes_set: bool = True,
+                     kmin: int = 5, kmax: int = 5000):
+    """A gene-set collection with the SHAPE of the one the reference benchmarks with -- `playdata::GSETxGENE`, 61,459 sets
+    over the genes of the data set (experiments/benchmark/benchmark-plaid.R:18-35; the package is not in the tree, so
+    its shape is restated, not its content):
+
+      * set sizes log-normal (median 40, sigma 1.2) clipped to [kmin, kmax] = 5 ... 5,000 genes -- a long right tail, and
+        at least three sets beyond 3,000 genes once m >= 1,000;
+      * ONE set that holds every gene (`all_genes_set`), the largest the planner can meet;
+      * Zipf-like gene popularity, p(gene of popularity rank r) ~ (r + 20)^-0.7: a handful of hub genes sit in 10-25 % of
+        all sets, the median gene in ~0.5 %;
+      * duplicate-heavy overlaps: 15 % of the sets are children of an earlier set (90 % of the parent's genes + 10 % new
+        ones), 1 % are exact copies under another name -- what curated collections (GO parents / children, the same
+        pathway from several sources) look like;
+      * columns ordered by decreasing size like gmt2mat() output (R/gmt-utils.R:25).
+
+    hubs: "front" keeps popularity rank = row index (gmt2mat orders ROWS by decreasing frequency, R/gmt-utils.R:31,62 --
+    the layout of a matrix straight from gmt2mat); "scattered" (default) permutes the genes, which is what plaid() sees
+    after re-indexing the pattern into X's row space (R/plaid.R:65-72: the order of rownames(X)).
+    Returns (Gp int32[m+1], Gi int32[z] sorted inside a column)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kmax = min(kmax, g)
+    kmin = max(1, min(kmin, kmax))
+    sizes = np.rint(np.exp(rng.normal(np.log(40.0), 1.2, size=m))).astype(np.int64)
+    sizes = np.clip(sizes, kmin, kmax)
+    if m >= 1000:
+        sizes[:3] = np.maximum(sizes[:3], np.minimum(kmax, 3000 + np.arange(3) * 800))
+    w = (np.arange(g, dtype=np.float64) + 20.0) ** -0.7
+    cw = np.cumsum(w / w.sum())
+    sets = [None] * m
+    # weighted draws WITHOUT replacement: oversampled draws with replacement, de-duplicated in drawing order; sets that
+    # take a large part of the genes (the draws would mostly repeat) use the exponential-keys method instead
+    for j in range(m):
+        k = int(sizes[j])
+        r = rng.random()
+        if j >= 10 and r < 0.01:                                   # exact copy of an earlier set
+            sets[j] = sets[int(rng.integers(0, j))]
+            continue
+        if j >= 10 and r < 0.16:                                   # child: 90 % of the parent + new genes
+            par = sets[int(rng.integers(0, j))]
+            keep = par[rng.random(len(par)) < 0.9]
+            extra = np.searchsorted(cw, rng.random(max(1, len(par) // 10)))
+            sets[j] = np.unique(np.concatenate([keep, np.minimum(extra, g - 1)])).astype(np.int32)
+            continue
+        if k * 6 > g:
+            keys = rng.exponential(size=g) / w
+            sets[j] = np.sort(np.argpartition(keys, k - 1)[:k]).astype(np.int32)
+            continue
+        got = np.zeros(0, dtype=np.int64)
+        while len(got) < k:
+            d = np.minimum(np.searchsorted(cw, rng.random(int(1.4 * (k - len(got))) + 8)), g - 1)
+            allv = np.concatenate([got, d])
+            _, first = np.unique(allv, return_index=True)
+            got = allv[np.sort(first)]
+        sets[j] = np.sort(got[:k]).astype(np.int32)
+    if all_genes_set and m > 0:
+        sets[0] = np.arange(g, dtype=np.int32)
+    if hubs == "scattered":
+        perm = rng.permutation(g).astype(np.int32)
+        sets = [np.sort(perm[s_]) for s_ in sets]
+    elif hubs != "front":
+        raise ValueError("hubs: 'scattered' or 'front'")
+    order = np.argsort(-np.array([len(s_) for s_ in sets]), kind="stable")   # gmt2mat: decreasing size
+    sets = [sets[j] for j in order]
+    Gp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum([len(s_) for s_ in sets], out=Gp[1:])
+    assert Gp[-1] < 2**31 - 1
+    Gi = np.concatenate(sets).astype(np.int32) if m else np.zeros(0, np.int32)
+    return Gp.astype(np.int32), Gi
+
+
 def _block_rng(seed: int, block: int):
     return np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, block])))
 

@@ -1321,3 +1321,20 @@ def test_mfma_backend_matches_the_spmm_route(pinned_ctx, g, n, m):
     np.testing.assert_allclose(got["sum"], ref["sum"], rtol=1e-5, atol=1e-3)                    # sums ~ 1e3, medians removed
     np.testing.assert_allclose(got["ssgsea"], ref["ssgsea"], rtol=1e-5, atol=1e-6)              # centred scores
     np.testing.assert_allclose(got["ssgsea"], _oracle().replaid_ssgsea(X, rn, G, rn, alpha=0.25), rtol=1e-5, atol=1e-6)
+
+
+def test_mfma_backend_at_config_4_width_50k_sets(pinned_ctx, g50k):
+    """config 4 is named "MFMA path": the dense-G backend at the full 50,000 sets (2 GB of bf16 G) x 20,000 genes on 2,048
+    samples -- replaid.ssgsea(alpha = 0.25), ranks and medians included -- against the SpMM route and the oracle"""
+    from plaid_amd import synth as sy
+    g, m, Gp, Gi, G, rn = g50k
+    n = 2048
+    X = sy.dense_columns(g, 0, n)
+    ref = pinned_ctx().ssgsea_dense(X, Gp, Gi, 0.25)
+    got = pinned_ctx(spmm_dense_kernel="mfma").ssgsea_dense(X, Gp, Gi, 0.25)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert 0 < float(np.max(np.abs(got - ref))) < 1e-6                  # really the bf16 x 3 / fp32 path, inside its bound
+    cols = np.r_[0:24, n - 24:n]                                        # oracle on a sample of the columns: max(rX) is
+    exp = _oracle().replaid_ssgsea(X[:, cols], rn, G, rn, alpha=0.25)   # g^1.25 in every tie-free column, the mean of the
+    raw = got[:, cols] - got[:, cols].mean(axis=0, keepdims=True)       # medians is not: compare up to the column shift
+    np.testing.assert_allclose(raw, exp - exp.mean(axis=0, keepdims=True), rtol=1e-5, atol=1e-6)

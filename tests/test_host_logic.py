@@ -424,3 +424,42 @@ def test_r_shim_goes_through_a_c_compiler():
                           "-I" + os.path.join(ROOT, "tests", "r_api_stub"), "-I" + os.path.join(ROOT, "include"),
                           os.path.join(ROOT, "r-pkg", "src", "plaidhip_R.c")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_planners_take_the_reference_shaped_collection(tmp_path):
+    """The reference benchmarks with playdata::GSETxGENE: 61,459 real gene sets (experiments/benchmark/benchmark-plaid.R:18-35),
+    not 15-500-gene synthetic ones.  `make plan-probe` builds geneset.cpp for the host (HIP stand-ins) and runs
+    plaidhip_geneset_create on a collection of that shape (synth.geneset_csc_real: sizes 3 ... 5,000 + an all-genes set,
+    Zipf gene popularity, duplicated sets): every membership is scheduled exactly once in the pair plan and in the scatter
+    plan's id lists, within stated time / memory / padding budgets."""
+    import json
+    import subprocess
+    import numpy as np
+    from plaid_amd import synth
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "plaid_amd", "csrc"), "plan-probe"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    probe = os.path.join(ROOT, "plaid_amd", "csrc", "diag", "plan_probe")
+    for g, m, gen in ((12010, 61459, synth.geneset_csc_real), (25000, 3000, synth.geneset_csc_real),
+                      (20000, 5000, synth.geneset_csc)):
+        Gp, Gi = gen(g, m)
+        path = str(tmp_path / "gs.bin")
+        with open(path, "wb") as f:
+            f.write(np.array([g, m], dtype=np.int32).tobytes())
+            f.write(Gp.tobytes())
+            f.write(Gi.tobytes())
+        r = subprocess.run([probe, path, "check"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        d = json.loads(r.stdout)
+        z = int(Gp[-1])
+        assert d["rc"] == 0 and d["z"] == z
+        assert d["pair_found"] == z and d["pair_wrong"] == 0            # pair plan: each membership once, right set and slice
+        assert d["scatter_found"] == z and d["scatter_wrong"] == 0      # scatter plan: each membership once, right gene and chunk
+        assert d["create_s"] < 30.0, d                                   # (2.5 s here; R's gmt2mat alone: 50.9 s for 50k sets)
+        assert d["device_bytes"] < 400e6 + 64.0 * z, d                   # index lists + metadata + the partial-sum scratch
+        real = gen is synth.geneset_csc_real
+        if m >= 5000:   # (with few sets the all-genes set's tile -- as long as its longest lane -- dominates the padding)
+            assert z / d["slots_one_column"] > (0.70 if real else 0.85), d   # slot efficiency (real / padded index slots)
+            assert z / d["slots_pair"] > (0.60 if real else 0.78), d
+        assert d["pair_conflicts"] < 0.01 * z                            # deliberate two-way conflicts of over-full slots only
+        assert d["scatter_collisions"] < 0.08 * z                        # ids sharing an LDS bank inside a 16-lane group

@@ -4,7 +4,9 @@
 // are not available for device code on this pool, and the index planning, the GMT parser and the statistics tails are
 // host code anyway.  Never linked into libplaidhip.so.
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -13,9 +15,22 @@
 
 #include "../../plaid_amd/csrc/common.h"
 
+static std::atomic<int64_t> g_live{0}, g_peak{0}, g_total{0};   // "device" bytes (tools/plan_probe reports them)
 extern "C" {
-hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+void plaidhip_stub_alloc_stats(int64_t* live, int64_t* peak, int64_t* total) { *live = g_live; *peak = g_peak; *total = g_total; }
+hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  if (!*p) return hipErrorOutOfMemory;
+  const int64_t now = (g_live += (int64_t)malloc_usable_size(*p));
+  g_total += (int64_t)n;
+  if (now > g_peak) g_peak = now;
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  if (p) g_live -= (int64_t)malloc_usable_size(p);
+  free(p);
+  return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

@@ -1,10 +1,11 @@
 #!/bin/bash
-# One-shot evidence run for profiles/ (round 3 layout).  Run through gpurun:
-#     gpurun --timeout 2400 -- 'bash tools/profile_round.sh gpurun_out/r03x'
+# One-shot evidence run for profiles/ (round 4 layout).  Run through gpurun:
+#     gpurun --timeout 2400 -- 'bash tools/profile_round.sh gpurun_out/r04x'
 #  * the bench line (all blocks);
-#  * rocprofv3 --kernel-trace --stats of `python3 bench.py --config c2`, `--config c3`, `--config c4` SEPARATELY, so that
-#    every tracked kernel_stats CSV has one launch shape per kernel row (the pair kernel's C2 and C4 launches are not
-#    pooled any more) and its average duration can be read against the bench line's HIP-event time;
+#  * rocprofv3 --kernel-trace --stats of `python3 bench.py --config c2` (the headline alone: no pre-heat, no mixed-precision
+#    leg) and of `--profile --config c3 | c4 | ref` (ONLY that block, no C2 headline in the process), so that every tracked
+#    kernel_stats CSV has ONE launch shape per kernel row and its average duration can be read against the bench line's
+#    HIP-event time;
 #  * PMC passes (separate --pmc runs: FETCH_SIZE / WRITE_SIZE / the SQ set / TCC hits / GRBM) for the dominant kernels of
 #    C2 (pair kernel), C3 (scatter kernel, fixed-point and fp64 accumulators), C4 (pair kernel at 50k sets, bucket
 #    ranker) and of the rank crossprod (quad kernel), summarised per kernel;
@@ -14,8 +15,9 @@ out=${1:-gpurun_out/prof}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
-for cfg in c2 c3 c4; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$cfg -- python3 bench.py --config $cfg --cpu-sample 0 --no-mixed > $out/stats_$cfg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -- python3 bench.py --config c2 --preheat-steps 0 --cpu-sample 0 --no-mixed > $out/stats_c2.log 2>&1
+for cfg in c3 c4 ref; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$cfg -- python3 bench.py --profile --config $cfg --cpu-sample 0 --no-mixed > $out/stats_$cfg.log 2>&1
 done
 SQSET="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY"
 run_pmc() {   # tag, then bench_spmm.py arguments
@@ -62,7 +64,7 @@ for tag in ("c2", "c3", "c3f64", "c4", "sing", "c2step"):
             for c, v in sorted(d.items()):
                 fh.write(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
 # kernel stats of the three bench runs: one csv each
-for cfg in ("c2", "c3", "c4"):
+for cfg in ("c2", "c3", "c4", "ref"):
     for f in glob.glob(out + f"/stats_{cfg}/**/*kernel_stats.csv", recursive=True):
         os.replace(f, out + f"/bench_{cfg}_kernel_stats.csv")
 print(open(out + "/pmc_c2_summary.txt").read()[:1500])
