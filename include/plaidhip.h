@@ -43,7 +43,15 @@ enum plaidhip_stat { PLAIDHIP_STAT_MEAN = 0, PLAIDHIP_STAT_SUM = 1 }; /* R/plaid
 enum plaidhip_ties {                                                   /* R/plaid.R:593 `ties.method` */
   PLAIDHIP_TIES_AVERAGE = 0,
   PLAIDHIP_TIES_MIN = 1,
-  PLAIDHIP_TIES_MAX = 2
+  PLAIDHIP_TIES_MAX = 2,
+  /* passed through like the reference does (R/plaid.R:614-617 -> matrixStats::colRanks; :639-642 -> base::rank): ties in
+   * order of their position / reverse position / without gaps ("dense": dense columns only, as in matrixStats).  Composed
+   * from two or three passes of the min-rank kernels: exact, off the hot path, no fused power / column maximum, and the
+   * CSC form reads Xp[n] back (not stream-ordered).                                                                     */
+  PLAIDHIP_TIES_FIRST = 3,
+  PLAIDHIP_TIES_LAST = 4,
+  PLAIDHIP_TIES_DENSE = 5,
+  PLAIDHIP_TIES_RANDOM = 6 /* legal in R, REFUSED here (PLAIDHIP_EUNSUPPORTED): not a function of the input */
 };
 enum plaidhip_ignore_zero { /* R/plaid.R:554 `ignore.zero`: NULL / FALSE / TRUE */
   PLAIDHIP_IGNORE_ZERO_AUTO = -1,

@@ -231,9 +231,17 @@ def plaid(X, rownames_x, matG, rownames_g, stats="mean", chunk=None, normalize=T
 # ranks  (R/plaid.R:589-650)
 # ---------------------------------------------------------------------------
 def _rank_vec(x, ties_method):
-    """base::rank / matrixStats::colRanks on one NaN-free vector."""
+    """base::rank / matrixStats::colRanks on one NaN-free vector.  ties.method is passed through by the reference
+    (R/plaid.R:614-617, 639-642): "first" breaks ties by position (scipy "ordinal"), "last" by reverse position
+    (rank(c(1, 1, 1), ties.method = "last") is 3 2 1), "dense" leaves no gaps (matrixStats only)."""
     if len(x) == 0:
         return np.zeros(0)
+    if ties_method == "first":
+        return st.rankdata(x, method="ordinal").astype(np.float64)
+    if ties_method == "last":
+        return st.rankdata(np.asarray(x)[::-1], method="ordinal")[::-1].astype(np.float64)
+    if ties_method == "random":
+        raise ValueError("ties.method = 'random' has no deterministic oracle")
     return st.rankdata(x, method=ties_method).astype(np.float64)
 
 
@@ -253,6 +261,8 @@ def rank_by_counting(x, ties_method="average"):
 def sparse_colranks(X, signed=False, ties_method="average"):
     """R/plaid.R:631-650: rank the stored non-zeros of each CSC column among
     themselves; pattern unchanged, @x replaced (:645-646)."""
+    if ties_method == "dense":
+        raise ValueError("'arg' should be one of average, first, last, random, max, min")   # base::rank has no "dense"
     X = sp.csc_matrix(X).copy()
     X.sort_indices()
     out = X.data.astype(np.float64).copy()
@@ -273,6 +283,8 @@ def colranks(X, sparse=None, signed=False, keep_zero=False, ties_method="average
         sparse = sp.issparse(X)                           # :595-596
     if sparse and keep_zero:
         return sparse_colranks(X, signed=signed, ties_method=ties_method)
+    if sparse and ties_method not in ("max", "average", "min"):
+        raise ValueError("'arg' should be one of max, average, min")   # sparseMatrixStats::colRanks (:605-608)
     D = np.asarray(X.todense()) if sp.issparse(X) else np.asarray(X, dtype=np.float64)
     out = np.empty(D.shape, dtype=np.float64)
     for j in range(D.shape[1]):

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PLAIDHIP_LIB") or os.path.join(_HERE, "csrc", "libpla
 
 OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ENODEVICE = range(6)
 STAT = {"mean": 0, "sum": 1}
-TIES = {"average": 0, "min": 1, "max": 2}
+TIES = {"average": 0, "min": 1, "max": 2, "first": 3, "last": 4, "dense": 5, "random": 6}
 FLAG_HAS_NEG, FLAG_HAS_ZERO, FLAG_HAS_NAN = 1, 2, 4
 # enum plaidhip_option and its values (include/plaidhip.h)
 OPTIONS = {

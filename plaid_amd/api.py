@@ -18,7 +18,7 @@ from .gmt import GmtList, gmt2mat
 from .matrix import NamedMatrix, as_named
 
 INT_MAX = 2147483647  # .Machine$integer.max
-_TIES = ("average", "min", "max")
+_TIES = ("average", "min", "max", "first", "last", "dense", "random")   # what matrixStats::colRanks takes
 
 
 def _message(txt: str):
@@ -169,15 +169,19 @@ def normalize_medians(x, ignore_zero=None, ctx: Context | None = None):
     return NamedMatrix(S, x.rownames, x.colnames)
 
 
-def _check_ties(ties_method):
-    if ties_method not in _TIES:
-        raise PlaidHipError(EUNSUPPORTED, f"ties.method={ties_method!r}: only {_TIES} are built")
+def _check_ties(ties_method, allowed=_TIES):
+    """ties.method is passed through like the reference does (R/plaid.R:614-617, 639-642); which values are legal depends on
+    the function behind the branch: matrixStats::colRanks (all), base::rank (no "dense"), sparseMatrixStats::colRanks
+    (max / average / min).  An illegal value raises like R's match.arg; "random" is legal in R and refused by the library
+    (PLAIDHIP_EUNSUPPORTED: not a function of the input)."""
+    if ties_method not in allowed:
+        raise ValueError("'arg' should be one of " + ", ".join(f"\u2018{t}\u2019" for t in allowed))
 
 
 def sparse_colranks(X, signed=False, ties_method="average", ctx: Context | None = None):
     """sparse_colranks(), R/plaid.R:631-650: ranks of the stored non-zeros per column; the
     sparsity pattern is kept, @x replaced."""
-    _check_ties(ties_method)
+    _check_ties(ties_method, ("average", "first", "last", "random", "max", "min"))     # base::rank, :639-642
     X = as_named(X)
     V = sp.csc_matrix(X.values)
     ctx = ctx or default_context()
@@ -189,13 +193,16 @@ def sparse_colranks(X, signed=False, ties_method="average", ctx: Context | None 
 def colranks(X, sparse=None, signed=False, keep_zero=False, ties_method="average",
              ctx: Context | None = None):
     """colranks(), R/plaid.R:589-623."""
-    _check_ties(ties_method)
     X = as_named(X)
     if sparse is None:
         sparse = X.is_sparse                                   # :595-596
     if sparse and keep_zero:
         return sparse_colranks(X, signed=signed, ties_method=ties_method, ctx=ctx)   # :600-601
+    # the `sparse` ARGUMENT picks the function: sparseMatrixStats::colRanks (:603-608) or matrixStats::colRanks (:611-617)
+    _check_ties(ties_method, ("max", "average", "min") if sparse else _TIES)
     ctx = ctx or default_context()
+    if X.is_sparse and ties_method not in ("max", "average", "min"):
+        X = NamedMatrix(X.values.toarray(), X.rownames, X.colnames)   # sparse = FALSE on a dgCMatrix: as.matrix(X), :617
     if X.is_sparse:
         # sparse without keep.zero: the reference's result is dense with the zeros ranked
         # (sparseMatrixStats::colRanks, :603-609) -- computed from the CSC arrays on the device

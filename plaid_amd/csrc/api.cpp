@@ -348,6 +348,7 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   ctx->gs_cache.clear();
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->rank_scratch) hipFree(ctx->rank_scratch);
+  if (ctx->tie_scratch) hipFree(ctx->tie_scratch);
   if (ctx->d_sel) hipFree(ctx->d_sel);
   for (int k = 0; k < plaidhip_ctx::kHostBufs; ++k)
     if (ctx->hbuf[k]) hipFree(ctx->hbuf[k]);
@@ -468,9 +469,23 @@ int plaidhip_dev_crossprod_weighted_csc_f64(plaidhip_ctx* ctx, const void* Wp, c
                                        static_cast<double*>(S), lds);
 }
 
-static int check_ties(int ties) {
-  PH_REQUIRE(ties == PLAIDHIP_TIES_AVERAGE || ties == PLAIDHIP_TIES_MIN || ties == PLAIDHIP_TIES_MAX,
-             "colranks: unsupported ties.method code %d (average/min/max)", ties);
+// which: 0 dense columns (matrixStats::colRanks: average / min / max / first / last / dense), 1 the stored values of a
+// dgCMatrix (base::rank, R/plaid.R:639-642: no "dense"), 2 a dgCMatrix with its zeros ranked (sparseMatrixStats::colRanks,
+// R/plaid.R:605-608: max / average / min only).  "random" is legal in R and refused here: its result is not a function of
+// the input.  first / last / dense come without the fused power and column maximum (no caller of the reference combines them).
+static int check_ties(int ties, int which = 0, double power = 1.0, const void* colmax = nullptr) {
+  if (ties == PLAIDHIP_TIES_RANDOM) {
+    set_error("colranks: ties.method = \"random\" is not supported (the ranks would not be reproducible)");
+    return PLAIDHIP_EUNSUPPORTED;
+  }
+  PH_REQUIRE(ties >= PLAIDHIP_TIES_AVERAGE && ties <= PLAIDHIP_TIES_DENSE, "colranks: unknown ties.method code %d", ties);
+  if (ties >= PLAIDHIP_TIES_FIRST) {
+    PH_REQUIRE(which != 2, "colranks: 'arg' should be one of \"max\", \"average\", \"min\" for a sparse matrix whose zeros are "
+               "ranked (sparseMatrixStats::colRanks, R/plaid.R:605-608)");
+    PH_REQUIRE(!(which == 1 && ties == PLAIDHIP_TIES_DENSE), "sparse_colranks: 'arg' should be one of \"average\", \"first\", \"last\", "
+               "\"random\", \"max\", \"min\" (base::rank, R/plaid.R:639-642)");
+    PH_REQUIRE(power == 1.0 && colmax == nullptr, "colranks: ties.method first / last / dense come without power / colmax");
+  }
   return PLAIDHIP_OK;
 }
 
@@ -494,7 +509,7 @@ int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ld
                                     int32_t n, int ties, int is_signed, double power, void* R,
                                     int64_t ldr, void* colmax) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 0, power, colmax));
   PH_REQUIRE(g >= 0 && n >= 0, "colranks: bad dims g=%d n=%d", g, n);
   PH_REQUIRE(g == 0 || n == 0 || (X && R), "colranks: null X/R");
   PH_REQUIRE(ldx >= g && ldr >= g, "colranks: leading dims below g");
@@ -506,7 +521,7 @@ int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void*
                                   int32_t max_col_nnz, int ties, int is_signed, double power, void* Rx,
                                   void* colmax) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 1, power, colmax));
   PH_REQUIRE(n >= 0 && max_col_nnz >= 0, "colranks_csc: n=%d max_col_nnz=%d", n, max_col_nnz);
   PH_REQUIRE(n == 0 || Xp != nullptr, "colranks_csc: null Xp");
   return launch_colranks_csc_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const double*>(Xx),
@@ -518,7 +533,7 @@ int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const
                                         int32_t g, int32_t n, int ties, int is_signed, double power,
                                         void* R, int64_t ldr, void* colmax) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
   PH_REQUIRE(n == 0 || g == 0 || (Xp && R), "colranks_csc_dense: null Xp/R");
   return launch_colranks_csc_dense_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
@@ -530,7 +545,7 @@ int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, co
                                            int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
                                            void* Rx_scratch, void* R, int64_t ldr, void* colmax) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense_nz: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
   PH_REQUIRE(n == 0 || g == 0 || (Xp && R), "colranks_csc_dense_nz: null Xp/R");
   PH_REQUIRE(max_col_nnz >= 0 && max_col_nnz <= g, "colranks_csc_dense_nz: max_col_nnz=%d outside [0, nrow(X)=%d]", max_col_nnz, g);
@@ -689,7 +704,7 @@ int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t 
 int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, int ties,
                             int is_signed, double* R_out) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 0));
   PH_REQUIRE(g >= 0 && n >= 0, "colranks_dense: bad dims");
   if ((int64_t)g * n == 0) return PLAIDHIP_OK;
   PH_REQUIRE(X && R_out, "colranks_dense: null X/R_out");
@@ -706,7 +721,7 @@ int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32
 int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
                           int ties, int is_signed, double* Rx_out) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 1));
   PH_REQUIRE(n >= 0 && Xp != nullptr, "colranks_csc: bad arguments");
   PH_TRY(check_host_csc(Xp, nullptr, 0, n));
   const int64_t zx = Xp[n];
@@ -728,7 +743,7 @@ int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx
 int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                                 int32_t g, int32_t n, int ties, int is_signed, double* R_out) {
   PH_CTX(ctx);
-  PH_TRY(check_ties(ties));
+  PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && Xp != nullptr, "colranks_csc_dense: bad arguments");
   PH_TRY(check_host_csc(Xp, Xi, g, n));
   if ((int64_t)g * n == 0) return PLAIDHIP_OK;

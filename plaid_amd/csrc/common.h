@@ -71,6 +71,8 @@ struct plaidhip_ctx {
   double* d_sel = nullptr;        // {0 or -1, max, smallest > 0} of the stored values of a sparse X (scatter kernel's choice of accumulators)
   uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
   uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
+  void* tie_scratch = nullptr;    // ties.method first / last / dense: two scratch columns per column (kernels_rank.hip)
+  size_t tie_scratch_bytes = 0;
   void* rank_scratch = nullptr;   // value-partitioned ranking of columns beyond the LDS (kernels_rank.hip), grown on demand
   size_t rank_scratch_bytes = 0;
   int debug_fail_crossprod = 0;   // test hook (plaidhip_debug_sharded_on_one_device): this context's shard fails in the crossprod phase

@@ -744,9 +744,135 @@ static int launch_colranks_partitioned(plaidhip_ctx* ctx, const double* X, int64
                         fb_grid, 0, fb_list, fb_count);
 }
 
+
+// ---- ties.method = "first" / "last" / "dense" (matrixStats::colRanks and base::rank take them: R/plaid.R:593,614-617,
+// 639-642 forward any ties.method) -------------------------------------------------------------------------------------
+// Composed from the min-rank kernels, which stay the only ranking code: with lb_i = #{x_j < x_i} (min rank - 1, the same
+// for every member of a tie group and different between groups) the pairs (lb_i, i) are all distinct, and
+//     first_i = 1 + #{(lb_j, j) < (lb_i, i)}        -- the min rank of the tie-free column  y_i = lb_i * 2^26 + i
+//     last_i  = the same with  y_i = lb_i * 2^26 + (cnt - 1 - i)     (rank(c(1,1,1), ties = "last") is 3 2 1)
+//     dense_i = 1 + #{tie groups below x_i}: the first member of a group is its leader (first_i == lb_i + 1); the min rank
+//               of the column that holds lb at the leaders and NaN elsewhere IS the dense rank at the leaders (a NaN gets
+//               no rank and disturbs nobody's); the leaders leave it at slot lb of a scratch column, every member reads
+//               its group's slot.
+// y is exact in a double (lb, i < 2^26).  NaN inputs stay NaN through every pass.  Signed: the ranks of |x|, signed at the
+// end.  These methods are off the hot path (plaid's own callers use "average" and "min" only): 2 - 3 passes of the fast
+// kernels plus element-wise kernels, any column length the rank kernels take.
+constexpr double kTieShift = 67108864.0;   // 2^26
+
+struct TieCols {   // columns of a dense matrix (Xp == nullptr) or the stored values of CSC columns
+  const int32_t* Xp;
+  int32_t g, n;
+  int64_t ldx, ldr, lds;   // leading dimensions of X, R and of the scratch columns
+};
+
+template <typename F>
+__device__ __forceinline__ void tie_for_each(const TieCols& t, F f) {
+  for (int c = blockIdx.y; c < t.n; c += gridDim.y) {
+    int64_t xb, rb, sb;
+    int32_t cnt;
+    if (t.Xp != nullptr) { xb = rb = sb = t.Xp[c]; cnt = t.Xp[c + 1] - t.Xp[c]; }
+    else { xb = (int64_t)c * t.ldx; rb = (int64_t)c * t.ldr; sb = (int64_t)c * t.lds; cnt = t.g; }
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) f(xb + i, rb + i, sb, i, cnt);
+  }
+}
+
+// A = lb (NaN for a NaN input), B = the tie-free column y.  R holds sign * min rank of |x| (signed) or the min rank.
+__global__ void __launch_bounds__(256)
+tie_prep_kernel(TieCols t, const double* __restrict__ X, const double* __restrict__ R, int is_signed, int last,
+                double* __restrict__ A, double* __restrict__ B) {
+  tie_for_each(t, [&](int64_t xi, int64_t ri, int64_t sb, int32_t i, int32_t cnt) {
+    const double x = X[xi], r = R[ri];
+    // signed ranks are 0 at x == 0, whose |x| is the smallest value of the column: lb = 0
+    const double lb = (r != r) ? r : ((is_signed && x == 0.0) ? 0.0 : fabs(r) - 1.0);
+    A[sb + i] = lb;
+    B[sb + i] = lb * kTieShift + (double)(last ? cnt - 1 - i : i);
+  });
+}
+
+// first / last: R holds the min rank of y = the wanted rank of |x| (or x); signed: put the sign on
+__global__ void __launch_bounds__(256)
+tie_sign_kernel(TieCols t, const double* __restrict__ X, double* __restrict__ R) {
+  tie_for_each(t, [&](int64_t xi, int64_t ri, int64_t, int32_t, int32_t) {
+    const double x = X[xi], r = R[ri];
+    R[ri] = (x == 0.0) ? 0.0 : ((x < 0.0) ? -r : r);   // (NaN: neither branch, r is NaN already)
+  });
+}
+
+// dense, step 1: R holds first ranks, A the lower bounds: B = lb at the leaders, NaN elsewhere
+__global__ void __launch_bounds__(256)
+tie_leader_kernel(TieCols t, const double* __restrict__ R, const double* __restrict__ A, double* __restrict__ B) {
+  tie_for_each(t, [&](int64_t, int64_t ri, int64_t sb, int32_t i, int32_t) {
+    const double lb = A[sb + i];
+    B[sb + i] = (R[ri] == lb + 1.0) ? lb : __longlong_as_double(0x7ff8000000000000ll);
+  });
+}
+// step 2: R holds the dense rank at the leaders (NaN elsewhere): leave it at slot lb of the scratch column
+__global__ void __launch_bounds__(256)
+tie_scatter_kernel(TieCols t, const double* __restrict__ R, const double* __restrict__ A, double* __restrict__ B) {
+  tie_for_each(t, [&](int64_t, int64_t ri, int64_t sb, int32_t i, int32_t) {
+    const double d = R[ri];
+    if (d == d) B[sb + (int64_t)A[sb + i]] = d;
+  });
+}
+// step 3: every member reads its group's slot
+__global__ void __launch_bounds__(256)
+tie_gather_kernel(TieCols t, const double* __restrict__ X, const double* __restrict__ A, const double* __restrict__ B,
+                  int is_signed, double* __restrict__ R) {
+  tie_for_each(t, [&](int64_t xi, int64_t ri, int64_t sb, int32_t i, int32_t) {
+    const double lb = A[sb + i], x = X[xi];
+    double r = (lb != lb) ? lb : B[sb + (int64_t)lb];
+    if (is_signed) r = (x == 0.0) ? 0.0 : ((x < 0.0) ? -r : r);
+    R[ri] = r;
+  });
+}
+
+// `total`: number of values (dense: unused; CSC: Xp[n], which the caller reads back -- these methods are not stream-ordered)
+static int launch_colranks_composed(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, const int32_t* Xp, int32_t n,
+                                    int32_t max_len, int64_t total, int ties, int is_signed, double* R, int64_t ldr) {
+  if (n == 0 || max_len == 0) return PLAIDHIP_OK;
+  const int64_t lds = ((int64_t)g + 1) & ~1ll;
+  const size_t count = Xp != nullptr ? (size_t)total : (size_t)lds * n;
+  // two scratch columns per column (grown on demand, kept with the context)
+  if (ctx->tie_scratch_bytes < 2 * count * 8) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->tie_scratch) PH_HIP(hipFree(ctx->tie_scratch));
+    ctx->tie_scratch = nullptr;
+    ctx->tie_scratch_bytes = 0;
+    PH_HIP(hipMalloc(&ctx->tie_scratch, 2 * count * 8));
+    ctx->tie_scratch_bytes = 2 * count * 8;
+  }
+  double* A = static_cast<double*>(ctx->tie_scratch);
+  double* B = A + count;
+  auto ranks_min = [&](const double* V, int64_t ldv, int sgn, double* Out, int64_t ldo) -> int {
+    if (Xp != nullptr) return launch_colranks_csc_f64(ctx, Xp, V, n, max_len, PLAIDHIP_TIES_MIN, sgn, 1.0, Out, nullptr);
+    return launch_colranks_dense_f64(ctx, V, ldv, g, n, PLAIDHIP_TIES_MIN, sgn, 1.0, Out, ldo, nullptr);
+  };
+  TieCols t{Xp, g, n, ldx, ldr, lds};
+  const dim3 grid((unsigned)std::min<int64_t>(((int64_t)max_len + 255) / 256, 64), (unsigned)std::min(n, 16384));
+  int rc = ranks_min(X, ldx, is_signed, R, ldr);                                  // lb + 1 (with the sign when signed)
+  if (rc != PLAIDHIP_OK) return rc;
+  hipLaunchKernelGGL(tie_prep_kernel, grid, dim3(256), 0, ctx->stream, t, X, R, is_signed, ties == PLAIDHIP_TIES_LAST ? 1 : 0, A, B);
+  rc = ranks_min(B, lds, 0, R, ldr);                                              // first (or last) ranks
+  if (rc != PLAIDHIP_OK) return rc;
+  if (ties != PLAIDHIP_TIES_DENSE) {
+    if (is_signed) hipLaunchKernelGGL(tie_sign_kernel, grid, dim3(256), 0, ctx->stream, t, X, R);
+  } else {
+    hipLaunchKernelGGL(tie_leader_kernel, grid, dim3(256), 0, ctx->stream, t, R, A, B);
+    rc = ranks_min(B, lds, 0, R, ldr);                                            // dense ranks at the leaders
+    if (rc != PLAIDHIP_OK) return rc;
+    hipLaunchKernelGGL(tie_scatter_kernel, grid, dim3(256), 0, ctx->stream, t, R, A, B);
+    hipLaunchKernelGGL(tie_gather_kernel, grid, dim3(256), 0, ctx->stream, t, X, A, B, is_signed, R);
+  }
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 int launch_colranks_dense_f64(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t g, int32_t n,
                               int ties, int is_signed, double power, double* R, int64_t ldr,
                               double* colmax) {
+  if (ties >= PLAIDHIP_TIES_FIRST)   // "first" / "last" / "dense": composed from min-rank passes (power 1, no column maximum)
+    return launch_colranks_composed(ctx, X, ldx, g, nullptr, n, g, 0, ties, is_signed, R, ldr);
   // columns beyond the bucket ranker's LDS: cut by value into segments it takes (above), unless the context pins a kernel
   if (g > kMaxBucketKeys && (g + kPartTarget - 1) / kPartTarget <= kPartMax && ctx->opt_rank_kernel != 1)
     return launch_colranks_partitioned(ctx, X, ldx, g, nullptr, n, ties, is_signed, power, R, ldr, colmax);
@@ -856,6 +982,15 @@ int max_sparse_rank_column() { return kMaxBucketKeys; }
 // stream-ordered: the caller states the longest column (include/plaidhip.h), nothing is read back
 int launch_colranks_csc_f64(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n, int32_t max_col_nnz,
                             int ties, int is_signed, double power, double* Rx, double* colmax) {
+  if (ties >= PLAIDHIP_TIES_FIRST && n > 0) {   // "first" / "last": composed; needs nnz(X) on the host (one read-back)
+    int32_t ends[1] = {0};
+    int32_t first[1] = {0};
+    PH_HIP(hipMemcpyAsync(ends, Xp + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipMemcpyAsync(first, Xp, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (first[0] != 0) { set_error("colranks_csc: ties.method first / last need Xp[0] == 0"); return PLAIDHIP_EINVAL; }
+    return launch_colranks_composed(ctx, Xx, 0, max_col_nnz, Xp, n, max_col_nnz, ends[0], ties, is_signed, Rx, 0);
+  }
   // columns with more stored values than the bucket ranker's LDS holds: cut by value (launch_colranks_partitioned)
   if (n > 0 && max_col_nnz > kMaxBucketKeys && (max_col_nnz + kPartTarget - 1) / kPartTarget <= kPartMax && ctx->opt_rank_kernel != 1)
     return launch_colranks_partitioned(ctx, Xx, 0, max_col_nnz, Xp, n, ties, is_signed, power, Rx, 0, colmax);

@@ -28,10 +28,13 @@
 }
 
 .stat_code <- function(stats) match(stats[1], c("mean", "sum")) - 1L
-.ties_code <- function(ties.method) {
-  code <- match(ties.method, c("average", "min", "max"))
-  if (is.na(code)) stop("ties.method '", ties.method, "' is not built (average/min/max)")
-  code - 1L
+## ties.method is passed through like the reference does (R/plaid.R:614-617, 639-642).  `allowed`: what the function
+## behind the branch takes (match.arg there): matrixStats::colRanks all seven, base::rank no "dense",
+## sparseMatrixStats::colRanks max / average / min.  "random" is refused by the library (not a function of the input).
+.ties_all <- c("average", "min", "max", "first", "last", "dense", "random")
+.ties_code <- function(ties.method, allowed = .ties_all) {
+  ties.method <- match.arg(ties.method, allowed)
+  match(ties.method, .ties_all) - 1L
 }
 
 ## intersect + binarise (reference R/plaid.R:65-73) WITHOUT copying X: the membership pattern
@@ -147,7 +150,8 @@ sparse_colranks <- function(X, signed = FALSE, ties.method = "average") {
   .session()
   X <- methods::as(X, "CsparseMatrix")
   rX <- X
-  rX@x <- .Call("R_plaidhip_colranks_csc", X@p, as.double(X@x), .ties_code(ties.method), signed,
+  rX@x <- .Call("R_plaidhip_colranks_csc", X@p, as.double(X@x),
+                .ties_code(ties.method, c("average", "first", "last", "random", "max", "min")), signed,
                 PACKAGE = "plaidhip")
   rX
 }
@@ -156,14 +160,16 @@ colranks <- function(X, sparse = NULL, signed = FALSE, keep.zero = FALSE, ties.m
   if (is.null(sparse)) sparse <- inherits(X, "CsparseMatrix")
   if (sparse && keep.zero) return(sparse_colranks(X, signed = signed, ties.method = ties.method))
   .session()
-  if (inherits(X, "CsparseMatrix")) {
+  ## the `sparse` ARGUMENT picks the function (R/plaid.R:598-619): sparseMatrixStats::colRanks or matrixStats::colRanks
+  code <- .ties_code(ties.method, if (sparse) c("max", "average", "min") else .ties_all)
+  if (inherits(X, "CsparseMatrix") && code <= 2L) {
     ## zeros are ranked and the result is dense (sparseMatrixStats::colRanks, R/plaid.R:602-609), but the
     ## matrix goes to the device as its three CSC slots: no as.matrix(X) on the host
-    rX <- .Call("R_plaidhip_colranks_csc_dense", X@p, X@i, as.double(X@x), nrow(X), .ties_code(ties.method),
+    rX <- .Call("R_plaidhip_colranks_csc_dense", X@p, X@i, as.double(X@x), nrow(X), code,
                 signed, PACKAGE = "plaidhip")
   } else {
     D <- as.matrix(X); storage.mode(D) <- "double"
-    rX <- .Call("R_plaidhip_colranks_dense", D, .ties_code(ties.method), signed, PACKAGE = "plaidhip")
+    rX <- .Call("R_plaidhip_colranks_dense", D, code, signed, PACKAGE = "plaidhip")
   }
   dimnames(rX) <- dimnames(X)
   rX

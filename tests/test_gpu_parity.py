@@ -323,8 +323,62 @@ def test_bad_arguments_raise(hip_ctx):
     import plaid_amd
     with pytest.raises(plaid_amd.PlaidHipError):
         hip_ctx.plaid_dense(np.ones((5, 3)), np.array([0, 1], dtype=np.int32), np.array([7], dtype=np.int32))
-    with pytest.raises(plaid_amd.PlaidHipError):
-        plaid_amd.colranks(np.ones((4, 2)), ties_method="first")
+    with pytest.raises(plaid_amd.PlaidHipError):                                   # legal in R, refused: not reproducible
+        plaid_amd.colranks(np.ones((4, 2)), ties_method="random")
+    with pytest.raises(ValueError):                                                # R: match.arg error
+        plaid_amd.colranks(np.ones((4, 2)), ties_method="nonsense")
+
+
+@pytest.mark.parametrize("signed", [False, True])
+@pytest.mark.parametrize("tm", ["first", "last", "dense"])
+@pytest.mark.parametrize("g", [1, 7, 300, 4097, 20000, 20352, 25000])
+def test_colranks_ties_method_is_passed_through(hip_ctx, tm, g, signed):
+    """ties.method goes through to matrixStats::colRanks / base::rank in the reference (R/plaid.R:593,614-617,639-642):
+    "first" / "last" / "dense" composed on the device from min-rank passes -- bit-exact against scipy's ordinal / dense
+    ranks on the hard columns of the bucket ranker's own test (heavy ties, 95 % zeros, constants, NaN, +-0, infinities)"""
+    rng = np.random.default_rng(g)
+    X = _rank_cases(g, rng)
+    exp = _oracle().colranks(X, signed=signed, ties_method=tm)
+    got = hip_ctx.colranks_dense(X, tm, signed)
+    ok = ~np.isnan(X)
+    for c in range(X.shape[1]):      # NaN: the oracle's rankdata has no NA handling; the device returns NaN there and ranks the rest
+        if np.isnan(X[:, c]).any():
+            v = X[ok[:, c], c]
+            sub = _oracle().colranks(v.reshape(-1, 1), signed=signed, ties_method=tm)[:, 0]
+            assert np.isnan(got[~ok[:, c], c]).all() and np.array_equal(got[ok[:, c], c], sub), (c, tm)
+        else:
+            assert np.array_equal(got[:, c], exp[:, c]), (c, tm)
+
+
+@pytest.mark.parametrize("tm", ["first", "last"])
+def test_sparse_colranks_ties_method_first_and_last(hip_ctx, tm):
+    """sparse_colranks -> base::rank(ties.method) on the stored values of every column (R/plaid.R:631-650), ragged columns,
+    an empty one, signed and unsigned; "dense" is not a base::rank method and raises like match.arg; colranks() of a sparse
+    matrix with its zeros ranked is sparseMatrixStats::colRanks: max / average / min only"""
+    import plaid_amd
+    rng = np.random.default_rng(3)
+    g, n = 5000, 23
+    cols, vals = [], []
+    for j in range(n):
+        k = 0 if j == 5 else int(rng.integers(1, 900))
+        cols.append(np.sort(rng.choice(g, k, replace=False)))
+        vals.append(np.round(rng.normal(0, 2, k), 0))                    # heavy ties, negatives, stored zeros
+    Xp = np.concatenate([[0], np.cumsum([len(c_) for c_ in cols])]).astype(np.int32)
+    Xs = sp.csc_matrix((np.concatenate(vals), np.concatenate(cols).astype(np.int32), Xp), shape=(g, n))
+    for signed in (False, True):
+        got = plaid_amd.sparse_colranks(Xs, signed=signed, ties_method=tm).values
+        exp = _oracle().sparse_colranks(Xs, signed=signed, ties_method=tm)
+        assert np.array_equal(got.indptr, exp.indptr) and np.array_equal(got.indices, exp.indices)
+        assert np.array_equal(got.data, exp.data)
+        assert np.array_equal(plaid_amd.colranks(Xs, keep_zero=True, signed=signed, ties_method=tm).values.data, exp.data)
+    with pytest.raises(ValueError):
+        plaid_amd.sparse_colranks(Xs, ties_method="dense")
+    with pytest.raises(ValueError):
+        plaid_amd.colranks(Xs, ties_method=tm)                          # sparse = TRUE: sparseMatrixStats takes max / average / min
+    # sparse = FALSE on a dgCMatrix: as.matrix(X) through matrixStats, every method legal (R/plaid.R:611-617)
+    D = Xs.toarray()
+    for t2 in (tm, "dense"):
+        assert np.array_equal(plaid_amd.colranks(Xs, sparse=False, ties_method=t2).values, _oracle().colranks(D, ties_method=t2))
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE C2)

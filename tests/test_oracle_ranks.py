@@ -71,3 +71,25 @@ def test_chunked_crossprod_chunk_boundary(synth):
     # auto chunk width: round(0.8 * (2^31-1) / ncol(x))  (R/plaid.R:103-104)
     assert po._r_round(0.8 * po.INT_MAX / 5000) == 343597
     assert po._r_round(0.8 * po.INT_MAX / 50000) == 34360
+
+
+def test_oracle_first_last_dense_against_their_definitions():
+    """ties.method "first" / "last" / "dense" (passed through by R/plaid.R:614-617, 639-642) restated by counting:
+    first_i = 1 + #{x_j < x_i} + #{j < i, x_j == x_i}; last_i = #{x_j <= x_i} - #{j < i, x_j == x_i};
+    dense_i = #{distinct values <= x_i}; and R's documented example rank(c(2, 1, 2, 1, 3, 2))."""
+    import numpy as np
+    from oracle import plaid_oracle as po
+    x = np.array([2.0, 1, 2, 1, 3, 2])
+    assert po.colranks(x.reshape(-1, 1), ties_method="first")[:, 0].tolist() == [3, 1, 4, 2, 6, 5]
+    assert po.colranks(x.reshape(-1, 1), ties_method="last")[:, 0].tolist() == [5, 2, 4, 1, 6, 3]
+    assert po.colranks(x.reshape(-1, 1), ties_method="dense")[:, 0].tolist() == [2, 1, 2, 1, 3, 2]
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 17, 300):
+        v = np.round(rng.normal(0, 1.5, n), 0)
+        lt = (v[None, :] < v[:, None]).sum(axis=1)
+        le = (v[None, :] <= v[:, None]).sum(axis=1)
+        before = np.array([(v[:i] == v[i]).sum() for i in range(n)])
+        assert np.array_equal(po.colranks(v.reshape(-1, 1), ties_method="first")[:, 0], lt + 1 + before)
+        assert np.array_equal(po.colranks(v.reshape(-1, 1), ties_method="last")[:, 0], le - before)
+        assert np.array_equal(po.colranks(v.reshape(-1, 1), ties_method="dense")[:, 0],
+                              np.array([len(np.unique(v[v <= t])) for t in v]))
