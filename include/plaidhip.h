@@ -101,7 +101,8 @@ enum plaidhip_option {
   PLAIDHIP_OPT_RANKS_F32 = 4,          /* staging of RANK inputs in the crossprod, all three exact and bit-identical:
                                           2 (default) u16 (2 * rank), four samples per LDS entry, integer sums |
                                           1 fp32 staging | 0 the fp64 kernels                                        */
-  PLAIDHIP_OPT_RANK_KERNEL = 5,        /* 0 auto (default) | 1 sorting network | 2 bucket ranker                    */
+  PLAIDHIP_OPT_RANK_KERNEL = 5,        /* 0 auto (default) | 1 sorting network | 2 bucket ranker | 3 bucket ranker with
+                                          512 threads x 40 keys for columns beyond 12,288 keys (default: 1,024 x 20)  */
   PLAIDHIP_OPT_SCATTER_FIXED = 6,      /* sparse-X scatter kernel, inputs declared bounded (rank weights): 1 (default) u64
                                           fixed-point accumulators: exact integer sums, bit-reproducible | 0 fp64 atomics  */
   PLAIDHIP_OPT_SCATTER_ORDER = 7       /* sparse-X scatter kernel: 1 (default) all workgroups on one chunk of sets at a

@@ -21,7 +21,7 @@ OPTIONS = {
     "spmm_sparse_kernel": (2, {"auto": 0, "scatter": 1, "gather": 2}),
     "nt_store": (3, {"auto": -1, "off": 0, "on": 1}),
     "ranks_f32": (4, {"off": 0, "on": 1, "f64": 0, "f32": 1, "u16": 2}),   # staging of rank inputs (default 2 = u16)
-    "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2}),
+    "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2, "bucket512": 3}),
     "scatter_fixed": (6, {"off": 0, "on": 1}),
     "scatter_order": (7, {"column": 0, "chunk": 1}),
 }

@@ -256,7 +256,7 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
       ctx->opt_scatter_order = value;
       break;
     case PLAIDHIP_OPT_RANK_KERNEL:
-      PH_REQUIRE(value >= 0 && value <= 2, "set_option: rank kernel %d (0 auto, 1 network, 2 bucket)", value);
+      PH_REQUIRE(value >= 0 && value <= 3, "set_option: rank kernel %d (0 auto, 1 network, 2 bucket, 3 bucket with 512 x 40 for long columns)", value);
       ctx->opt_rank_kernel = value;
       break;
     default:

@@ -26,8 +26,8 @@ constexpr int kMaxLdsGenesPair = kLdsBytes / 16 - kPadSlotsPair;   // 10224
 constexpr int kMaxPairSlices = 8;
 // scatter kernel (sparse X): fp64 accumulators of one chunk of gene sets in LDS
 constexpr int kScatterTrash = 64;                      // accumulators behind a chunk that padded id slots add into
-constexpr int kScatterStage = 16 * 64 * 16;            // bytes: per wavefront 64 staged {segment, count, value} entries
-constexpr int kScatterChunk = 20480 - kScatterTrash - kScatterStage / 8;   // 160 KiB / 8, less trash slots and staging
+constexpr int kScatterBlock = 1024;                    // threads per workgroup of the scatter kernel (512: two workgroups per CU, measured slower)
+constexpr int kScatterChunk = 20480 / (1024 / kScatterBlock) - kScatterTrash;   // the workgroup's share of 160 KiB / 8, less the trash slots
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -156,7 +156,7 @@ struct plaidhip_scatter_plan {
   uint16_t* d_ids = nullptr;
   double* d_w = nullptr;   // per set 1/(1e-8 + size)
   double* d_k = nullptr;   // per set size
-  double* d_kw = nullptr;  // {size, 1/(1e-8 + size)} interleaved: one 16-byte load per set in the scatter kernel's epilogue
+  double* d_kw = nullptr;  // {size x weight, weight} per set, m entries for STAT_MEAN then m for STAT_SUM: one 16-byte load per set in the scatter kernel's epilogue
 #ifdef PLAIDHIP_KEEP_HOST_PLANS
   std::vector<int32_t> h_seg;    // host-only tools build (tools/plan_probe): the uploaded plan, for its checker
   std::vector<uint16_t> h_ids;

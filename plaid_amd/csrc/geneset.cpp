@@ -638,8 +638,9 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     // as few chunks as the LDS allows: every chunk is one more pass over the column's stored values.  (Dealing
     // eight smaller chunks to the eight XCDs so that an XCD's L2 holds only its share of the id lists was measured:
     // 1.7x SLOWER -- the passes are bound by their chains of dependent loads, not by L2 misses.)
-    sp.ch = std::min<int32_t>((m + 15) & ~15, kScatterChunk);   // multiple of 16: the trash slots keep their banks
-    sp.nch = (m + sp.ch - 1) / sp.ch;
+    sp.nch = (m + kScatterChunk - 1) / kScatterChunk;
+    sp.ch = (((m + sp.nch - 1) / sp.nch) + 15) & ~15;           // equal chunks; a multiple of 16: the trash slots keep their banks
+    if (sp.ch > kScatterChunk) sp.ch = kScatterChunk & ~15;
     {
       int32_t kmax = 1;
       for (int32_t j = 0; j < m; ++j) kmax = std::max(kmax, Gp[j + 1] - Gp[j]);
@@ -706,9 +707,11 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
           }
         }
         // group q = (instruction q / 4, lanes 16 * (q & 3) ..): instruction i is the low (i even) or high (i odd)
-        // half of segment i / 2; lane l holds list positions 2 l and 2 l + 1 of its segment
-        if (nins & 1)
-          for (int l = 0; l < 64; ++l) base[(size_t)(nsg - 1) * 128 + 2 * l + 1] = (uint16_t)0xffffu;
+        // half of segment i / 2; lane l holds list positions 2 l and 2 l + 1 of its segment.  An unused second
+        // instruction of the last segment keeps the trash ids every slot starts with: the kernel applies both halves of
+        // every segment without a test (a test per (value, chunk) costs more than the spare LDS atomic)
+        if (nins & 1)   // (the sequential fill above left list entries in those high halves)
+          for (int l = 0; l < 64; ++l) base[(size_t)(nsg - 1) * 128 + 2 * l + 1] = (uint16_t)(sp.ch + (l & 15));
         for (int gq = 0; gq < ngr; ++gq) {
           const int ins = gq >> 2, quarter = gq & 3, sgm = ins >> 1, half = ins & 1;
           bool used[16] = {false};
@@ -742,8 +745,16 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     if ((rc = upload(ctx, w, &sp.d_w)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, k, &sp.d_k)) != PLAIDHIP_OK) goto fail;
     {
-      std::vector<double> kw((size_t)2 * m);
-      for (int32_t j = 0; j < m; ++j) { kw[2 * (size_t)j] = k[j]; kw[2 * (size_t)j + 1] = w[j]; }
+      // per set {size x weight, weight} for each statistic (mean: weight = 1 / (1e-8 + size); sum: weight = 1): the
+      // scatter epilogue's  alpha * (sum * weight) + beta * (size * weight)  then needs no select and one product less
+      // (size * weight is the same IEEE product here as on the device)
+      std::vector<double> kw((size_t)4 * m);
+      for (int32_t j = 0; j < m; ++j) {
+        kw[2 * (size_t)j] = k[j] * w[j];
+        kw[2 * (size_t)j + 1] = w[j];
+        kw[2 * ((size_t)m + j)] = k[j];
+        kw[2 * ((size_t)m + j) + 1] = 1.0;
+      }
       if ((rc = upload(ctx, kw, &sp.d_kw)) != PLAIDHIP_OK) goto fail;
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
@@ -850,8 +861,8 @@ extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_
 #ifdef PLAIDHIP_KEEP_HOST_PLANS
 // Test hook of the host-only tools build: checks the scatter plan (gene-major id segments per chunk of sets) against the
 // pattern.  out[0] = chunks, out[1] = segments, out[2] = memberships found (each exactly once, in the list of its gene and
-// chunk), out[3] = wrong / repeated / out-of-chunk ids, out[4] = LDS atomic wave-instructions over all lists (what a
-// stored value of that gene costs), out[5] = ids that share their 8-byte bank (id mod 16) with an earlier id of the same
+// chunk), out[3] = wrong / repeated / out-of-chunk ids, out[4] = LDS atomic wave-instructions over all lists, two per
+// segment (what a stored value of that gene costs), out[5] = ids that share their 8-byte bank (id mod 16) with an earlier id of the same
 // 16-lane group of an instruction (each costs one more 2-cycle pass of that group).
 extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int64_t out[8]) {
   PH_REQUIRE(gs && out, "scatter_plan_check: null argument");
@@ -867,10 +878,6 @@ extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int
       for (int32_t sgm = sp.h_seg[cell]; sgm < sp.h_seg[cell + 1]; ++sgm) {
         const uint16_t* base = sp.h_ids.data() + (size_t)sgm * 128;
         for (int half = 0; half < 2; ++half) {
-          if (half == 1 && base[1] == 0xffffu) {     // an empty second instruction: every high half carries the mark
-            for (int l = 0; l < 64; ++l) if (base[2 * l + 1] != 0xffffu) ++wrong;
-            continue;
-          }
           ++instr;
           for (int quarter = 0; quarter < 4; ++quarter) {
             uint32_t banks = 0;

@@ -365,7 +365,7 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
   // kernel choice: the bucket ranker for every column that fits the LDS (measured); the sorting
   // network beyond, as the bucket kernel's fallback for clustered columns, and when the context asks for it
   const bool can_bucket = max_len <= kMaxBucketKeys;
-  const bool use_bucket = can_bucket && (ctx->opt_rank_kernel == 2 || (ctx->opt_rank_kernel == 0 && max_len > 256));
+  const bool use_bucket = can_bucket && (ctx->opt_rank_kernel >= 2 || (ctx->opt_rank_kernel == 0 && max_len > 256));
   // workspace: [densify scratch (CSC input, dense result)] [fallback counter + list] [global key scratch]
   int grid_cap = n;
   size_t ws_off = 0;
@@ -414,13 +414,18 @@ static int launch_ranks(plaidhip_ctx* ctx, const double* Xv, int64_t ldx, int32_
   a.dbg = g_rank_dbg;
 #endif
   int rc;
-  // 512 threads x 40 keys for a 20k-gene column: 1,024 threads would cap the kernel at 128 registers, short of
-  // the 120 a thread needs for its keys and their state alone
+  // a 20k-gene column fills the CU's LDS, so ONE workgroup runs per CU: with 1,024 threads x 20 keys it brings four
+  // wavefronts per SIMD instead of the two of 512 threads x 40 keys, and the kernel -- 46 % of its wave cycles waiting, its
+  // LDS active 21 % of the time (profiles/r03i_pmc_c4_summary.txt) -- has something to hide its latencies with.  The
+  // 128-register cap of 1,024 threads costs 19 spilled registers; measured all the same (tools/bench_rank.py, 8,192 columns
+  // x 20,000 genes): 1.55 against 1.94 ms tie-free, 1.81 / 2.24 ms with the fused power, 1.62 / 2.02 ms rounded values,
+  // 2.27 / 2.67 ms with 95 % zeros.  PLAIDHIP_OPT_RANK_KERNEL = 3 keeps the 512 x 40 shape for comparison.
   if (max_len <= 2048) rc = launch_bucket<256, 8>(ctx, a, max_len, grid_cap);
   else if (max_len <= 4096) rc = launch_bucket<256, 16>(ctx, a, max_len, grid_cap);
   else if (max_len <= 8192) rc = launch_bucket<512, 16>(ctx, a, max_len, grid_cap);
   else if (max_len <= 12288) rc = launch_bucket<512, 24>(ctx, a, max_len, grid_cap);
-  else rc = launch_bucket<512, 40>(ctx, a, max_len, grid_cap);
+  else if (ctx->opt_rank_kernel == 3) rc = launch_bucket<512, 40>(ctx, a, max_len, grid_cap);   // (A/B: two waves per SIMD)
+  else rc = launch_bucket<1024, 20>(ctx, a, max_len, grid_cap);
   if (rc != PLAIDHIP_OK) return rc;
   // columns the bucket kernel gave up on (clustered values): a small persistent grid reads the device-side list
   const int fb_grid = grid_cap < ctx->num_cu ? grid_cap : ctx->num_cu;

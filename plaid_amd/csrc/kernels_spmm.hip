@@ -709,6 +709,20 @@ spmm_colpair_f64(SpmmPairArgs a) {
 // range per lane) and walks them eight at a time with two 256-byte id segments per value in
 // flight.  At 5 % density this is ~20x fewer LDS operations than gathering every membership.
 // Sums are accumulated in arrival order, so the last bits differ from run to run (fp64, ~1e-16).
+// raw buffer loads: address = descriptor base + per-lane VGPR offset + SCALAR offset -- a wave-uniform part of the address
+// costs no vector instruction (a global load wants the whole address in vector registers or a 64-bit scalar base per load)
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+__device__ int32_t raw_buffer_load_i32(i32x4 rsrc, int32_t voffset, int32_t soffset, int32_t aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ __forceinline__ i32x4 make_raw_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  i32x4 r;
+  r.x = (int32_t)(uint32_t)a;
+  r.y = (int32_t)((uint32_t)(a >> 32) & 0xffffu);   // stride 0
+  r.z = (int32_t)bytes;
+  r.w = 0x00020000;                                 // 32-bit raw data format (gfx90a / gfx94x / gfx950)
+  return r;
+}
+
 struct ScatterArgs {
   const int32_t* Xp;
   const int32_t* Xi;
@@ -717,10 +731,11 @@ struct ScatterArgs {
   int64_t dense_cells;      // auto mode: run only if 8 * nnz(X) < g * n (0 = always run)
   const int32_t* seg;
   const uint16_t* ids;
+  uint32_t ids_bytes;
   int32_t dummy_seg;
   const double* w;
   const double* k;
-  const f64x2* kw;           // {size, 1/(1e-8 + size)} per set
+  const f64x2* kw;           // {size x weight, weight} per set for this launch's statistic
   int32_t stat, nt_store;
   double alpha, beta;
   const double* alpha_div;
@@ -741,8 +756,14 @@ struct ScatterArgs {
   const double* sel;
   int32_t sel_want;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
+  int32_t abl;               // tools/ build: 1 no LDS atomics | 2 no id loads (synthetic conflict-free ids) | 3 no score stores | 4 = 1 + 2 | 5 no walk
 };
 
+#ifdef PLAIDHIP_DIAG
+#define PH_SC_ABL(k) (a.abl == (k) || (a.abl == 4 && ((k) == 1 || (k) == 2)))
+#else
+#define PH_SC_ABL(k) false
+#endif
 #ifdef PLAIDHIP_DIAG
 #define PH_SC_STAMP(k)                                                                \
   do {                                                                                 \
@@ -792,9 +813,10 @@ __device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded,
   xmax_out = xmax;
   return ok;
 }
-template <bool FIXED>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
+template <bool FIXED, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
 spmm_scatter_csc_f64(ScatterArgs a) {
+  constexpr int NW = BLOCK / 64;   // wavefronts of the workgroup
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* acc = reinterpret_cast<double*>(smem_raw);
   if (a.dense_cells != 0 && ((int64_t)a.Xp[a.n] - a.Xp[0]) * 8 >= a.dense_cells) return;   // the gather kernel takes this input
@@ -812,26 +834,32 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t f = 0;
+  double vmin = INFINITY, vamin = INFINITY;   // smallest score / smallest magnitude this lane wrote (NaN skipped)
+  uint32_t nnan = 0;                          // NaN scores this lane wrote
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
-  const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
   double fx_scale = 1.0, fx_inv = 1.0;
   if constexpr (FIXED) {   // (only ever launched with sel_want == 1: every stored value lies in [0, xmax] and is finite)
     fx_scale = ldexp(1.0, fx_e);
     fx_inv = ldexp(1.0, -fx_e);
   }
-  for (int i = tid; i < a.ch + kScatterTrash; i += 1024) acc[i] = 0.0;   // (all-zero bits: 0 in either number format)
+  for (int i = tid; i < a.ch + kScatterTrash; i += BLOCK) acc[i] = 0.0;   // (all-zero bits: 0 in either number format)
   __syncthreads();
   const uint32_t* __restrict__ idw = reinterpret_cast<const uint32_t*>(a.ids);   // two u16 ids per lane and load
-  // one dword = two u16 accumulator ids per lane -> two ds_add_f64 wave-instructions.  No compare and no branch
-  // per lane: padded slots hold the id of a trash accumulator behind the chunk (geneset.cpp); a segment whose
-  // second instruction is empty carries 0xffff in every high half (tested once, on lane 0's dword, wave-uniform).
+  const int lane_i = lane;
+  const int32_t loff_b = lane * 4;
+  // buffer descriptor of the id lists: base, no stride, size in bytes (loads past it return 0), raw dword format
+  const i32x4 ids_rsrc = make_raw_rsrc(a.ids, a.ids_bytes);
+  // one dword = two u16 accumulator ids per lane -> two ds_add wave-instructions.  No compare and no branch, per lane or
+  // per wavefront: padded slots -- a whole empty second instruction included -- hold ids of trash accumulators behind the
+  // chunk, on 16 different banks per 16 lanes (geneset.cpp).  (Round 3 marked an empty second instruction with 0xffff and
+  // skipped it: a v_readfirstlane, a compare and a branch per (value, chunk) to save an atomic the LDS has room for.)
   // The accumulators start at LDS address 0, so id << 3 IS the LDS address.  (Plain C on purpose: next to an inline-asm
   // statement hipcc stops counting vmcnt and drains every load in flight, which would serialise the double buffer.)
   typedef __attribute__((address_space(3))) double lds_f64;
   typedef __attribute__((address_space(3))) unsigned long long lds_u64;
   // (FIXED: `val` carries the bits of the u64 fixed-point value in a double, see the conversion where v is set)
 #define PLAIDHIP_ADD_AT(addr_, val)                                                                              \
-  {                                                                                                              \
+  if (!PH_SC_ABL(1)) {                                                                                           \
     if constexpr (FIXED)                                                                                         \
       __hip_atomic_fetch_add(reinterpret_cast<lds_u64*>(static_cast<uintptr_t>(addr_)),                          \
                              (unsigned long long)__double_as_longlong(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
@@ -841,9 +869,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   }
 #define PLAIDHIP_SCATTER2(id2, val)                                                                              \
   {                                                                                                              \
-    PLAIDHIP_ADD_AT(((id2) & 0xffffu) << 3, val)                                                                 \
-    if (((uint32_t)__builtin_amdgcn_readfirstlane((int)(id2)) >> 16) != 0xffffu)                                 \
-      PLAIDHIP_ADD_AT(((id2) >> 16) << 3, val)                                                                   \
+    const double val_ = (val);                                                                                   \
+    PLAIDHIP_ADD_AT(off_lo(id2), val_)                                                                           \
+    PLAIDHIP_ADD_AT(off_hi(id2), val_)                                                                           \
   }
   // The id segments a wavefront has to apply are a flat work list: lane u holds stored value u of its 64 and the
   // segment range [s0, s1) of that value's gene in the current chunk; "pass" p takes segment s0 + p of every lane
@@ -878,37 +906,37 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   _Pragma("unroll") for (int u = 0; u < UN; ++u) if (u < CNT) PLAIDHIP_SCATTER2(IDV[u], VALV[u])
 
   // A wavefront applies its 64 stored values one after the other.  Per value the lanes need the value (the data of
-  // the atomic) and the first id segment of its gene in this chunk (the address of the id load): both are staged in
-  // LDS by the owning lane and read back with a wave-uniform address (one broadcast ds_read_b128) -- cross-lane
-  // broadcasts through v_readlane + SGPR bookkeeping made the kernel issue-bound (23 scalar + 12 vector instructions
-  // per segment, PMC) long before the LDS atomics were.  Segment 0 of every value goes through a static pipeline
-  // (8 loads in flight behind the 8 being applied); the few genes with more than 128 sets in the chunk walk their
-  // further segments afterwards (flattened work list, as before).
-  struct __attribute__((aligned(16))) StageEnt { int32_t s0, ns; double v; };
-  StageEnt* stg = reinterpret_cast<StageEnt*>(smem_raw + (size_t)(a.ch + kScatterTrash) * 8) + wave * 64;
+  // the atomic) and the first id segment of its gene in this chunk (the address of the id load).  Both are wave-uniform
+  // and come out of the owning lane with v_readlane at a CONSTANT lane index (the walk is unrolled over the 64 values):
+  // the segment number goes to scalar registers and becomes the scalar base of the id load, the value's two halves come
+  // back through two v_mov.  Round 3 staged {segment, count, value} in LDS and read them back with wave-uniform addresses:
+  // two broadcast reads per (value, chunk) on the one LDS pipe all sixteen wavefronts share with the atomics themselves
+  // (12k of the 65k LDS-active cycles per column, PMC) and ~20 vector instructions per (value, chunk); round 2's first
+  // version used v_readlane with a dynamic lane (ballot / ctz bookkeeping, 23 scalar + 12 vector instructions).  Segment 0
+  // of every value goes through a static pipeline (48 id loads in flight); the few genes with more than 128 sets in the
+  // chunk walk their further segments afterwards (flattened work list).
+#define PLAIDHIP_S0_OF(u) ((uint32_t)__builtin_amdgcn_readlane(s0e, (u)))
+#define PLAIDHIP_V_OF(u) readlane_f64(v, (u))
+#define PLAIDHIP_ID_LOAD(u)                                                                             \
+  (PH_SC_ABL(2) ? ((uint32_t)(2 * lane_i) | ((uint32_t)(2 * lane_i + 1) << 16))                          \
+                : (uint32_t)raw_buffer_load_i32(ids_rsrc, loff_b, (int32_t)(PLAIDHIP_S0_OF(u) << 8), 0))
 #define PLAIDHIP_WALK_SEGMENTS()                                                                       \
   {                                                                                                    \
-    stg[lane] = StageEnt{ns > 0 ? s0 : a.dummy_seg, ns, v};                                            \
+    const int s0e = ns > 0 ? s0 : a.dummy_seg;                                                         \
     PLAIDHIP_AFTER_STAGE()                                                                             \
-    const uint32_t loff = (uint32_t)lane * 4u;                                                         \
-    const unsigned char* idb = reinterpret_cast<const unsigned char*>(idw);                            \
     /* 48 id loads in flight per wavefront (three groups of 16 ahead of the group being applied): the loop was     \
-       bound by one L2 round trip per group of 8 values, not by the atomics; the values are re-read from the stage */  \
+       bound by one L2 round trip per group of 8 values, not by the atomics */                        \
     constexpr int HW = 16;                                                                             \
     uint32_t idA[HW], idB[HW], idC[HW], idD[HW];                                                       \
     const int nval = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(have)));            \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
-      idA[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[u].s0 * 256u + loff));          \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
-      idB[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[HW + u].s0 * 256u + loff));     \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
-      idC[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[2 * HW + u].s0 * 256u + loff)); \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idA[u], stg[u].v)                 \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u)                                                     \
-      idD[u] = *reinterpret_cast<const uint32_t*>(idb + ((uint32_t)stg[3 * HW + u].s0 * 256u + loff)); \
-    if (nval > HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idB[u], stg[HW + u].v) }      \
-    if (nval > 2 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idC[u], stg[2 * HW + u].v) } \
-    if (nval > 3 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idD[u], stg[3 * HW + u].v) } \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) idA[u] = PLAIDHIP_ID_LOAD(u);                       \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) idB[u] = PLAIDHIP_ID_LOAD(HW + u);                  \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) idC[u] = PLAIDHIP_ID_LOAD(2 * HW + u);              \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idA[u], PLAIDHIP_V_OF(u))         \
+    _Pragma("unroll") for (int u = 0; u < HW; ++u) idD[u] = PLAIDHIP_ID_LOAD(3 * HW + u);              \
+    if (nval > HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idB[u], PLAIDHIP_V_OF(HW + u)) }      \
+    if (nval > 2 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idC[u], PLAIDHIP_V_OF(2 * HW + u)) } \
+    if (nval > 3 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idD[u], PLAIDHIP_V_OF(3 * HW + u)) } \
     /* genes in more than 128 sets of the chunk: their segments 1, 2, ... (flattened over the lanes) */ \
     uint64_t wmask = __ballot(ns > 1);                                                                 \
     if (wmask != 0ull) {                                                                               \
@@ -928,14 +956,14 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 // its stored values, BEFORE the barrier that ends the walk: they land while the slower wavefronts finish, and the
 // epilogue behind the barrier is LDS reads, arithmetic and stores with no load latency in it (it used to be four to five
 // dependent round trips to L2 per chunk, 15 % of the kernel).
-  constexpr int kEpiSets = (kScatterChunk + 1023) / 1024;
+  constexpr int kEpiSets = (kScatterChunk + BLOCK - 1) / BLOCK;
 #define PLAIDHIP_EPI_PREFETCH()                                                                    \
   f64x2 kwv[kEpiSets];                                                                              \
   {                                                                                                 \
     int tid_e = tid;                                                                                \
     asm volatile("" : "+v"(tid_e));                                                                 \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
-      const int i = tid_e + u * 1024;                                                               \
+      const int i = tid_e + u * BLOCK;                                                              \
       kwv[u] = a.kw[j0 + (i < nj ? i : nj - 1)];                                                    \
     }                                                                                               \
   }
@@ -947,17 +975,21 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     int tid_e = tid;                                                                                \
     asm volatile("" : "+v"(tid_e));                                                                 \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
-      const int i = tid_e + u * 1024;                                                               \
+      const int i = tid_e + u * BLOCK;                                                              \
       if (i < nj) {                                                                                 \
         double sum = acc[i];                                                                        \
-        if constexpr (FIXED) sum = (double)(unsigned long long)__double_as_longlong(sum) * fx_inv;  \
+        if constexpr (FIXED) {   /* u64 -> double, one rounding: hi * 2^32 + lo as a single fma */           \
+          const unsigned long long b_ = (unsigned long long)__double_as_longlong(sum);              \
+          sum = __fma_rn((double)(uint32_t)(b_ >> 32), 4294967296.0, (double)(uint32_t)b_) * fx_inv; \
+        }                                                                                           \
         acc[i] = 0.0;                                                                               \
-        const double wj = is_mean ? kwv[u].y : 1.0;                                                 \
-        const double val = alpha * (sum * wj) + a.beta * (kwv[u].x * wj);                           \
-        __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);                        \
-        f |= (val < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                                              \
-        f |= (val == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                                            \
-        f |= (val != val) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                                             \
+        const double val = alpha * (sum * kwv[u].y) + a.beta * kwv[u].x;                            \
+        if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);     \
+        /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */ \
+        /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */       \
+        vmin = fmin(vmin, val);                                                                     \
+        vamin = fmin(vamin, fabs(val));                                                             \
+        nnan += (val != val) ? 1u : 0u;                                                             \
       }                                                                                             \
     }                                                                                               \
   }
@@ -989,7 +1021,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 // A column of nnz stored values takes nr = ceil(nnz / 1024) rounds of per = ceil(nnz / nr) values (balanced rounds:
 // 1,100 values are 2 x 550, not 1,024 + 76); inside a round the values are dealt to the wavefronts in groups of 16
 // (group i of the round goes to wavefront i mod 16), so every wavefront applies the same number of groups +- 1.
-#define PLAIDHIP_ITEM_ROUNDS(q0_, q1_) (((q1_) - (q0_) + 1023) >> 10 > 1 ? ((q1_) - (q0_) + 1023) >> 10 : 1)
+#define PLAIDHIP_ITEM_ROUNDS(q0_, q1_) (((q1_) - (q0_) + BLOCK - 1) / BLOCK > 1 ? ((q1_) - (q0_) + BLOCK - 1) / BLOCK : 1)
 #define PLAIDHIP_ITEM_NEXT(c_, ch_, r_, q0_, q1_)                                                       \
   if (c_ < a.n) {                                                                                       \
     if (r_ + 1 < PLAIDHIP_ITEM_ROUNDS(q0_, q1_)) {                                                      \
@@ -1018,7 +1050,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     const int per_ = nr_ == 1 ? nnz_ : (nnz_ + nr_ - 1) / nr_;                                          \
     const int lo_ = (r_) * per_;                                                                        \
     const int cnt_ = nnz_ - lo_ < per_ ? nnz_ - lo_ : per_;                                             \
-    const int i_ = ((((lane >> 4) << 4) + wave) << 4) + (lane & 15);                                    \
+    const int i_ = (((lane >> 4) * NW + wave) << 4) + (lane & 15);                                      \
     have_ = i_ < cnt_;                                                                                  \
     qi_ = (q0_) + (have_ ? lo_ + i_ : 0);                                                               \
   }
@@ -1071,7 +1103,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     }
 #define PLAIDHIP_AFTER_STAGE()
     PH_SC_STAMP(0);
-    if (__ballot(have) != 0ull) {   // (a wavefront without a value in this round has nothing to apply)
+    if (__ballot(have) != 0ull && !PH_SC_ABL(5)) {   // (a wavefront without a value in this round has nothing to apply)
       PLAIDHIP_WALK_SEGMENTS()
     }
 #undef PLAIDHIP_AFTER_STAGE
@@ -1107,11 +1139,15 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_ASM_LOAD_CELL
 #ifdef PLAIDHIP_DIAG
   if (a.dbg != nullptr && (tid & 63) == 0)
-    for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * 16 + wave) * 8 + k] = t_ph[k];
+    for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = t_ph[k];
 #endif
 #undef PLAIDHIP_WALK_SEGMENTS
+#undef PLAIDHIP_S0_OF
+#undef PLAIDHIP_V_OF
+#undef PLAIDHIP_ID_LOAD
 #undef PLAIDHIP_CHUNK_EPILOGUE
 #undef PLAIDHIP_EPI_PREFETCH
+  f |= (vmin < 0.0 ? PLAIDHIP_FLAG_HAS_NEG : 0u) | (vamin == 0.0 ? PLAIDHIP_FLAG_HAS_ZERO : 0u) | (nnan ? PLAIDHIP_FLAG_HAS_NAN : 0u);
   publish_flags(f, a.flags);
 #undef PLAIDHIP_ADD_AT
 #undef PLAIDHIP_SCATTER2
@@ -1156,10 +1192,11 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   a.dense_cells = auto_select ? (int64_t)gs->g * n : 0;
   a.seg = sp.d_seg;
   a.ids = sp.d_ids;
+  a.ids_bytes = (uint32_t)std::min<uint64_t>(((uint64_t)sp.nseg + 1) * 256, 0xffffffffull);
   a.dummy_seg = (int32_t)sp.nseg;
   a.w = sp.d_w;
   a.k = sp.d_k;
-  a.kw = reinterpret_cast<const f64x2*>(sp.d_kw);
+  a.kw = reinterpret_cast<const f64x2*>(sp.d_kw) + (stat == PLAIDHIP_STAT_MEAN ? 0 : gs->m);
   a.stat = stat;
   a.alpha = alpha;
   a.beta = beta;
@@ -1169,8 +1206,9 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   a.flags = flags;
 #ifdef PLAIDHIP_DIAG
   a.dbg = g_dbg;
+  a.abl = g_ablate > 100 ? g_ablate - 100 : 0;
 #endif
-  const size_t smem = (size_t)(sp.ch + kScatterTrash) * sizeof(double) + kScatterStage;
+  const size_t smem = (size_t)(sp.ch + kScatterTrash) * sizeof(double);
   {
     // the kernel reserves v120..v125 by hand (amdgpu_num_vgpr + one clobber): if a toolchain ever sized its register
     // file differently it could not be launched with 1,024 threads -- say so here instead of failing at the launch
@@ -1178,33 +1216,33 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
     if (checked.load(std::memory_order_acquire) == 0) {
       hipFuncAttributes fa{};
       hipFuncAttributes fb{};
-      PH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<false>)));
-      PH_HIP(hipFuncGetAttributes(&fb, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<true>)));
+      PH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<false, kScatterBlock>)));
+      PH_HIP(hipFuncGetAttributes(&fb, reinterpret_cast<const void*>(&spmm_scatter_csc_f64<true, kScatterBlock>)));
       if (fb.numRegs > fa.numRegs) fa.numRegs = fb.numRegs;
       if (fb.maxThreadsPerBlock < fa.maxThreadsPerBlock) fa.maxThreadsPerBlock = fb.maxThreadsPerBlock;
-      if (fa.maxThreadsPerBlock < 1024 || fa.numRegs > 128) {
-        set_error("spmm_scatter_csc_f64 was built with %d registers (max %d threads per workgroup): it needs <= 128 at 1,024 "
-                  "threads; rebuild with the toolchain of the Makefile", fa.numRegs, fa.maxThreadsPerBlock);
+      if (fa.maxThreadsPerBlock < kScatterBlock || fa.numRegs > 128) {
+        set_error("spmm_scatter_csc_f64 was built with %d registers (max %d threads per workgroup): it needs <= 128 (sixteen "
+                  "wavefronts per CU); rebuild with the toolchain of the Makefile", fa.numRegs, fa.maxThreadsPerBlock);
         return PLAIDHIP_EUNSUPPORTED;
       }
       checked.store(1, std::memory_order_release);
     }
   }
-  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<false>));
-  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<true>));
-  int per_cu = (int)(kLdsBytes / (smem ? smem : 1));
-  if (per_cu > 2) per_cu = 2;
-  if (per_cu < 1) per_cu = 1;
-  int grid = ctx->num_cu * per_cu;
+  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<false, kScatterBlock>));
+  PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<true, kScatterBlock>));
+  // TWO workgroups of 512 threads per CU, each with half the LDS: while one is in its barriers and chunk epilogue (45 % of
+  // an item with one 1,024-thread workgroup per CU: tools/bench_spmm.py --kernel c3 --ablate 105) the other one's walk
+  // keeps the LDS atomic unit busy
+  int grid = ctx->num_cu * (1024 / kScatterBlock);
   if (grid > n) grid = n;
   if (try_fixed) {
     a.sel = ctx->d_sel;
     a.sel_want = 1;
-    hipLaunchKernelGGL(spmm_scatter_csc_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+    hipLaunchKernelGGL((spmm_scatter_csc_f64<true, kScatterBlock>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
     a.sel_want = 2;
-    hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+    hipLaunchKernelGGL((spmm_scatter_csc_f64<false, kScatterBlock>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
   } else {
-    hipLaunchKernelGGL(spmm_scatter_csc_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
+    hipLaunchKernelGGL((spmm_scatter_csc_f64<false, kScatterBlock>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
@@ -2011,7 +2049,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
                         bool bounded, const double* xmax_dev, double xmax_host) {
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
-  if ((g_ablate == 0 || g_ablate == 100) && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
+  if ((g_ablate == 0 || g_ablate >= 100) && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
     // sparse-aware scatter or dense-work gather.  With nnz(X) from the caller the choice is made here (one
     // launch); without it (nnz < 0: only the device knows) both are enqueued and the one that does not apply
     // returns at once.

@@ -805,6 +805,9 @@ def test_bucket_ranker_matches_oracle_on_hard_columns(pinned_ctx, g):
             got = pinned_ctx(rank_kernel="bucket").colranks_dense(X, tm, signed)
             ref = pinned_ctx(rank_kernel="network").colranks_dense(X, tm, signed)
             assert np.array_equal(got, ref, equal_nan=True), (g, tm, signed)
+            if g > 12288:   # the long-column shape before round 4 (512 threads x 40 keys), kept as an option
+                alt = pinned_ctx(rank_kernel="bucket512").colranks_dense(X, tm, signed)
+                assert np.array_equal(alt, ref, equal_nan=True), (g, tm, signed)
             assert np.array_equal(got[:, ok], c_oracle.colranks_dense(X[:, ok], tm, signed)), (g, tm, signed)
     # sparse ranks (stored values only) through the same kernel
     if g >= 64:
@@ -825,8 +828,9 @@ def test_bucket_ranker_power_and_colmax(pinned_ctx):
     rn = [str(k) for k in range(g)]
     G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
     for alpha in (0.25, 0.5, 1.0, 0.3):
-        outs = [pinned_ctx(rank_kernel=k).ssgsea_dense(X, Gp, Gi, alpha) for k in ("bucket", "network")]
+        outs = [pinned_ctx(rank_kernel=k).ssgsea_dense(X, Gp, Gi, alpha) for k in ("bucket", "network", "bucket512")]
         np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12, atol=1e-14)
+        assert np.array_equal(outs[0], outs[2])
         close(outs[0], _oracle().replaid_ssgsea(X, rn, G, rn, alpha=alpha))
 
 

@@ -37,7 +37,7 @@ def main():
         ctx.lib.plaidhip_debug_set_rank_stamps.argtypes = [ctypes.c_void_p]
         ctx.lib.plaidhip_debug_set_rank_stamps(dbg.data_ptr())
     for name, Xd in data.items():
-        for kern in ("bucket", "network"):
+        for kern in ("bucket", "bucket512", "network"):
             for power in (1.0, 1.25):
                 ctx.set_option("rank_kernel", kern)
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
@@ -50,7 +50,7 @@ def main():
                 torch.cuda.synchronize()
                 ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
                 line = f"{name:18s} {kern:8s} power {power:4.2f}: {ms:8.3f} ms  {g * n / ms / 1e6:8.2f} Gkeys/s  {16.0 * g * n / ms / 1e6:7.1f} GB/s algorithmic"
-                if diag and kern == "bucket":
+                if diag and kern.startswith("bucket"):
                     t = dbg.cpu().numpy().astype(np.float64).sum(axis=0)
                     line += "  phases% " + " ".join(f"{100 * v / t.sum():.0f}" for v in t[:6])
                 print(line, flush=True)
