@@ -353,8 +353,9 @@ def run_c2(a, env):
     lds_bytes = float(info["padded_slots"]) * 8.0 * n
     roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes), 2.0 * z * n)
     kernels = {
-        "col_medians": _roof("col_medians_wave_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms),
-        "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms),
+        "col_medians": _roof("col_medians_wave_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms,
+                             _traffic("col_medians_wave_kernel", f"{n}x{m}") if m <= 6144 else None),
+        "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"{n}x{m}")),
     }
 
     gather = _bench_gather(env, S, world * n, ("device",)) if (use_dist and not a.no_gather) else None
@@ -673,8 +674,8 @@ def run_c4(a, env):
                       "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
         "rank_keys_per_s": round(float(g) * n / (rank_ms * 1e-3), 1),
         "kernels": {
-            "colranks": _roof("colranks_bucket_kernel<512,40>", 16.0 * g * n, rank_ms,
-                              _traffic("colranks_bucket_kernel<512,40>", f"{g}xN", n)),
+            "colranks": _roof("colranks_bucket_kernel<1024,20>", 16.0 * g * n, rank_ms,
+                              _traffic("colranks_bucket_kernel<1024,20>", f"{g}xN", n)),
             "crossprod": _fp64_roof(_roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
                                           lds_bytes=float(info["padded_slots"]) * 8.0 * n), 2.0 * z * n),
             "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),

@@ -46,6 +46,9 @@ python3 tools/bench_spmm.py --kernel step --iters 10 2>&1 | grep "^step" > $out/
 python3 tools/bench_weighted.py > $out/weighted.log 2>&1
 python3 tools/bench_rank_long.py > $out/rank_long.log 2>&1
 python3 tools/bench_sparse_sing.py > $out/sparse_sing.log 2>&1
+for ab in 0 2 6 7 5; do PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --iters 10 --ablate $ab 2>&1 | grep -E "^spmm|algorithmic" | tail -2; done > $out/pair_ablations.log 2>&1
+for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 3 --ablate $ab 2>&1 | grep -E "^c3|stamps" | tail -2; done > $out/scatter_ablations.log 2>&1
+[ -x tools/ubench/inexact_flag ] && ./tools/ubench/inexact_flag > $out/ubench_inexact_flag.log 2>&1
 [ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
 [ -x tools/ubench/stream_rw ] && ./tools/ubench/stream_rw 3.2 > $out/ubench_stream_rw.log 2>&1
 python3 - "$out" <<'PY'
