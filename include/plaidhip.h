@@ -246,6 +246,28 @@ int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, co
 int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags);
 int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n,
                              int ignore_zero, const void* flags, void* med);
+/* The sparse crossprod that ALSO prepares normalize_medians (round 4).  plaidhip_dev_spmm_csc_fused_f64 is
+ * plaidhip_dev_spmm_csc_f64 (rmax == NULL) or plaidhip_dev_spmm_csc_ranks_f64 (rmax != NULL) -- same S, same flags --
+ * and, when the scatter kernel takes the input and the result has more than 6,144 sets per column, it classifies every
+ * score it writes against a bracket around the column's median (predicted from the column's mean score, which is known from
+ * X before the crossprod, and calibrated on the first 256 columns): counts below / zero / NaN and the 1-5 % of the scores
+ * inside the bracket go to a scratch the context owns.  plaidhip_dev_col_medians_resume then is plaidhip_dev_col_medians
+ * for that S: the medians are selected among the candidates -- the same two middle values, bit for bit -- and only columns
+ * whose bracket missed (or everything, if the matrix turns out to follow the other ignore.zero rule than the calibration
+ * columns) are read again by the standalone kernel.  The 40 GB second pass of config 3 is gone.  Call it after the flag
+ * words are final (a sample-sharded host all-reduces them in between) and before S is changed; with any other S, or after
+ * an ineligible crossprod, it simply is plaidhip_dev_col_medians.  nnz must be the caller's true count (>= 0) for the
+ * fused form to apply.  Stream-ordered, no host round trip.                                                          */
+int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp, const void* Xi,
+                                    const void* Xx, int32_t n, int64_t nnz, int stat, double alpha, const void* alpha_div,
+                                    double beta, void* S, int64_t lds, void* flags, const void* rmax);
+int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
+                                    const void* flags, void* med);
+/* what the last fused crossprod of this context left behind (tests, tools): info[0] = its number of columns (0: it ran the
+ * plain route), info[1] = device pointer to int32 status[n] (after ..._resume: 1 = median selected from the candidates,
+ * 0 = the standalone kernel computed it), info[2] = device pointer to the calibration {offset, half width, ignore-zero},
+ * info[3] = 1 while a resume is pending.                                                                              */
+int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]);
 int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[2]: sum, #non-NaN */);
 int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,
                                const void* med, double add, const void* red);

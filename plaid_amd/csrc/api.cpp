@@ -349,6 +349,7 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->rank_scratch) hipFree(ctx->rank_scratch);
   if (ctx->tie_scratch) hipFree(ctx->tie_scratch);
+  if (ctx->fmed_buf) hipFree(ctx->fmed_buf);
   if (ctx->d_sel) hipFree(ctx->d_sel);
   for (int k = 0; k < plaidhip_ctx::kHostBufs; ++k)
     if (ctx->hbuf[k]) hipFree(ctx->hbuf[k]);
@@ -503,6 +504,43 @@ int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
                              static_cast<const double*>(Rx), n, nnz, stat, alpha, static_cast<const double*>(rmax), beta,
                              static_cast<double*>(S), lds, static_cast<uint32_t*>(flags), /*bounded=*/true,
                              static_cast<const double*>(rmax), 0.0);
+}
+
+int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp, const void* Xi,
+                                    const void* Xx, int32_t n, int64_t nnz, int stat, double alpha, const void* alpha_div,
+                                    double beta, void* S, int64_t lds, void* flags, const void* rmax) {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm_csc_fused: null geneset");
+  PH_REQUIRE(n >= 0, "spmm_csc_fused: n=%d", n);
+  PH_REQUIRE(n == 0 || (Xp != nullptr && S != nullptr), "spmm_csc_fused: null Xp/S");
+  PH_REQUIRE(lds >= gs->m, "spmm_csc_fused: lds=%lld < m=%d", (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_csc_fused: bad stat %d", stat);
+  PH_REQUIRE(rmax == nullptr || alpha_div == nullptr || alpha_div == rmax, "spmm_csc_fused: rmax and alpha_div differ");
+  const double* div = static_cast<const double*>(rmax != nullptr ? rmax : alpha_div);
+  return launch_spmm_csc_fused_f64(ctx, gs, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
+                                   static_cast<const double*>(Xx), n, nnz, stat, alpha, div, beta, static_cast<double*>(S), lds,
+                                   static_cast<uint32_t*>(flags), rmax != nullptr, static_cast<const double*>(rmax), 0.0);
+}
+
+int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
+                                    const void* flags, void* med) {
+  PH_CTX(ctx);
+  PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "col_medians_resume: bad dims m=%d n=%d lds=%lld", m, n, (long long)lds);
+  PH_REQUIRE(n == 0 || (S != nullptr && med != nullptr), "col_medians_resume: null S/med");
+  PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "col_medians_resume: ignore_zero=%d", ignore_zero);
+  PH_REQUIRE(ignore_zero >= 0 || flags != nullptr, "col_medians_resume: ignore_zero = auto needs the flag words");
+  return launch_col_medians_resume(ctx, static_cast<const double*>(S), lds, m, n, ignore_zero,
+                                   static_cast<const uint32_t*>(flags), static_cast<double*>(med));
+}
+
+int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]) {
+  PH_CTX(ctx);
+  PH_REQUIRE(info != nullptr, "fused_medians_info: null info");
+  info[0] = ctx->fmed.n;
+  info[1] = (int64_t)reinterpret_cast<intptr_t>(ctx->fmed.status);
+  info[2] = (int64_t)reinterpret_cast<intptr_t>(ctx->fmed.cal);
+  info[3] = ctx->fmed.valid ? 1 : 0;
+  return PLAIDHIP_OK;
 }
 
 int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ldx, int32_t g,

@@ -71,6 +71,22 @@ struct plaidhip_ctx {
   double* d_sel = nullptr;        // {0 or -1, max, smallest > 0} of the stored values of a sparse X (scatter kernel's choice of accumulators)
   uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
   uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
+  // medians selected inside the last sparse crossprod launch (launch_spmm_csc_fused_f64): what plaidhip_dev_col_medians_resume
+  // needs to finish them.  The scratch holds, per sample column: the predicted mean, the status word, per (chunk, wavefront)
+  // four counts and a slice of candidate scores.
+  void* fmed_buf = nullptr;
+  size_t fmed_bytes = 0;
+  struct fused_medians {
+    bool valid = false;
+    const double* S = nullptr;
+    int64_t lds = 0;
+    int32_t m = 0, n = 0, nslice = 0, capc = 0;
+    double* pred = nullptr;
+    double* cal = nullptr;
+    uint32_t* cnt = nullptr;
+    unsigned long long* cand = nullptr;
+    int32_t* status = nullptr;
+  } fmed;
   void* tie_scratch = nullptr;    // ties.method first / last / dense: two scratch columns per column (kernels_rank.hip)
   size_t tie_scratch_bytes = 0;
   void* rank_scratch = nullptr;   // value-partitioned ranking of columns beyond the LDS (kernels_rank.hip), grown on demand
@@ -157,6 +173,8 @@ struct plaidhip_scatter_plan {
   double* d_w = nullptr;   // per set 1/(1e-8 + size)
   double* d_k = nullptr;   // per set size
   double* d_kw = nullptr;  // {size x weight, weight} per set, m entries for STAT_MEAN then m for STAT_SUM: one 16-byte load per set in the scatter kernel's epilogue
+  double* d_u = nullptr;   // per gene (1 / m) sum of the weights of its sets: g entries for STAT_MEAN, then g for STAT_SUM
+  double kappa[2] = {0.0, 0.0};   // (1 / m) sum_j size_j weight_j per statistic
 #ifdef PLAIDHIP_KEEP_HOST_PLANS
   std::vector<int32_t> h_seg;    // host-only tools build (tools/plan_probe): the uploaded plan, for its checker
   std::vector<uint16_t> h_ids;
@@ -247,7 +265,21 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
                                 bool auto_select, bool bounded = false, const double* xmax_dev = nullptr, double xmax_host = 0.0,
-                                int64_t nnz = -1);
+                                int64_t nnz = -1, const struct plaidhip_scatter_med* med = nullptr);
+// what the MED form of the scatter kernel needs (medians selected while the scores are written)
+struct plaidhip_scatter_med {
+  const double* pred;
+  const double* cal;
+  unsigned long long* cand;
+  uint32_t* cnt;
+  int32_t capc;
+};
+// the sparse crossprod + everything normalize_medians can know by then; launch_col_medians_resume finishes the medians
+int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                              int32_t n, int64_t nnz, int stat, double alpha, const double* alpha_div, double beta, double* S,
+                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host);
+int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
+                              const uint32_t* flags, double* med);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)
 int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, int64_t nnz_hint, double* out);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
@@ -284,7 +316,17 @@ int max_sparse_rank_column();
 // kernels_norm.hip
 int launch_minflags(plaidhip_ctx* ctx, const double* S, int64_t count, uint32_t* flags);
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
-                       int ignore_zero, const uint32_t* flags, double* med);
+                       int ignore_zero, const uint32_t* flags, double* med,
+                       // non-null (streaming kernel, m > 6,144 only): columns with status[c] != 0 already have their median
+                       const int32_t* status = nullptr);
+// medians selected inside the sparse crossprod launch (kernels_norm.hip / kernels_spmm.hip: MED)
+int launch_colmean_predict(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t n, const double* u,
+                           double alpha, const double* alpha_div, double beta_kappa, double* pred);
+int launch_median_calibrate(plaidhip_ctx* ctx, const double* medK, const double* pred, int32_t K, const uint32_t* flagsK,
+                            double* cal);
+int launch_median_select(plaidhip_ctx* ctx, const unsigned long long* cand, const uint32_t* cnt, int32_t n, int32_t nslice,
+                         int32_t capc, int32_t m, const double* cal, int ignore_zero, const uint32_t* flags, double* med,
+                         int32_t* status);
 int launch_sum(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,

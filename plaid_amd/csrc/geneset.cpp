@@ -756,6 +756,21 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
         kw[2 * ((size_t)m + j) + 1] = 1.0;
       }
       if ((rc = upload(ctx, kw, &sp.d_kw)) != PLAIDHIP_OK) goto fail;
+      // the MEAN score of a sample column without the crossprod: mean_j S[j, c] = alpha * sum_i x[i, c] u[i] + beta * kappa
+      // with u[i] = (1 / m) sum_{j containing i} weight_j and kappa = (1 / m) sum_j size_j weight_j (per statistic, like
+      // kw above).  The scatter launch that selects the column medians on the fly brackets them around this mean
+      // (kernels_norm.hip: colmean_predict_kernel).
+      std::vector<double> uv((size_t)2 * g, 0.0);
+      sp.kappa[0] = sp.kappa[1] = 0.0;
+      for (int32_t j = 0; j < m; ++j) {
+        for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) { uv[(size_t)Gi[p]] += w[j]; uv[(size_t)g + Gi[p]] += 1.0; }
+        sp.kappa[0] += k[j] * w[j];
+        sp.kappa[1] += k[j];
+      }
+      for (double& x : uv) x /= (double)m;
+      sp.kappa[0] /= (double)m;
+      sp.kappa[1] /= (double)m;
+      if ((rc = upload(ctx, uv, &sp.d_u)) != PLAIDHIP_OK) goto fail;
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
@@ -787,6 +802,7 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   hipFree(gs->scatter.d_w);
   hipFree(gs->scatter.d_k);
   hipFree(gs->scatter.d_kw);
+  hipFree(gs->scatter.d_u);
   hipFree(gs->pair.d_slices);
   hipFree(gs->pair.d_partial);
   for (plaidhip_pair_slice& d : gs->pair.slices) {

@@ -1340,7 +1340,7 @@ __global__ void __launch_bounds__(256, 4)   // four workgroups per CU is what th
 col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
                           int ignore_zero_mode, const uint32_t* __restrict__ flags,
                           double* __restrict__ med, unsigned long long* __restrict__ cand_all, int32_t ccap,
-                          unsigned long long* __restrict__ dbg) {
+                          unsigned long long* __restrict__ dbg, const int32_t* __restrict__ status = nullptr) {
 #ifdef PLAIDHIP_DIAG
 #define PH_SSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - tl; tl = t_; }
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
@@ -1363,6 +1363,7 @@ col_medians_stream_kernel(const double* __restrict__ S, int64_t lds, int32_t m, 
   // this wavefront's candidate list in global memory (see the sampled start below)
   unsigned long long* cand = cand_all != nullptr ? cand_all + (size_t)(blockIdx.x * 4 + wave) * (size_t)ccap : nullptr;
   for (int c = blockIdx.x * 4 + wave; c < n; c += nwaves) {
+    if (status != nullptr && status[c] != 0) continue;   // (wave-uniform) its median came out of the crossprod launch
     const double* sc = S + (int64_t)c * lds;
     uint32_t cnt = 0, k_lo = 0, k_hi = 0, k = 0, count = 0;
     uint32_t ncand = 0;          // keys of the sample interval written to `cand` by the sampled start (0: none / overflow)
@@ -1728,8 +1729,175 @@ static void launch_radix(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_
                      m, n, ignore_zero, flags, med);
 }
 
+// ---- medians selected while the sparse crossprod writes the scores (spmm_scatter_csc_f64<.., MED>, kernels_spmm.hip) ----
+// 1. the mean score of every column before the crossprod: alpha * sum_i x[i, c] u[i] + beta * kappa (geneset.cpp: u, kappa)
+__global__ void __launch_bounds__(256)
+colmean_predict_kernel(const int32_t* __restrict__ Xp, const int32_t* __restrict__ Xi, const double* __restrict__ Xx, int32_t n,
+                       const double* __restrict__ u, double alpha, const double* __restrict__ alpha_div, double beta_kappa,
+                       double* __restrict__ pred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double al = alpha_div != nullptr ? alpha / *alpha_div : alpha;
+  for (int c = blockIdx.x * 4 + wave; c < n; c += gridDim.x * 4) {
+    double s = 0.0;
+    for (int q = Xp[c] + lane; q < Xp[c + 1]; q += 64) s += Xx[q] * u[Xi[q]];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) pred[c] = al * s + beta_kappa;
+  }
+}
+
+// 2. calibration on the first K <= 256 columns (crossprod + standalone medians of those ran before), ROBUST against odd
+//    columns among them (empty cells, outliers, NaN): offset = the MEDIAN of (column median - predicted mean), half width =
+//    2.3 x the 90th percentile of the absolute deviations from it (normal deviates: 1.645 sigma -> a bracket of ~3.8 sigma
+//    either side, 1-5 % of a column's scores); the ignore-zero rule of the sample is what the bracket is calibrated for.
+//    Columns outside the bracket are simply left to the standalone kernel.
+__global__ void __launch_bounds__(256)
+median_calibrate_kernel(const double* __restrict__ medK, const double* __restrict__ pred, int32_t K,
+                        const uint32_t* __restrict__ flagsK, double* __restrict__ cal) {
+  __shared__ double s_v[256];
+  __shared__ double s_pick;
+  __shared__ int s_cnt;
+  const int t = threadIdx.x;
+  double d = INFINITY;
+  if (t < K) {
+    const double x = medK[t] - pred[t];
+    if (x == x && fabs(x) < INFINITY) d = x;
+  }
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  if (d < INFINITY) atomicAdd(&s_cnt, 1);
+  auto select = [&](double mine, int k) {   // the k-th smallest (0-based) of the 256 values, ties by thread index
+    s_v[t] = mine;
+    __syncthreads();
+    int r = 0;
+    for (int j = 0; j < 256; ++j) r += (s_v[j] < mine || (s_v[j] == mine && j < t)) ? 1 : 0;
+    if (r == k) s_pick = mine;
+    __syncthreads();
+    const double out = s_pick;
+    __syncthreads();
+    return out;
+  };
+  __syncthreads();
+  const int n_ok = s_cnt;
+  if (n_ok < 16) {   // too few usable columns: an empty bracket (every column goes to the standalone kernel)
+    if (t == 0) { cal[0] = 0.0; cal[1] = -1.0; cal[2] = 0.0; }
+    return;
+  }
+  const double off = select(d, (n_ok - 1) / 2);
+  const double dev = d < INFINITY ? fabs(d - off) : INFINITY;
+  const double q90 = select(dev, (int)(0.9 * (n_ok - 1)));
+  if (t == 0) {
+    cal[0] = off;
+    cal[1] = 2.3 * q90 + 4.0 * fabs(off) * 0x1p-52;
+    cal[2] = (flagsK[1] != 0u && flagsK[0] == 0u) ? 1.0 : 0.0;
+  }
+}
+
+// 3. one wavefront per column: the counts of its (chunk, wavefront) slices say whether both middle order statistics lie
+//    among the candidates; if so they are selected from them (<= 64 per lane, in registers: wave_radix_select) -- the same
+//    two values the standalone kernels select, averaged the same way.  status[c] = 1: med[c] is final; 0: unresolved
+//    (bracket missed, a slice overflowed, empty column, or the matrix as a whole follows the other ignore.zero rule than
+//    the calibration sample did).
+constexpr int kFmedItems = 64;   // candidates per lane: 4,096 per column
+__global__ void __launch_bounds__(64)
+median_select_kernel(const unsigned long long* __restrict__ cand, const uint4* __restrict__ cnt, int32_t n, int32_t nslice,
+                     int32_t capc, int32_t m, const double* __restrict__ cal, int ignore_zero_mode,
+                     const uint32_t* __restrict__ flags, double* __restrict__ med, int32_t* __restrict__ status) {
+  __shared__ __align__(16) uint32_t s_hist[256 + 64];
+  __shared__ uint32_t s_off[257];
+  const int lane = threadIdx.x;
+  const int iz_true = resolve_ignore_zero(ignore_zero_mode, flags);
+  const bool mode_ok = (cal[2] != 0.0) == (iz_true != 0) && cal[1] >= 0.0;
+  *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);
+  s_hist[256 + lane] = 0u;
+  wave_lds_sync();
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    // counts of the column's slices (nslice <= 256: chunks x wavefronts)
+    uint32_t below = 0, zero = 0, nan = 0, total = 0;
+    bool over = false;
+    for (int s0 = 0; s0 < nslice; s0 += 64) {
+      const int sidx = s0 + lane;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (sidx < nslice) v = cnt[(int64_t)c * nslice + sidx];
+      over |= v.w > (uint32_t)capc;
+      const uint32_t incl = wave_scan_add_u32(v.w);
+      if (sidx < nslice) s_off[sidx] = total + incl - v.w;
+      total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      uint32_t b = v.x, z = v.y, q = v.z;
+      for (int off = 32; off >= 1; off >>= 1) { b += __shfl_xor(b, off, 64); z += __shfl_xor(z, off, 64); q += __shfl_xor(q, off, 64); }
+      below += b; zero += z; nan += q;
+    }
+    if (lane == 0) s_off[nslice] = total;
+    wave_lds_sync();
+    const bool any_over = __ballot(over) != 0ull;
+    const int64_t nv = (int64_t)m - nan - (iz_true ? zero : 0);
+    const int64_t k1 = (nv - 1) >> 1, k2 = nv >> 1;
+    const bool ok = mode_ok && !any_over && nv > 0 && total <= (uint32_t)(kFmedItems * 64) && (int64_t)below <= k1 &&
+                    k2 < (int64_t)below + total;
+    if (!ok) {
+      if (lane == 0) status[c] = 0;
+      wave_lds_sync();
+      continue;
+    }
+    // gather the candidates: flat index f -> slice by binary search in the offsets
+    uint64_t key[kFmedItems];
+    uint64_t kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int t = 0; t < kFmedItems; ++t) {
+      const uint32_t f = (uint32_t)t * 64u + (uint32_t)lane;
+      uint64_t kk = ~0ull;
+      if (f < total) {
+        int lo = 0, hi = nslice;              // largest s with s_off[s] <= f
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= f) lo = mid; else hi = mid; }
+        const double v = __longlong_as_double((long long)cand[((int64_t)c * nslice + lo) * capc + (f - s_off[lo])]);
+        kk = masked_key(v, 0);
+        kmin = kk < kmin ? kk : kmin;
+        kmax = kk > kmax ? kk : kmax;
+      }
+      key[t] = kk;
+    }
+    kmin = wave_min_u64(kmin);
+    kmax = wave_max_u64(kmax);
+    const uint64_t a1 = wave_radix_select<kFmedItems>(key, (uint32_t)(k1 - below), total, kmin, kmax, s_hist, lane);
+    const uint64_t a2 = (k2 == k1) ? a1 : wave_radix_select<kFmedItems>(key, (uint32_t)(k2 - below), total, kmin, kmax, s_hist, lane);
+    if (lane == 0) {
+      med[c] = (a1 == a2) ? key_to_f64(a1) : 0.5 * (key_to_f64(a1) + key_to_f64(a2));
+      status[c] = 1;
+    }
+    wave_lds_sync();
+  }
+}
+
+int launch_colmean_predict(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t n, const double* u,
+                           double alpha, const double* alpha_div, double beta_kappa, double* pred) {
+  if (n == 0) return PLAIDHIP_OK;
+  const int cap = ctx->num_cu * 8;
+  const int need = (n + 3) / 4;
+  hipLaunchKernelGGL(colmean_predict_kernel, dim3(need < cap ? need : cap), dim3(256), 0, ctx->stream, Xp, Xi, Xx, n, u, alpha,
+                     alpha_div, beta_kappa, pred);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_median_calibrate(plaidhip_ctx* ctx, const double* medK, const double* pred, int32_t K, const uint32_t* flagsK,
+                            double* cal) {
+  hipLaunchKernelGGL(median_calibrate_kernel, dim3(1), dim3(256), 0, ctx->stream, medK, pred, K, flagsK, cal);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_median_select(plaidhip_ctx* ctx, const unsigned long long* cand, const uint32_t* cnt, int32_t n, int32_t nslice,
+                         int32_t capc, int32_t m, const double* cal, int ignore_zero, const uint32_t* flags, double* med,
+                         int32_t* status) {
+  if (n == 0) return PLAIDHIP_OK;
+  const int cap = ctx->num_cu * 16;
+  hipLaunchKernelGGL(median_select_kernel, dim3(n < cap ? n : cap), dim3(64), 0, ctx->stream, cand,
+                     reinterpret_cast<const uint4*>(cnt), n, nslice, capc, m, cal, ignore_zero, flags, med, status);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n,
-                       int ignore_zero, const uint32_t* flags, double* med) {
+                       int ignore_zero, const uint32_t* flags, double* med, const int32_t* status) {
   if (n == 0) return PLAIDHIP_OK;
   // default: register-resident radix selection up to 6,144 values per column (one wavefront per column), wave-per-column
   // streaming beyond
@@ -1790,10 +1958,10 @@ int launch_col_medians(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t 
 #endif
     if (sc == 16)
       hipLaunchKernelGGL((col_medians_stream_kernel<1024, 16>), dim3(grid), dim3(256), 0, ctx->stream, S,
-                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
+                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps(), status);
     else
       hipLaunchKernelGGL((col_medians_stream_kernel<1024, 8>), dim3(grid), dim3(256), 0, ctx->stream, S,
-                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps());
+                         lds, m, n, ignore_zero, flags, med, cand, ccap, median_stamps(), status);
   } else if (want_radix && m <= 16384) {
     if (m <= 2048) launch_radix<256, 8>(ctx, S, lds, m, n, ignore_zero, flags, med);
     else if (m <= 4096) launch_radix<256, 16>(ctx, S, lds, m, n, ignore_zero, flags, med);

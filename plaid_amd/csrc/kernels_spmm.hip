@@ -755,6 +755,14 @@ struct ScatterArgs {
   int32_t kbits, bounded;
   const double* sel;
   int32_t sel_want;
+  // MED (medians selected on the fly, see the kernel): predicted column means, {offset, half width, ignore-zero} of the
+  // calibration, per (column, chunk, wavefront) a slice of `med_capc` candidate scores and the counts {below, zero, NaN,
+  // candidates} of what that wavefront wrote of the chunk
+  const double* med_pred;
+  const double* med_cal;
+  unsigned long long* med_cand;
+  uint32_t* med_cnt;
+  int32_t med_capc;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
   int32_t abl;               // tools/ build: 1 no LDS atomics | 2 no id loads (synthetic conflict-free ids) | 3 no score stores | 4 = 1 + 2 | 5 no walk
 };
@@ -813,7 +821,16 @@ __device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded,
   xmax_out = xmax;
   return ok;
 }
-template <bool FIXED, int BLOCK>
+// MED: the launch also CLASSIFIES every score it writes for normalize_medians (R/plaid.R:561-572), so that the column
+// medians of a 50,000-set result need no second pass over 40 GB of scores.  The median of a column lies within a few 1e-4
+// of (column mean + a collection-wide offset), and the column mean is known BEFORE the crossprod (sum_i x[i, c] u[i],
+// colmean_predict_kernel); the offset and its spread are calibrated on the first columns (median_calibrate_kernel).  The
+// chunk epilogue counts the scores below the bracket [lo, hi], the exact zeros and the NaN with ballots (scalar counters)
+// and appends the 1-5 % of the scores inside the bracket to the (column, chunk) slice of a candidate list; a small kernel
+// (median_select_kernel) then picks the two middle order statistics out of <= 4,096 candidates per column -- the same values
+// the standalone kernels select, bit for bit -- and columns whose bracket missed, overflowed or met the other
+// ignore.zero rule go to the standalone kernel (device-side status, no host round trip).
+template <bool FIXED, int BLOCK, bool MED = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_vgpr(60)))   // v120.. are the prefetch registers (asm)
 spmm_scatter_csc_f64(ScatterArgs a) {
   constexpr int NW = BLOCK / 64;   // wavefronts of the workgroup
@@ -967,6 +984,46 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       kwv[u] = a.kw[j0 + (i < nj ? i : nj - 1)];                                                    \
     }                                                                                               \
   }
+#define PLAIDHIP_EPI_ONE(u, VALID)                                                                 \
+  {                                                                                                 \
+    const int i = tid_e + (u) * BLOCK;                                                              \
+    const bool valid_ = (VALID);                                                                    \
+    double val = 0.0;                                                                               \
+    if (valid_) {                                                                                   \
+      double sum = acc[i];                                                                          \
+      if constexpr (FIXED) {   /* u64 -> double, one rounding: hi * 2^32 + lo as a single fma */             \
+        const unsigned long long b_ = (unsigned long long)__double_as_longlong(sum);                \
+        sum = __fma_rn((double)(uint32_t)(b_ >> 32), 4294967296.0, (double)(uint32_t)b_) * fx_inv;  \
+      }                                                                                             \
+      acc[i] = 0.0;                                                                                 \
+      val = alpha * (sum * kwv[u].y) + a.beta * kwv[u].x;                                           \
+      if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);       \
+      /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */  \
+      /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */        \
+      vmin = fmin(vmin, val);                                                                       \
+      vamin = fmin(vamin, fabs(val));                                                               \
+      nnan += (val != val) ? 1u : 0u;                                                               \
+    }                                                                                               \
+    if constexpr (MED) {   /* single compares as ballots, combined in scalar registers */           \
+      const uint64_t live_ = __ballot(valid_);                                                      \
+      const uint64_t nan_ = __ballot(val != val) & live_;                                           \
+      const uint64_t zero_ = __ballot(val == 0.0) & live_;                                          \
+      const uint64_t part_ = live_ & ~nan_ & (med_iz ? ~zero_ : ~0ull);                             \
+      const uint64_t lt_ = __ballot(val < med_lo);                                                  \
+      const uint64_t le_ = __ballot(val <= med_hi);                                                 \
+      const uint64_t in_ = part_ & ~lt_ & le_;                                                      \
+      w_below += (uint32_t)__popcll(part_ & lt_);                                                   \
+      w_zero += (uint32_t)__popcll(zero_);                                                          \
+      w_nan += (uint32_t)__popcll(nan_);                                                            \
+      if (in_ != 0ull) {   /* (wave-uniform) append to this wavefront's own slice: no shared counter, no atomic */ \
+        const uint32_t slot_ = w_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(in_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in_, 0u)); \
+        if (((in_ >> lane) & 1ull) && slot_ < (uint32_t)a.med_capc)                                  \
+          med_slice[slot_] = (unsigned long long)__double_as_longlong(val);                         \
+        w_cand += (uint32_t)__popcll(in_);                                                          \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);   /* one set at a time: interleaved passes spill */        \
+    }                                                                                               \
+  }
 #define PLAIDHIP_CHUNK_EPILOGUE()                                                                  \
   {                                                                                                 \
     /* all factors are awaited before the first store: one whose use is skipped (i >= nj) would stay "pending" in */ \
@@ -975,21 +1032,18 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     int tid_e = tid;                                                                                \
     asm volatile("" : "+v"(tid_e));                                                                 \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
-      const int i = tid_e + u * BLOCK;                                                              \
-      if (i < nj) {                                                                                 \
-        double sum = acc[i];                                                                        \
-        if constexpr (FIXED) {   /* u64 -> double, one rounding: hi * 2^32 + lo as a single fma */           \
-          const unsigned long long b_ = (unsigned long long)__double_as_longlong(sum);              \
-          sum = __fma_rn((double)(uint32_t)(b_ >> 32), 4294967296.0, (double)(uint32_t)b_) * fx_inv; \
-        }                                                                                           \
-        acc[i] = 0.0;                                                                               \
-        const double val = alpha * (sum * kwv[u].y) + a.beta * kwv[u].x;                            \
-        if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);     \
-        /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */ \
-        /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */       \
-        vmin = fmin(vmin, val);                                                                     \
-        vamin = fmin(vamin, fabs(val));                                                             \
-        nnan += (val != val) ? 1u : 0u;                                                             \
+      /* (wave-uniform tests: all 1,024 sets of a full pass exist, only the chunk's last pass is partial -- no per-lane */ \
+      /* mask is kept alive across the unrolled passes) */                                          \
+      if ((u + 1) * BLOCK <= nj) {                                                                  \
+        PLAIDHIP_EPI_ONE(u, true)                                                                   \
+      } else if (u * BLOCK < nj) {                                                                  \
+        PLAIDHIP_EPI_ONE(u, (tid_e + u * BLOCK < nj))                                               \
+      }                                                                                             \
+    }                                                                                               \
+    if constexpr (MED) {   /* the wavefront's counts of this (column, chunk) */                     \
+      if (lane == 0) {                                                                              \
+        uint4* o_ = reinterpret_cast<uint4*>(a.med_cnt) + (((int64_t)c * a.nch + chunk) * NW + wave); \
+        *o_ = make_uint4(w_below, w_zero, w_nan, w_cand);                                           \
       }                                                                                             \
     }                                                                                               \
   }
@@ -1113,6 +1167,17 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     if (rr + 1 >= PLAIDHIP_ITEM_ROUNDS(q0, q1)) {   // last round of this (column, chunk): scale and write the chunk's scores
       const int j0 = chunk * a.ch;
       const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
+      double med_lo = 0.0, med_hi = 0.0;
+      bool med_iz = false;
+      unsigned long long* med_slice = nullptr;
+      uint32_t w_below = 0, w_zero = 0, w_nan = 0, w_cand = 0;
+      if constexpr (MED) {
+        const double ctr = a.med_pred[c] + a.med_cal[0];
+        med_lo = ctr - a.med_cal[1];
+        med_hi = ctr + a.med_cal[1];
+        med_iz = a.med_cal[2] != 0.0;
+        med_slice = a.med_cand + (((int64_t)c * a.nch + chunk) * NW + wave) * a.med_capc;
+      }
       PLAIDHIP_EPI_PREFETCH()
       __syncthreads();
       PH_SC_STAMP(2);
@@ -1146,6 +1211,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_V_OF
 #undef PLAIDHIP_ID_LOAD
 #undef PLAIDHIP_CHUNK_EPILOGUE
+#undef PLAIDHIP_EPI_ONE
 #undef PLAIDHIP_EPI_PREFETCH
   f |= (vmin < 0.0 ? PLAIDHIP_FLAG_HAS_NEG : 0u) | (vamin == 0.0 ? PLAIDHIP_FLAG_HAS_ZERO : 0u) | (nnan ? PLAIDHIP_FLAG_HAS_NAN : 0u);
   publish_flags(f, a.flags);
@@ -1163,7 +1229,8 @@ static int sparse_mode(const plaidhip_ctx* ctx) { return ctx->opt_sparse_kernel;
 int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                                 const int32_t* Xi, const double* Xx, int32_t n, int stat, double alpha,
                                 const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
-                                bool auto_select, bool bounded, const double* xmax_dev, double xmax_host, int64_t nnz) {
+                                bool auto_select, bool bounded, const double* xmax_dev, double xmax_host, int64_t nnz,
+                                const plaidhip_scatter_med* med) {
   const plaidhip_scatter_plan& sp = gs->scatter;
   ScatterArgs a{};
   // One sweep over the stored values ({all finite and >= 0, max, smallest > 0}; its range comes from Xp on the device, `nnz`
@@ -1235,6 +1302,26 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   // keeps the LDS atomic unit busy
   int grid = ctx->num_cu * (1024 / kScatterBlock);
   if (grid > n) grid = n;
+  if (med != nullptr) {   // medians selected on the fly (launch_spmm_csc_fused_f64)
+    a.med_pred = med->pred;
+    a.med_cal = med->cal;
+    a.med_cand = med->cand;
+    a.med_cnt = med->cnt;
+    a.med_capc = med->capc;
+    PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<false, kScatterBlock, true>));
+    PH_FULL_LDS(ctx, (&spmm_scatter_csc_f64<true, kScatterBlock, true>));
+    if (try_fixed) {
+      a.sel = ctx->d_sel;
+      a.sel_want = 1;
+      hipLaunchKernelGGL((spmm_scatter_csc_f64<true, kScatterBlock, true>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
+      a.sel_want = 2;
+      hipLaunchKernelGGL((spmm_scatter_csc_f64<false, kScatterBlock, true>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
+    } else {
+      hipLaunchKernelGGL((spmm_scatter_csc_f64<false, kScatterBlock, true>), dim3(grid), dim3(kScatterBlock), smem, ctx->stream, a);
+    }
+    PH_HIP(hipGetLastError());
+    return PLAIDHIP_OK;
+  }
   if (try_fixed) {
     a.sel = ctx->d_sel;
     a.sel_want = 1;
@@ -2068,6 +2155,94 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
   a.Xx = Xx;
   fill_args(ctx, a, gs, n, stat, alpha, alpha_div, beta, S, lds, flags);
   return launch_colgather<true>(ctx, gs, a);
+}
+
+// ---- the sparse crossprod that also selects the column medians of its result (normalize_medians, R/plaid.R:561-572) ----
+// Applies when the scatter kernel takes the input and the result has more sets per column than the register-resident median
+// kernel takes (m > 6,144: there the standalone median kernel is a second pass over the whole score matrix -- 40 GB at
+// config 3); everything else runs the plain crossprod and launch_col_medians_resume the standalone kernels.
+//   1. calibration: crossprod + standalone medians of the first K columns (their scores are written again below);
+//   2. the predicted mean of every column (one pass over the stored values of X);
+//   3. {offset, half width, ignore-zero rule} of the bracket from 1. and 2.;
+//   4. the crossprod of ALL columns with the classifying epilogue.
+// Nothing is read back: the decisions are taken in steps 3 / 5 on the device.  (5 = launch_col_medians_resume, after the
+// caller has all-reduced the flag words of a sharded run: selection among the candidates, standalone kernel for the rest.)
+int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp, const int32_t* Xi, const double* Xx,
+                              int32_t n, int64_t nnz, int stat, double alpha, const double* alpha_div, double beta, double* S,
+                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host) {
+  ctx->fmed.valid = false;
+  ctx->fmed.n = 0;
+  constexpr int K = 256;                         // calibration columns
+  const plaidhip_scatter_plan& sp = gs->scatter;
+  int sm = sparse_mode(ctx);
+  if (sm == 0 && nnz >= 0) sm = (nnz * 8 < (int64_t)gs->g * n) ? 1 : 2;
+  const int32_t nslice = sp.nch * (kScatterBlock / 64);
+  // candidate slots per (column, chunk, wavefront): 8,192 per column over its slices (twice what the selection takes: the
+  // chunk of the largest sets holds most of the scores near the median)
+  const int32_t kCapC = std::max<int32_t>(64, (8192 / std::max<int32_t>(nslice, 1)) & ~15);
+  const bool eligible = sm == 1 && nnz >= 0 && gs->m > 6144 && n >= 4 * K && flags != nullptr && nslice <= 256 &&
+                        g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty();
+  if (!eligible)
+    return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev, xmax_host);
+  // scratch: [pred n f64][cal 4 f64][medK K f64][flagsK 4 u32 (+pad)][status n i32 (+pad)][cnt n nslice 4 u32][cand n nslice capc u64]
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_pred = 0, o_cal = up(o_pred + (size_t)n * 8), o_medK = up(o_cal + 32), o_flagsK = up(o_medK + (size_t)K * 8),
+               o_status = up(o_flagsK + 16), o_cnt = up(o_status + (size_t)n * 4), o_cand = up(o_cnt + (size_t)n * nslice * 16),
+               total = o_cand + (size_t)n * nslice * kCapC * 8;
+  if (ctx->fmed_bytes < total) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->fmed_buf) PH_HIP(hipFree(ctx->fmed_buf));
+    ctx->fmed_buf = nullptr;
+    ctx->fmed_bytes = 0;
+    if (hipMalloc(&ctx->fmed_buf, total) != hipSuccess) {   // no room for the candidate lists: the plain route
+      (void)hipGetLastError();
+      return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev, xmax_host);
+    }
+    ctx->fmed_bytes = total;
+  }
+  char* base = static_cast<char*>(ctx->fmed_buf);
+  double* pred = reinterpret_cast<double*>(base + o_pred);
+  double* cal = reinterpret_cast<double*>(base + o_cal);
+  double* medK = reinterpret_cast<double*>(base + o_medK);
+  uint32_t* flagsK = reinterpret_cast<uint32_t*>(base + o_flagsK);
+  PH_HIP(hipMemsetAsync(flagsK, 0, 16, ctx->stream));
+  int rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, K, stat, alpha, alpha_div, beta, S, lds, flagsK, false, bounded, xmax_dev,
+                                       xmax_host, nnz / n * K + 1);
+  if (rc != PLAIDHIP_OK) return rc;
+  rc = launch_col_medians(ctx, S, lds, gs->m, K, -1, flagsK, medK);
+  if (rc != PLAIDHIP_OK) return rc;
+  const int si = stat == PLAIDHIP_STAT_MEAN ? 0 : 1;
+  rc = launch_colmean_predict(ctx, Xp, Xi, Xx, n, sp.d_u + (size_t)si * gs->g, alpha, alpha_div, beta * sp.kappa[si], pred);
+  if (rc != PLAIDHIP_OK) return rc;
+  rc = launch_median_calibrate(ctx, medK, pred, K, flagsK, cal);
+  if (rc != PLAIDHIP_OK) return rc;
+  plaidhip_scatter_med med{pred, cal, reinterpret_cast<unsigned long long*>(base + o_cand), reinterpret_cast<uint32_t*>(base + o_cnt), kCapC};
+  rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, false, bounded, xmax_dev,
+                                   xmax_host, nnz, &med);
+  if (rc != PLAIDHIP_OK) return rc;
+  ctx->fmed.valid = true;
+  ctx->fmed.S = S;
+  ctx->fmed.lds = lds;
+  ctx->fmed.m = gs->m;
+  ctx->fmed.n = n;
+  ctx->fmed.nslice = nslice;
+  ctx->fmed.capc = kCapC;
+  ctx->fmed.pred = pred;
+  ctx->fmed.cal = cal;
+  ctx->fmed.cnt = med.cnt;
+  ctx->fmed.cand = med.cand;
+  ctx->fmed.status = reinterpret_cast<int32_t*>(base + o_status);
+  return PLAIDHIP_OK;
+}
+
+int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
+                              const uint32_t* flags, double* med) {
+  const auto& f = ctx->fmed;
+  if (!(f.valid && f.S == S && f.lds == lds && f.m == m && f.n == n)) return launch_col_medians(ctx, S, lds, m, n, ignore_zero, flags, med);
+  ctx->fmed.valid = false;   // (consumed: S is about to be shifted)
+  const int rc = launch_median_select(ctx, f.cand, f.cnt, n, f.nslice, f.capc, m, f.cal, ignore_zero, flags, med, f.status);
+  if (rc != PLAIDHIP_OK) return rc;
+  return launch_col_medians(ctx, S, lds, m, n, ignore_zero, flags, med, f.status);
 }
 
 }  // namespace plaidhip

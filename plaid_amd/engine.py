@@ -148,6 +148,26 @@ class Context:
         check(self.lib.plaidhip_dev_spmm_csc_ranks_f64(self.handle, gs.handle, Xp, Xi, Rx, n, int(nnz), STAT[stat], alpha,
                                                        rmax, beta, S, lds, flags))
 
+    def dev_spmm_csc_fused(self, gs: Geneset, Xp: int, Xi: int, Xx: int, n: int, S: int, lds: int, stat="mean", alpha=1.0,
+                           beta=0.0, flags: int | None = None, alpha_div: int | None = None, rmax: int | None = None,
+                           nnz: int = -1):
+        """dev_spmm_csc (rmax None) / dev_spmm_csc_ranks (rmax set) that also classifies the scores for
+        normalize_medians while it writes them; dev_col_medians_resume then finishes the medians without a second pass
+        over S (plaidhip_dev_spmm_csc_fused_f64)"""
+        check(self.lib.plaidhip_dev_spmm_csc_fused_f64(self.handle, gs.handle, Xp, Xi, Xx, n, int(nnz), STAT[stat], alpha,
+                                                       alpha_div, beta, S, lds, flags, rmax))
+
+    def dev_col_medians_resume(self, S: int, lds: int, m: int, n: int, ignore_zero, med: int, flags: int | None = None):
+        """dev_col_medians for the S the last dev_spmm_csc_fused on this context wrote"""
+        iz = -1 if ignore_zero is None else int(bool(ignore_zero))
+        check(self.lib.plaidhip_dev_col_medians_resume(self.handle, S, lds, m, n, iz, flags, med))
+
+    def dev_fused_medians_info(self):
+        """(columns of the last fused crossprod or 0, device pointer of status[n], device pointer of the calibration, pending)"""
+        buf = (C.c_int64 * 4)()
+        check(self.lib.plaidhip_dev_fused_medians_info(self.handle, buf))
+        return int(buf[0]), int(buf[1]), int(buf[2]), bool(buf[3])
+
     def dev_crossprod_weighted(self, Wp: int, Wi: int, Wx: int, g: int, m: int, Y: int, ldy: int, n: int, S: int,
                                lds: int):
         """t(x) %*% y for a sparse x with arbitrary stored values (device dgCMatrix slots), y dense"""
