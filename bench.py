@@ -517,12 +517,14 @@ def run_sparse_ssgsea(a, env, n, label, collective):
             ev.rec(k, 1)
             if collective:
                 dist.all_reduce(gmax, op=dist.ReduceOp.MAX)                   # max(rX) over all shards
-            ctx.dev_spmm_csc_ranks(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), n, S.data_ptr(), m, gmax.data_ptr(),
-                                   "mean", 1.0, -0.5, flags.data_ptr(), nnz=nnz)
+            # the crossprod also classifies its scores for normalize_medians (plaidhip_dev_spmm_csc_fused_f64); the resume
+            # call selects the medians among the candidates and sweeps only the columns it could not resolve
+            ctx.dev_spmm_csc_fused(gs, Xp.data_ptr(), Xi.data_ptr(), Rx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
+                                   flags.data_ptr(), None, gmax.data_ptr(), nnz=nnz)
             ev.rec(k, 2)
             if collective:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX)
-            ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
             ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
             ev.rec(k, 3)
             if collective:
@@ -859,8 +861,10 @@ def run_ref_shape(a, env, name):
     steps = a.block_steps
     ev = Events(torch, stream, steps, 4)
 
-    def crossprod(fl):
-        if sparse:
+    def crossprod(fl, fused=False):
+        if sparse and fused:
+            ctx.dev_spmm_csc_fused(gs, Xp.data_ptr(), Xi.data_ptr(), Xx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0, fl, None, None, nnz=nnz)
+        elif sparse:
             ctx.dev_spmm_csc(gs, Xp.data_ptr(), Xi.data_ptr(), Xx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0, fl, None, nnz=nnz)
         else:
             ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, fl)
@@ -869,9 +873,9 @@ def run_ref_shape(a, env, name):
         with torch.cuda.stream(stream):
             flags.zero_()
             ev.rec(k, 0)
-            crossprod(flags.data_ptr())
+            crossprod(flags.data_ptr(), fused=True)
             ev.rec(k, 1)
-            ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
             ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
             ev.rec(k, 2)
             ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())

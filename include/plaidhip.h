@@ -105,8 +105,11 @@ enum plaidhip_option {
                                           512 threads x 40 keys for columns beyond 12,288 keys (default: 1,024 x 20)  */
   PLAIDHIP_OPT_SCATTER_FIXED = 6,      /* sparse-X scatter kernel, inputs declared bounded (rank weights): 1 (default) u64
                                           fixed-point accumulators: exact integer sums, bit-reproducible | 0 fp64 atomics  */
-  PLAIDHIP_OPT_SCATTER_ORDER = 7       /* sparse-X scatter kernel: 1 (default) all workgroups on one chunk of sets at a
+  PLAIDHIP_OPT_SCATTER_ORDER = 7,      /* sparse-X scatter kernel: 1 (default) all workgroups on one chunk of sets at a
                                           time (chunk, column order) | 0 column after column                              */
+  PLAIDHIP_OPT_FUSED_MEDIANS = 8       /* plaidhip_dev_spmm_csc_fused_f64 and the host pipelines on a dgCMatrix: medians
+                                          selected inside the crossprod launch 0 (default) from 1e9 scores on | 1 whenever
+                                          the shapes allow | 2 never                                                      */
 };
 int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value);
 /* Size limits of the kernels a host has to route by (so that no binding repeats them as literals).  Unknown `which`:

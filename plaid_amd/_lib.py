@@ -24,6 +24,7 @@ OPTIONS = {
     "rank_kernel": (5, {"auto": 0, "network": 1, "bucket": 2, "bucket512": 3}),
     "scatter_fixed": (6, {"off": 0, "on": 1}),
     "scatter_order": (7, {"column": 0, "chunk": 1}),
+    "fused_medians": (8, {"auto": 0, "on": 1, "off": 2}),
 }
 
 

@@ -255,6 +255,10 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
       PH_REQUIRE(value == 0 || value == 1, "set_option: scatter_order %d (0 column-major, 1 chunk-major)", value);
       ctx->opt_scatter_order = value;
       break;
+    case PLAIDHIP_OPT_FUSED_MEDIANS:
+      PH_REQUIRE(value >= 0 && value <= 2, "set_option: fused_medians %d (0 by size, 1 whenever possible, 2 never)", value);
+      ctx->opt_fused_medians = value;
+      break;
     case PLAIDHIP_OPT_RANK_KERNEL:
       PH_REQUIRE(value >= 0 && value <= 3, "set_option: rank kernel %d (0 auto, 1 network, 2 bucket, 3 bucket with 512 x 40 for long columns)", value);
       ctx->opt_rank_kernel = value;

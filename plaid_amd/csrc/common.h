@@ -27,7 +27,10 @@ constexpr int kMaxPairSlices = 8;
 // scatter kernel (sparse X): fp64 accumulators of one chunk of gene sets in LDS
 constexpr int kScatterTrash = 64;                      // accumulators behind a chunk that padded id slots add into
 constexpr int kScatterBlock = 1024;                    // threads per workgroup of the scatter kernel (512: two workgroups per CU, measured slower)
-constexpr int kScatterChunk = 20480 / (1024 / kScatterBlock) - kScatterTrash;   // the workgroup's share of 160 KiB / 8, less the trash slots
+// sets per chunk: 17 passes of the workgroup's 1,024 threads over the accumulators (136 KiB of the 160; the chunk epilogue
+// keeps one 16-byte factor pair per pass in registers, and 20 of them left none for anything else: 50,000 sets are three
+// chunks either way)
+constexpr int kScatterChunk = 17 * kScatterBlock;
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -68,6 +71,7 @@ struct plaidhip_ctx {
   int opt_rank_kernel = 0;     // 0 auto | 1 sorting network | 2 bucket ranker
   int opt_scatter_fixed = 1;   // scatter kernel: u64 fixed-point accumulators for inputs declared bounded (rank weights)
   int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
+  int opt_fused_medians = 0;   // medians selected inside the sparse crossprod: 0 by size (>= 1e9 scores) | 1 whenever possible | 2 never
   double* d_sel = nullptr;        // {0 or -1, max, smallest > 0} of the stored values of a sparse X (scatter kernel's choice of accumulators)
   uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
   uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
@@ -277,7 +281,8 @@ struct plaidhip_scatter_med {
 // the sparse crossprod + everything normalize_medians can know by then; launch_col_medians_resume finishes the medians
 int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                               int32_t n, int64_t nnz, int stat, double alpha, const double* alpha_div, double beta, double* S,
-                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host);
+                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host,
+                              int64_t nnz_choice = -1 /* what picks scatter / gather when it is not nnz itself */);
 int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
                               const uint32_t* flags, double* med);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)

@@ -1829,9 +1829,11 @@ median_select_kernel(const unsigned long long* __restrict__ cand, const uint4* _
     if (lane == 0) s_off[nslice] = total;
     wave_lds_sync();
     const bool any_over = __ballot(over) != 0ull;
-    const int64_t nv = (int64_t)m - nan - (iz_true ? zero : 0);
+    // (the crossprod launch only notes WHETHER a wavefront wrote NaN scores -- they are skipped, na.rm -- not how many: such
+    // a column is left to the standalone kernel)
+    const int64_t nv = (int64_t)m - (iz_true ? zero : 0);
     const int64_t k1 = (nv - 1) >> 1, k2 = nv >> 1;
-    const bool ok = mode_ok && !any_over && nv > 0 && total <= (uint32_t)(kFmedItems * 64) && (int64_t)below <= k1 &&
+    const bool ok = mode_ok && !any_over && nan == 0 && nv > 0 && total <= (uint32_t)(kFmedItems * 64) && (int64_t)below <= k1 &&
                     k2 < (int64_t)below + total;
     if (!ok) {
       if (lane == 0) status[c] = 0;

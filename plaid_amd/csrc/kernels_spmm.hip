@@ -723,6 +723,19 @@ __device__ __forceinline__ i32x4 make_raw_rsrc(const void* p, uint32_t bytes) {
   return r;
 }
 
+// fmin() compiles to a canonicalising v_max_f64 x, x in front of every v_min_f64 (IEEE mode: quiet a signalling NaN first);
+// the instruction alone already returns the other operand for any NaN -- two vector instructions per score saved
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_abs_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct ScatterArgs {
   const int32_t* Xp;
   const int32_t* Xi;
@@ -984,12 +997,11 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       kwv[u] = a.kw[j0 + (i < nj ? i : nj - 1)];                                                    \
     }                                                                                               \
   }
-#define PLAIDHIP_EPI_ONE(u, VALID)                                                                 \
+#define PLAIDHIP_EPI_ONE(u)                                                                        \
   {                                                                                                 \
     const int i = tid_e + (u) * BLOCK;                                                              \
-    const bool valid_ = (VALID);                                                                    \
-    double val = 0.0;                                                                               \
-    if (valid_) {                                                                                   \
+    double val = __longlong_as_double(0x7ff8000000000000ll);   /* (lanes without a set: fails every compare below) */ \
+    if (i < nj) {                                                                                   \
       double sum = acc[i];                                                                          \
       if constexpr (FIXED) {   /* u64 -> double, one rounding: hi * 2^32 + lo as a single fma */             \
         const unsigned long long b_ = (unsigned long long)__double_as_longlong(sum);                \
@@ -1000,28 +1012,26 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);       \
       /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */  \
       /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */        \
-      vmin = fmin(vmin, val);                                                                       \
-      vamin = fmin(vamin, fabs(val));                                                               \
+      vmin = min_f64(vmin, val);                                                                    \
+      vamin = min_abs_f64(vamin, val);                                                              \
       nnan += (val != val) ? 1u : 0u;                                                               \
     }                                                                                               \
-    if constexpr (MED) {   /* single compares as ballots, combined in scalar registers */           \
-      const uint64_t live_ = __ballot(valid_);                                                      \
-      const uint64_t nan_ = __ballot(val != val) & live_;                                           \
-      const uint64_t zero_ = __ballot(val == 0.0) & live_;                                          \
-      const uint64_t part_ = live_ & ~nan_ & (med_iz ? ~zero_ : ~0ull);                             \
+    if constexpr (MED) {                                                                            \
+      /* (converged again) three compares per score, as ballots -- scalar counters: below the bracket, not above it, */ \
+      /* exactly zero.  A NaN score fails all three like a lane without a set; whether the wavefront wrote any NaN */   \
+      /* comes from its lane counters at the end of the item (such a column is left to the standalone kernel).     */   \
       const uint64_t lt_ = __ballot(val < med_lo);                                                  \
       const uint64_t le_ = __ballot(val <= med_hi);                                                 \
-      const uint64_t in_ = part_ & ~lt_ & le_;                                                      \
-      w_below += (uint32_t)__popcll(part_ & lt_);                                                   \
+      const uint64_t zero_ = __ballot(val == 0.0);                                                  \
+      const uint64_t in_ = (le_ & ~lt_) & (med_iz ? ~zero_ : ~0ull);                                \
+      w_lt += (uint32_t)__popcll(lt_);                                                              \
       w_zero += (uint32_t)__popcll(zero_);                                                          \
-      w_nan += (uint32_t)__popcll(nan_);                                                            \
       if (in_ != 0ull) {   /* (wave-uniform) append to this wavefront's own slice: no shared counter, no atomic */ \
         const uint32_t slot_ = w_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(in_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in_, 0u)); \
-        if (((in_ >> lane) & 1ull) && slot_ < (uint32_t)a.med_capc)                                  \
+        if (__builtin_amdgcn_inverse_ballot_w64(in_) && slot_ < (uint32_t)a.med_capc)                \
           med_slice[slot_] = (unsigned long long)__double_as_longlong(val);                         \
         w_cand += (uint32_t)__popcll(in_);                                                          \
       }                                                                                             \
-      __builtin_amdgcn_sched_barrier(0);   /* one set at a time: interleaved passes spill */        \
     }                                                                                               \
   }
 #define PLAIDHIP_CHUNK_EPILOGUE()                                                                  \
@@ -1032,18 +1042,15 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     int tid_e = tid;                                                                                \
     asm volatile("" : "+v"(tid_e));                                                                 \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
-      /* (wave-uniform tests: all 1,024 sets of a full pass exist, only the chunk's last pass is partial -- no per-lane */ \
-      /* mask is kept alive across the unrolled passes) */                                          \
-      if ((u + 1) * BLOCK <= nj) {                                                                  \
-        PLAIDHIP_EPI_ONE(u, true)                                                                   \
-      } else if (u * BLOCK < nj) {                                                                  \
-        PLAIDHIP_EPI_ONE(u, (tid_e + u * BLOCK < nj))                                               \
-      }                                                                                             \
+      PLAIDHIP_EPI_ONE(u)                                                                           \
     }                                                                                               \
     if constexpr (MED) {   /* the wavefront's counts of this (column, chunk) */                     \
+      const uint32_t w_nan = (uint32_t)__popcll(__ballot(nnan != nnan0));   /* (lanes, not scores: only "any" matters) */ \
       if (lane == 0) {                                                                              \
         uint4* o_ = reinterpret_cast<uint4*>(a.med_cnt) + (((int64_t)c * a.nch + chunk) * NW + wave); \
-        *o_ = make_uint4(w_below, w_zero, w_nan, w_cand);                                           \
+        /* {scores below the bracket that take part, exact zeros, NaN, candidates}: with the zeros masked (ignore.zero) */ \
+        /* a zero below the bracket does not count                                                                     */ \
+        *o_ = make_uint4((med_iz && med_lo > 0.0) ? w_lt - w_zero : w_lt, w_zero, w_nan, w_cand);  \
       }                                                                                             \
     }                                                                                               \
   }
@@ -1170,7 +1177,8 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       double med_lo = 0.0, med_hi = 0.0;
       bool med_iz = false;
       unsigned long long* med_slice = nullptr;
-      uint32_t w_below = 0, w_zero = 0, w_nan = 0, w_cand = 0;
+      uint32_t w_lt = 0, w_zero = 0, w_cand = 0;
+      const uint32_t nnan0 = nnan;
       if constexpr (MED) {
         const double ctr = a.med_pred[c] + a.med_cal[0];
         med_lo = ctr - a.med_cal[1];
@@ -2169,21 +2177,28 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
 // caller has all-reduced the flag words of a sharded run: selection among the candidates, standalone kernel for the rest.)
 int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                               int32_t n, int64_t nnz, int stat, double alpha, const double* alpha_div, double beta, double* S,
-                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host) {
+                              int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host,
+                              int64_t nnz_choice) {
   ctx->fmed.valid = false;
   ctx->fmed.n = 0;
   constexpr int K = 256;                         // calibration columns
   const plaidhip_scatter_plan& sp = gs->scatter;
   int sm = sparse_mode(ctx);
-  if (sm == 0 && nnz >= 0) sm = (nnz * 8 < (int64_t)gs->g * n) ? 1 : 2;
+  if (nnz_choice < 0) nnz_choice = nnz;   // (a shard of a larger call: the density of the WHOLE matrix picks the kernel)
+  if (sm == 0 && nnz_choice >= 0) sm = (nnz_choice * 8 < (int64_t)gs->g * n) ? 1 : 2;
   const int32_t nslice = sp.nch * (kScatterBlock / 64);
   // candidate slots per (column, chunk, wavefront): 8,192 per column over its slices (twice what the selection takes: the
   // chunk of the largest sets holds most of the scores near the median)
   const int32_t kCapC = std::max<int32_t>(64, (8192 / std::max<int32_t>(nslice, 1)) & ~15);
-  const bool eligible = sm == 1 && nnz >= 0 && gs->m > 6144 && n >= 4 * K && flags != nullptr && nslice <= 256 &&
-                        g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty();
+  // worth it from ~1e9 scores on (measured: the classifying epilogue costs 0.4 ms per 1e9 scores and the calibration
+  // ~0.45 ms per call, the standalone median kernel 1.4 ms per 1e9 scores -- but it has a floor of ~1 ms as soon as a few
+  // hundred columns are left to it; at 6e8 scores, the reference's pbmc3k shape, the plain pair is faster)
+  const bool big_enough = ctx->opt_fused_medians == 1 || (int64_t)gs->m * n >= 1000000000ll;
+  const bool eligible = ctx->opt_fused_medians != 2 && big_enough && sm == 1 && nnz >= 0 && gs->m > 6144 && n >= 4 * K &&
+                        flags != nullptr && nslice <= 256 && g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty();
   if (!eligible)
-    return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev, xmax_host);
+    return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz_choice, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev,
+                               xmax_host);
   // scratch: [pred n f64][cal 4 f64][medK K f64][flagsK 4 u32 (+pad)][status n i32 (+pad)][cnt n nslice 4 u32][cand n nslice capc u64]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_pred = 0, o_cal = up(o_pred + (size_t)n * 8), o_medK = up(o_cal + 32), o_flagsK = up(o_medK + (size_t)K * 8),
@@ -2196,7 +2211,8 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
     ctx->fmed_bytes = 0;
     if (hipMalloc(&ctx->fmed_buf, total) != hipSuccess) {   // no room for the candidate lists: the plain route
       (void)hipGetLastError();
-      return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev, xmax_host);
+      return launch_spmm_csc_f64(ctx, gs, Xp, Xi, Xx, n, nnz_choice, stat, alpha, alpha_div, beta, S, lds, flags, bounded, xmax_dev,
+                                 xmax_host);
     }
     ctx->fmed_bytes = total;
   }

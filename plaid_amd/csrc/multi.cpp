@@ -384,6 +384,11 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       // in arrival order and agrees to the last bits only, as it does from run to run)
       const int64_t nnz_choice = (int64_t)((double)c.Xp[c.n] / (double)c.n * (double)nloc);
       // replaid.ssgsea: the values are rank weights in [0, max(rX)] (the scatter kernel may sum them in fixed point)
+      // (normalised results: the crossprod also classifies its scores for the medians below, launch_col_medians_resume)
+      const bool will_norm = c.method == 2 || (c.method == 0 && c.normalize);
+      if (will_norm)
+        return launch_spmm_csc_fused_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, zx, stat, a, nullptr, b,
+                                         dS.as<double>(), m, d_flags, /*bounded=*/c.method == 2, nullptr, gmax, nnz_choice);
       return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, nnz_choice, stat, a, nullptr, b,
                                  dS.as<double>(), m, d_flags, /*bounded=*/c.method == 2, nullptr, gmax);
     }
@@ -410,7 +415,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     const int ignore_zero = (sh.flags[1] != 0 && sh.flags[0] == 0) ? 1 : 0;   // min(x) == 0, R/plaid.R:556-557
     step([&]() -> int {
       if (nloc == 0) return PLAIDHIP_OK;
-      PH_TRY(launch_col_medians(ctx, dS.as<double>(), m, m, nloc, ignore_zero, nullptr, d_med));
+      PH_TRY(launch_col_medians_resume(ctx, dS.as<double>(), m, m, nloc, ignore_zero, nullptr, d_med));
       PH_HIP(hipMemcpyAsync(sh.med_all.data() + lo, d_med, (size_t)nloc * 8, hipMemcpyDeviceToHost, ctx->stream));
       PH_HIP(hipStreamSynchronize(ctx->stream));
       return PLAIDHIP_OK;

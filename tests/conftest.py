@@ -45,7 +45,7 @@ def hip_ctx():
 def pinned_ctx(hip_ctx):
     """the session context with kernel-selection options pinned for one test (plaidhip_set_option), reset afterwards"""
     defaults = {"spmm_dense_kernel": "auto", "spmm_sparse_kernel": "auto", "nt_store": "auto", "ranks_f32": 2,
-                "rank_kernel": "auto", "scatter_fixed": "on", "scatter_order": "chunk"}
+                "rank_kernel": "auto", "scatter_fixed": "on", "scatter_order": "chunk", "fused_medians": "auto"}
 
     def pin(**opts):
         for k, v in defaults.items():

@@ -65,6 +65,7 @@ def env():
     stream = torch.cuda.Stream(device=dev)
     ctx = plaid_amd.Context(0, stream.cuda_stream)
     ctx.set_option("spmm_sparse_kernel", "scatter")
+    ctx.set_option("fused_medians", "on")       # (by default only from 1e9 scores on: these matrices are smaller)
     yield torch, dev, stream, ctx
     ctx.close()
 
@@ -164,8 +165,10 @@ def test_fused_entry_is_the_plain_route_when_it_does_not_apply(env):
     torch, dev, stream, ctx = env
     from plaid_amd import synth as sy
     g = 20000
-    for m, n, kernel in ((3000, 1100, "scatter"), (24000, 300, "scatter"), (24000, 1100, "gather")):
+    for m, n, kernel, fm in ((3000, 1100, "scatter", "on"), (24000, 300, "scatter", "on"), (24000, 1100, "gather", "on"),
+                             (24000, 1100, "scatter", "auto"), (24000, 1100, "scatter", "off")):
         ctx.set_option("spmm_sparse_kernel", kernel)
+        ctx.set_option("fused_medians", fm)
         Gp, Gi = sy.geneset_csc(g, m)
         gs = ctx.geneset(g, Gp, Gi)
         Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
@@ -178,3 +181,27 @@ def test_fused_entry_is_the_plain_route_when_it_does_not_apply(env):
         assert np.array_equal(f1, f2) and np.allclose(m1, m2, rtol=0, atol=1e-12)
         gs.close()
     ctx.set_option("spmm_sparse_kernel", "scatter")
+    ctx.set_option("fused_medians", "on")
+
+
+def test_host_entries_take_the_fused_route_and_give_the_same_matrix(pinned_ctx):
+    """plaid() and replaid.ssgsea() on a dgCMatrix through the host entry points (what R's .Call reaches): with the fused
+    medians forced on and off the normalised score matrices are the same to the last bit (fixed-point sums, exact medians),
+    and both meet the oracle"""
+    import scipy.sparse as sp
+    from oracle import plaid_oracle as po
+    from plaid_amd import synth as sy
+    g, m, n = 20000, 9000, 1100
+    Gp, Gi = sy.geneset_csc(g, m)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    Xs = sp.csc_matrix((Xx, Xi, Xp), shape=(g, n))
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    outs = {}
+    for mode in ("on", "off"):
+        ctx = pinned_ctx(fused_medians=mode, spmm_sparse_kernel="scatter")
+        outs[mode] = (ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True),
+                      ctx.ssgsea_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, 0.25))
+    assert np.array_equal(outs["on"][0], outs["off"][0]) and np.array_equal(outs["on"][1], outs["off"][1])
+    np.testing.assert_allclose(outs["on"][0], po.plaid(Xs, rn, G, rn), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(outs["on"][1], po.replaid_ssgsea(Xs, rn, G, rn, alpha=0.25), rtol=1e-5, atol=1e-9)

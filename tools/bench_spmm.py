@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"])
     ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..7 (wrong results by design; needs PLAIDHIP_LIB=<the make diag library>)")
+    ap.add_argument("--fused", action="store_true", help="c3: medians selected inside the crossprod launch (dev_spmm_csc_fused + dev_col_medians_resume)")
     ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the scatter kernel (diag library)")
     ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
@@ -88,14 +89,21 @@ def main():
                     ctx.dev_colranks_dense(X.data_ptr(), g, g, n, R.data_ptr(), g, "average", False, 1.25, colmax.data_ptr())
                 ctx.dev_max(colmax.data_ptr(), n, red.data_ptr() + 16)
                 e1 = ev()
-                if a.kernel == "c3":
+                if a.kernel == "c3" and a.fused:
+                    ctx.dev_spmm_csc_fused(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, -0.5,
+                                           flags.data_ptr(), None, red.data_ptr() + 16, nnz=len(Xx))
+                elif a.kernel == "c3":
                     ctx.dev_spmm_csc_ranks(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m,
                                            red.data_ptr() + 16, "mean", 1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
                 else:
                     ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
                                        red.data_ptr() + 16)
                 e2 = ev()
-                ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+                if a.kernel == "c3" and a.fused:
+                    ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+                else:
+                    ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+                e2b = ev()
                 ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
                 ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
                 e3 = ev()
@@ -110,7 +118,7 @@ def main():
                 for k, nm in enumerate(names):
                     print(f"  {nm} by wave, WG 5:", d[5, :, k].astype(int).tolist())
             print(f"{a.kernel} ({g}x{n}x{m}): rank {e0.elapsed_time(e1):.3f} ms  spmm {e1.elapsed_time(e2):.3f} ms  "
-                  f"normalize {e2.elapsed_time(e3):.3f} ms  total {e0.elapsed_time(e3):.3f} ms -> "
+                  f"normalize {e2.elapsed_time(e3):.3f} ms (medians {e2.elapsed_time(e2b):.3f})  total {e0.elapsed_time(e3):.3f} ms -> "
                   f"{m*n/e0.elapsed_time(e3)/1e-3:.3e} scores/s")
         return
     if a.kernel == "sing":
