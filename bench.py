@@ -536,6 +536,23 @@ def run_sparse_ssgsea(a, env, n, label, collective):
     snap = None
     if not collective and rank == 0 and a.cpu_sample > 0:
         snap = _snapshot(torch, S, med, red, flags, n, m, {"colmax": colmax, "gmax": gmax})
+    fused_info = None
+    try:   # how the medians of the last timed step came about (status words of the fused crossprod, copied off the device)
+        import ctypes as _C
+        import numpy as _np
+        nf, p_status, p_cal, _ = ctx.dev_fused_medians_info()
+        if nf:
+            torch.cuda.synchronize()
+            st_h, cal_h = _np.zeros(nf, dtype=_np.int32), _np.zeros(4)
+            ctx.lib.plaidhip_memcpy_d2h(ctx.handle, st_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_status), _C.c_size_t(4 * nf))
+            ctx.lib.plaidhip_memcpy_d2h(ctx.handle, cal_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_cal), _C.c_size_t(32))
+            fused_info = {"columns": int(nf), "selected_from_candidates": int(st_h.sum()), "left_to_the_standalone_kernel": int(nf - st_h.sum()),
+                          "bracket": {"offset_from_predicted_mean": float(cal_h[0]), "half_width": float(cal_h[1]), "ignore_zero": bool(cal_h[2])},
+                          "note": "medians selected inside the crossprod launch (plaidhip_dev_spmm_csc_fused_f64 + ..._resume): "
+                                  "phases_ms.crossprod includes the calibration, the column-mean prediction and the classifying "
+                                  "epilogue; phases_ms.col_medians+sum is the selection + the standalone kernel on the columns left"}
+    except Exception as exc:  # pragma: no cover
+        fused_info = {"error": str(exc)[:200]}
     rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
     scatter = nnz * 8 < g * n
     spmm_alg = 12.0 * nnz + 4.0 * (n + 1) + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
@@ -549,13 +566,16 @@ def run_sparse_ssgsea(a, env, n, label, collective):
                       "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
         "rank_keys_per_s": round(nnz / (rank_ms * 1e-3), 1),
         "geneset_plan_s": round(t_plan, 2),
+        "fused_medians": fused_info,
         "kernels": {
             "sparse_colranks": _roof("colranks_bucket_kernel<256,8>" if max_nnz <= 2048 else "colranks_bucket_kernel", 16.0 * nnz, rank_ms,
                                      _traffic("colranks_bucket_kernel<256,8>", "csc", n) if max_nnz <= 2048 else None),
             "crossprod": _roof("spmm_scatter_csc_f64" if scatter else "spmm_colpair_f64<csc>", spmm_alg, spmm_ms,
-                               _traffic("spmm_scatter_csc_f64", f"{g}xNx{m}", n) if scatter else None,
+                               _traffic("spmm_scatter_csc_f64<med>" if (fused_info and fused_info.get("columns")) else "spmm_scatter_csc_f64", f"{g}xNx{m}", n) if scatter else None,
                                extra={"lds_atomic_adds_per_s": round(nnz * (z / g) / (spmm_ms * 1e-3), 1)} if scatter else None),
-            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),
+            "col_medians": _roof("median_select_kernel + col_medians_stream_kernel (unresolved columns)", 8.0 * m * n, med_ms, None,
+                                 extra={"note": "algorithmic bytes are those of the full sweep the fused crossprod made unnecessary: "
+                                                "frac > 1 would only say that S was not read again"}),
             "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
     }

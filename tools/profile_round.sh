@@ -30,11 +30,13 @@ run_pmc() {   # tag, then bench_spmm.py arguments
 }
 run_pmc c2 --kernel spmm --iters 3
 run_pmc c3 --kernel c3 --samples 8192 --sets 50000 --iters 3
+run_pmc c3fused --kernel c3 --samples 8192 --sets 50000 --iters 3 --fused
 run_pmc c3f64 --kernel c3 --samples 8192 --sets 50000 --iters 3 --scatter-fixed off --scatter-order column
 run_pmc c4 --kernel c4 --samples 4096 --sets 50000 --iters 3
 run_pmc sing --kernel sing --samples 4096 --sets 50000 --iters 2
 run_pmc c2step --kernel step --iters 3
 python3 tools/bench_spmm.py --kernel c3 --samples 4096 --sets 50000 --iters 3 > $out/c3_4096.log 2>&1
+for f in "" "--fused"; do python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 4 $f 2>&1 | grep "^c3" | tail -1; done > $out/c3_8192_fused.log 2>&1
 python3 tools/bench_spmm.py --kernel c4 --samples 2048 --sets 50000 --iters 3 > $out/c4_2048.log 2>&1
 python3 tools/bench_spmm.py --kernel sing --samples 4096 --sets 50000 --iters 3 > $out/sing_4096_50k.log 2>&1
 python3 tools/bench_spmm.py --kernel sing --samples 10000 --sets 5000 --iters 3 > $out/sing_10000_5k.log 2>&1
@@ -54,14 +56,14 @@ for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
-for tag in ("c2", "c3", "c3f64", "c4", "sing", "c2step"):
+for tag in ("c2", "c3", "c3fused", "c3f64", "c4", "sing", "c2step"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + f"/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(out + f"/pmc_{tag}_summary.txt", "w") as fh:
         for k, d in sorted(agg.items()):
-            if not any(x in k for x in ("spmm", "colranks", "medians", "shift")):
+            if not any(x in k for x in ("spmm", "colranks", "median", "shift", "colmean")):
                 continue
             fh.write(k + "\n")
             for c, v in sorted(d.items()):

@@ -43,9 +43,11 @@ ENTRIES = [
      "by L2 / Infinity Cache, which these counters do not separate from HBM)"),
     ("col_medians_wave_kernel/10000x5000", "c2step", "col_medians_wave_kernel", None, "every column read once into registers"),
     ("shift_columns_kernel/10000x5000", "c2step", "shift_columns_kernel", None, "read + write of S"),
-    ("spmm_scatter_csc_f64/20000xNx50000", "c3", "spmm_scatter_csc_f64<true", 8192,
+    ("spmm_scatter_csc_f64/20000xNx50000", "c3", "spmm_scatter_csc_f64<true, 1024, false>", 8192,
      "round-4 kernel (readlane broadcasts, buffer loads with scalar segment offsets, u64 fixed-point accumulators, chunk-major "
      "item order): fetched + written against 0.41 MB algorithmic per column"),
+    ("spmm_scatter_csc_f64<med>/20000xNx50000", "c3fused", "spmm_scatter_csc_f64<true, 1024, true>", 8192,
+     "the same kernel with the classifying epilogue (medians selected inside the launch): + the candidate slices and counts"),
     ("col_medians_stream_kernel/Nx50000", "c3", "col_medians_stream_kernel", 8192,
      "one sweep of a 400 KB column + the candidate list of the sample interval written and read back"),
     ("shift_columns_kernel/Nx50000", "c3", "shift_columns_kernel", 8192, "read + write of S: the algorithmic 16 m bytes per column"),
