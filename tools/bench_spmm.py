@@ -41,6 +41,8 @@ def main():
     ctx.set_option("nt_store", a.nt_store)
     ctx.set_option("scatter_fixed", a.scatter_fixed)
     ctx.set_option("scatter_order", a.scatter_order)
+    if a.fused:
+        ctx.set_option("fused_medians", "on")   # (by default only from 1e9 scores on)
     dbg = None
     if a.ablate or a.stamps:
         import ctypes
