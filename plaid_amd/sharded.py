@@ -86,13 +86,19 @@ class HipPhaseEngine:
         if X.n > 0:
             xx = X.x if values is None else values
             fl = flags.data_ptr() if flags is not None else None
-            if rank_weights and alpha_div is not None:
+            div = alpha_div.data_ptr() if alpha_div is not None else None
+            if fl is not None:
+                # a normalising caller (flag words wanted): the crossprod also classifies its scores for the medians
+                # (plaidhip_dev_spmm_csc_fused_f64; the plain kernels when the shapes do not call for it) -- medians() below
+                # finishes them after the flag words have been all-reduced
+                self.ctx.dev_spmm_csc_fused(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
+                                            stat, alpha, beta, fl, div, div if rank_weights else None, nnz=X.nnz)
+            elif rank_weights and alpha_div is not None:
                 self.ctx.dev_spmm_csc_ranks(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(),
-                                            self.gs.m, alpha_div.data_ptr(), stat, alpha, beta, fl, nnz=X.nnz)
+                                            self.gs.m, div, stat, alpha, beta, fl, nnz=X.nnz)
             else:
                 self.ctx.dev_spmm_csc(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
-                                      stat, alpha, beta, fl, alpha_div.data_ptr() if alpha_div is not None else None,
-                                      nnz=X.nnz)
+                                      stat, alpha, beta, fl, div, nnz=X.nnz)
         return S
 
     def sparse_colranks(self, X: CscShard, ties="average", signed=False, power=1.0):
@@ -163,7 +169,8 @@ class HipPhaseEngine:
         med = t.empty(max(n, 1), dtype=t.float64, device=self.device)
         red = t.zeros(2, dtype=t.float64, device=self.device)
         if n > 0:
-            self.ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            # (= dev_col_medians unless this S came out of a fused crossprod: then only unresolved columns are swept)
+            self.ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
             self.ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
         return med, red
 
