@@ -712,6 +712,7 @@ int launch_col_abs_sums(plaidhip_ctx* ctx, const double* X, int64_t ldx, int32_t
 
 int launch_affine(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n, double mul,
                   const double* col_div, double div_scale, const double* row_add, double add) {
+  ctx->fmed.valid = false;
   if (n == 0 || m == 0) return PLAIDHIP_OK;
   int bx = (m + 255) / 256;
   if (bx > 64) bx = 64;
@@ -2027,6 +2028,7 @@ int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out) {
 
 int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,
                          const double* med, double add, const double* red) {
+  ctx->fmed.valid = false;   // (S changes: the candidates of a fused crossprod are history)
   if (n == 0 || m == 0) return PLAIDHIP_OK;
   int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);   // workgroups per column: one trip of 2,048 values each, up to 16
   if (bx < 1) bx = 1;

@@ -2086,6 +2086,7 @@ static void fill_args(const plaidhip_ctx* ctx, SpmmArgs& a, const plaidhip_genes
 int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X,
                           int64_t ldx, int32_t n, int stat, double alpha, const double* alpha_div,
                           double beta, double* S, int64_t lds, uint32_t* flags, int x_kind) {
+  ctx->fmed.valid = false;   // (any other crossprod on this context: what a fused launch left behind no longer describes S)
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
   if (ctx->opt_dense_kernel == 3)   // opt-in: the dense contraction on the matrix cores (kernels_mfma.hip)
     return launch_spmm_mfma_f64(ctx, const_cast<plaidhip_geneset*>(gs), X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags);
@@ -2143,6 +2144,7 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
                         bool bounded, const double* xmax_dev, double xmax_host) {
+  ctx->fmed.valid = false;
   if (n == 0 || gs->m == 0) return PLAIDHIP_OK;
   if ((g_ablate == 0 || g_ablate >= 100) && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty()) {
     // sparse-aware scatter or dense-work gather.  With nnz(X) from the caller the choice is made here (one

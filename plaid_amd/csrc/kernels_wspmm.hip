@@ -127,6 +127,7 @@ int launch_one(plaidhip_ctx* ctx, const WeightedArgs& a, int grid) {
 int launch_crossprod_weighted_f64(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx, int32_t g,
                                   int32_t m, const double* Y, int64_t ldy, const int32_t* Yp, const int32_t* Yi,
                                   const double* Yx, int32_t n, double* S, int64_t lds) {
+  ctx->fmed.valid = false;
   if (n == 0 || m == 0) return PLAIDHIP_OK;
   WeightedArgs a{};
   a.Wp = Wp; a.Wi = Wi; a.Wx = Wx;

@@ -205,3 +205,34 @@ def test_host_entries_take_the_fused_route_and_give_the_same_matrix(pinned_ctx):
     assert np.array_equal(outs["on"][0], outs["off"][0]) and np.array_equal(outs["on"][1], outs["off"][1])
     np.testing.assert_allclose(outs["on"][0], po.plaid(Xs, rn, G, rn), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(outs["on"][1], po.replaid_ssgsea(Xs, rn, G, rn, alpha=0.25), rtol=1e-5, atol=1e-9)
+
+
+def test_a_later_crossprod_into_the_same_matrix_invalidates_the_candidates(env):
+    """fused crossprod of X1 into S, then a PLAIN crossprod of another X2 into the same S, then ..._resume(S): what the fused
+    launch left behind describes a matrix that is gone -- the medians must be those of the S that is there"""
+    torch, dev, stream, ctx = env
+    from plaid_amd import synth as sy
+    g, m, n = 20000, 9000, 1100
+    Gp, Gi = sy.geneset_csc(g, m)
+    gs = ctx.geneset(g, Gp, Gi)
+    X1 = sy.sparse_columns(g, 0, n)
+    X2 = sy.sparse_columns(g, 5000, 5000 + n)
+    with torch.cuda.stream(stream):
+        d1 = [torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (X1[0].astype(np.int32), X1[1].astype(np.int32), X1[2])]
+        d2 = [torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (X2[0].astype(np.int32), X2[1].astype(np.int32), X2[2])]
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        fl = torch.zeros(4, dtype=torch.int32, device=dev)
+        med_a = torch.zeros(n, dtype=torch.float64, device=dev)
+        med_b = torch.zeros(n, dtype=torch.float64, device=dev)
+        ctx.dev_spmm_csc_fused(gs, d1[0].data_ptr(), d1[1].data_ptr(), d1[2].data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0,
+                               fl.data_ptr(), None, None, nnz=len(X1[2]))
+        assert ctx.dev_fused_medians_info()[3]                       # a resume is pending
+        fl.zero_()
+        ctx.dev_spmm_csc(gs, d2[0].data_ptr(), d2[1].data_ptr(), d2[2].data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0,
+                         fl.data_ptr(), None, nnz=len(X2[2]))
+        assert not ctx.dev_fused_medians_info()[3]
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med_a.data_ptr(), fl.data_ptr())
+        ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med_b.data_ptr(), fl.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(med_a, med_b)
+    gs.close()
