@@ -227,6 +227,27 @@ const char* last_error_cstr();
 int run_sharded(plaidhip_ctx* const* ctxs, int ndev, int method, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                 int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double alpha,
                 double* S_out);
+// A result's way home into the caller's pageable buffer (multi.cpp).  R hands over FRESH memory (allocMatrix -> malloc ->
+// mmap): every page faults on its first write, inside the device-to-host copy -- 4.9 GB of scores took 309 ms instead of
+// 92 (tools/ubench/d2h_fresh.cpp).  prepare() asks for transparent huge pages on the range (madvise; a hint, ignored where
+// the system has them off) and starts threads that touch it chunk by chunk; copy() issues the chunk copies on the context's
+// stream as their pages appear and returns when the last one is enqueued (the pageable copies themselves are synchronous
+// in the runtime).  Small results are one plain copy.  The destination's previous contents are destroyed from prepare() on.
+class HomeBuffer {
+ public:
+  HomeBuffer() = default;
+  HomeBuffer(const HomeBuffer&) = delete;
+  HomeBuffer& operator=(const HomeBuffer&) = delete;
+  ~HomeBuffer() { finish(); }
+  void prepare(void* dst, size_t bytes);
+  int copy(plaidhip_ctx* ctx, const void* src_dev);   // (prepare() first; copies `bytes` of it)
+  void finish();                                      // joins the touch threads (idempotent)
+ private:
+  struct State;
+  State* st_ = nullptr;
+};
+// prepare + copy + finish
+int copy_home(plaidhip_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
 // opt a kernel into the full 160 KiB of dynamic LDS, once per (kernel, device)
 int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, std::atomic<uint32_t>* done_mask);
 #define PH_FULL_LDS(ctx, kernel)                                                          \

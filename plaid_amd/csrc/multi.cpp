@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "common.h"
 
 using namespace plaidhip;
@@ -39,6 +41,85 @@ extern "C" int plaidhip_shard_bounds(int64_t n, int ndev, int k, int64_t* lo, in
   *hi = std::min(n, *lo + per);
   return PLAIDHIP_OK;
 }
+
+namespace plaidhip {
+
+// ---- HomeBuffer ---------------------------------------------------------------------------------------------------------
+struct HomeBuffer::State {
+  char* dst = nullptr;
+  size_t bytes = 0, nchunk = 0;
+  std::vector<std::atomic<int>> done;
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  explicit State(size_t n) : done(n) {}
+};
+namespace {
+constexpr size_t kHomeChunk = (size_t)64 << 20;
+constexpr size_t kHomeMin = (size_t)16 << 20;   // below this one plain copy (a few thousand page faults)
+constexpr int kHomeThreads = 8;                 // touching 4.9 GB of huge pages: 29 ms with 8 threads, 68 with 4 (ubench)
+}  // namespace
+
+void HomeBuffer::prepare(void* dst, size_t bytes) {
+  finish();
+  const size_t nchunk = bytes >= kHomeMin ? (bytes + kHomeChunk - 1) / kHomeChunk : 0;
+  st_ = new State(nchunk);
+  st_->dst = static_cast<char*>(dst);
+  st_->bytes = bytes;
+  st_->nchunk = nchunk;
+  if (nchunk == 0) return;
+  for (auto& d : st_->done) d.store(0, std::memory_order_relaxed);
+  {
+    const uintptr_t b = ((uintptr_t)dst + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)dst + bytes) & ~(uintptr_t)4095;
+    if (e > b) (void)madvise(reinterpret_cast<void*>(b), e - b, MADV_HUGEPAGE);
+  }
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)kHomeThreads, nchunk, hw > 1 ? hw / 2 : 1}));
+  State* st = st_;
+  for (int t = 0; t < nt; ++t)
+    st_->th.emplace_back([st] {
+      for (;;) {
+        const size_t k = st->next.fetch_add(1);
+        if (k >= st->nchunk) return;
+        const size_t b = k * kHomeChunk, e = std::min(st->bytes, b + kHomeChunk);
+        // one write per 4 KiB page, at the page's first byte inside the buffer
+        for (size_t o = b; o < e; o = ((((uintptr_t)st->dst + o) | 4095) + 1) - (uintptr_t)st->dst)
+          *reinterpret_cast<volatile char*>(st->dst + o) = 0;
+        st->done[k].store(1, std::memory_order_release);
+      }
+    });
+}
+
+int HomeBuffer::copy(plaidhip_ctx* ctx, const void* src_dev) {
+  PH_REQUIRE(st_ != nullptr, "HomeBuffer::copy before prepare");
+  if (st_->bytes == 0) return PLAIDHIP_OK;
+  if (st_->nchunk == 0) {
+    PH_HIP(hipMemcpyAsync(st_->dst, src_dev, st_->bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PLAIDHIP_OK;
+  }
+  for (size_t k = 0; k < st_->nchunk; ++k) {
+    while (st_->done[k].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+    const size_t b = k * kHomeChunk, len = std::min(kHomeChunk, st_->bytes - b);
+    PH_HIP(hipMemcpyAsync(st_->dst + b, static_cast<const char*>(src_dev) + b, len, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  return PLAIDHIP_OK;
+}
+
+void HomeBuffer::finish() {
+  if (st_ == nullptr) return;
+  for (auto& t : st_->th) t.join();
+  delete st_;
+  st_ = nullptr;
+}
+
+int copy_home(plaidhip_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+  HomeBuffer hb;
+  hb.prepare(dst, bytes);
+  const int rc = hb.copy(ctx, src_dev);
+  hb.finish();
+  return rc;
+}
+
+}  // namespace plaidhip
 
 namespace {
 
@@ -248,9 +329,9 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
   const bool ranks = c.method != 0;
   plaidhip_geneset* gs = nullptr;
   CtxBuf dX{ctx, 0}, dXp{ctx, 1}, dXi{ctx, 2}, dR{ctx, 3}, dS{ctx, 4}, dsmall{ctx, 5};
-  // the caller's S is usually fresh, untouched memory (R: allocMatrix): first-touch page faults inside the final
-  // device-to-host copy cost ~17 ms per 400 MB; two helper threads touch the pages while the upload is in flight
-  std::vector<std::thread> prefault;
+  // the caller's S is usually fresh, untouched memory (R: allocMatrix): its pages are made while the upload and the
+  // kernels run, the copy home follows chunk by chunk (HomeBuffer, common.h)
+  HomeBuffer home;
   const int64_t ldg = even_ld(g);
   uint32_t* d_flags = nullptr;
   double *d_red = nullptr, *d_med = nullptr, *d_colmax = nullptr, *d_gmax = nullptr;
@@ -271,17 +352,6 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     PH_HIP(hipMemsetAsync(dsmall.p, 0, 64, ctx->stream));
     PH_TRY(dS.alloc((size_t)m * std::max(nloc, 1) * 8));
     if (nloc == 0) return PLAIDHIP_OK;
-    {
-      char* sbeg = reinterpret_cast<char*>(c.S_out + (int64_t)lo * m);
-      const size_t sbytes = (size_t)m * nloc * 8;
-      if (sbytes >= ((size_t)16 << 20))
-        for (int t = 0; t < 2; ++t)
-          prefault.emplace_back([=] {
-            const size_t half = (sbytes / 2 + 4095) & ~(size_t)4095;
-            const size_t b = t * half, e = std::min(sbytes, b + half);
-            for (size_t o = b; o < e; o += 4096) *reinterpret_cast<volatile char*>(sbeg + o) = 0;
-          });
-    }
     if (!sparse) {
       PH_TRY(dX.alloc((size_t)ldg * nloc * 8));
       if (ranks) PH_TRY(dR.alloc((size_t)ldg * nloc * 8));
@@ -301,6 +371,9 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       PH_TRY(upload_pipelined(ctx, dX.as<char>(), (size_t)ldg * 8, reinterpret_cast<const char*>(Xh), (size_t)g * 8, nloc,
                               on_panel));
       PH_TRACE("upload enqueued");
+      // (the result's pages are made from here on, not earlier: eight threads faulting pages in next to the four feeder
+      // threads cost the upload a quarter of its rate)
+      home.prepare(c.S_out + (int64_t)lo * m, (size_t)m * nloc * 8);
     } else {
       z0 = c.Xp[lo];
       zx = (int64_t)c.Xp[lo + nloc] - z0;
@@ -321,6 +394,7 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       PH_HIP(hipMemcpyAsync(dXp.p, ploc.data(), (size_t)(nloc + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
       PH_TRY(upload_pipelined(ctx, dXi.as<char>(), 1, reinterpret_cast<const char*>(c.Xi + z0), 1, zx * 4, nullptr));
       PH_TRY(upload_pipelined(ctx, dX.as<char>(), 1, reinterpret_cast<const char*>(c.X + z0), 1, zx * 8, nullptr));
+      home.prepare(c.S_out + (int64_t)lo * m, (size_t)m * nloc * 8);
       if (c.method == 1) {
         double* dRd = dR.as<double>();
         double* dRx = dRd + panel * ldg;
@@ -432,11 +506,9 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
   }
 
   // ---- the score shard goes home (pageable destination: the runtime's own staging runs at ~53 GB/s) ---------------------
-  for (auto& t : prefault) t.join();
   PH_TRACE("normalise enqueued");
   step([&]() -> int {
-    if (nloc > 0)
-      PH_HIP(hipMemcpyAsync(c.S_out + (int64_t)lo * m, dS.p, (size_t)m * nloc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (nloc > 0) PH_TRY(home.copy(ctx, dS.p));
     PH_HIP(hipStreamSynchronize(ctx->stream));
     PH_TRACE("scores home");
     return PLAIDHIP_OK;

@@ -218,23 +218,32 @@ class Context:
         check(self.lib.plaidhip_dev_shift_columns(self.handle, S, lds, m, n, med, float(add), red))
 
     # ---- host-level (numpy in, numpy out; the library stages through HBM) -------------
-    def plaid_dense(self, X, Gp, Gi, stat="mean", normalize=True) -> np.ndarray:
+    @staticmethod
+    def _result(out, m, n):
+        """the caller's own result buffer (any byte offset; Fortran order like an R matrix) or a fresh one"""
+        if out is None:
+            return np.empty((m, n), dtype=np.float64, order="F")
+        if out.shape != (m, n) or out.dtype != np.float64 or not out.flags.f_contiguous or not out.flags.writeable:
+            raise ValueError(f"out: a writeable Fortran-ordered float64 array of shape {(m, n)}")
+        return out
+
+    def plaid_dense(self, X, Gp, Gi, stat="mean", normalize=True, out=None) -> np.ndarray:
         X = _as_f64_fortran(X)
         g, n = X.shape
         Gp, Gi = _as_i32(Gp), _as_i32(Gi)
         m = len(Gp) - 1
-        S = np.empty((m, n), dtype=np.float64, order="F")
+        S = self._result(out, m, n)
         check(self.lib.plaidhip_plaid_dense(self.handle, _np_ptr(X), g, n, _np_ptr(Gp), _np_ptr(Gi), m,
                                             STAT[stat], int(bool(normalize)), _np_ptr(S)))
         return S
 
-    def plaid_csc(self, Xp, Xi, Xx, g: int, Gp, Gi, stat="mean", normalize=True) -> np.ndarray:
+    def plaid_csc(self, Xp, Xi, Xx, g: int, Gp, Gi, stat="mean", normalize=True, out=None) -> np.ndarray:
         Xp, Xi = _as_i32(Xp), _as_i32(Xi)
         Xx = np.ascontiguousarray(Xx, dtype=np.float64)
         n = len(Xp) - 1
         Gp, Gi = _as_i32(Gp), _as_i32(Gi)
         m = len(Gp) - 1
-        S = np.empty((m, n), dtype=np.float64, order="F")
+        S = self._result(out, m, n)
         check(self.lib.plaidhip_plaid_csc(self.handle, _np_ptr(Xp), _np_ptr(Xi), _np_ptr(Xx), int(g), n,
                                           _np_ptr(Gp), _np_ptr(Gi), m, STAT[stat], int(bool(normalize)),
                                           _np_ptr(S)))
