@@ -26,7 +26,12 @@ constexpr int kMaxLdsGenesPair = kLdsBytes / 16 - kPadSlotsPair;   // 10224
 constexpr int kMaxPairSlices = 8;
 // scatter kernel (sparse X): fp64 accumulators of one chunk of gene sets in LDS
 constexpr int kScatterTrash = 64;                      // accumulators behind a chunk that padded id slots add into
-constexpr int kScatterBlock = 1024;                    // threads per workgroup of the scatter kernel (512: two workgroups per CU, measured slower)
+// threads per workgroup of the scatter kernel (512: two workgroups per CU, measured slower; the -D override is for the
+// A/B builds of tools/: make variant NAME=b512 DEFS=-DPLAIDHIP_SCATTER_BLOCK=512)
+#ifndef PLAIDHIP_SCATTER_BLOCK
+#define PLAIDHIP_SCATTER_BLOCK 1024
+#endif
+constexpr int kScatterBlock = PLAIDHIP_SCATTER_BLOCK;
 // sets per chunk: 17 passes of the workgroup's 1,024 threads over the accumulators (136 KiB of the 160; the chunk epilogue
 // keeps one 16-byte factor pair per pass in registers, and 20 of them left none for anything else: 50,000 sets are three
 // chunks either way)
