@@ -393,6 +393,26 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
                         const int32_t* Gp, const int32_t* Gi, int32_t m, const double* gsetX, int tests,
                         int metap_method, double* out);
 
+/* plaid.test over SAMPLE SHARDS (one process per GPU): the statistics of R/plaid.R:407-431 are row-wise sums over the
+ * samples, so every shard reduces its own columns on the device and the caller adds the shards' results (an all-reduce
+ * of 2 x rows doubles) before the host half runs once.  All pointers of the two _dev_ entries are device pointers;
+ * stream-ordered, no synchronisation.
+ *   plaidhip_dev_row_group_sums: sums[0 * rows + r] = sum of A[r, c] over the columns with y[c] == 0, sums[rows + r] over
+ *     y[c] == 1 (rowMeans of :407-408 and :431 times the group size).  A: rows x n, column-major, leading dimension ld.
+ *   plaidhip_dev_row_group_ssd: ssd[.] = sum of (A[r, c] - mean[group, r])^2 per group, mean: [2][rows] -- the caller
+ *     passes the means of ALL shards, so the shards' results add up to the two-pass sums the one-device call computes
+ *     (the group variances of Rfast::ttests, :429).
+ *   plaidhip_plaid_test_finish (host only, no device): T = [2][m] per-set sums of fc and of fc^2 (crossprod of G with the
+ *     two columns, :478-479), tot1 / tot2 = sums of fc and fc^2 over all g genes (:490-493), SM = [4][m] group-0 mean,
+ *     group-1 mean, group-0 ssd, group-1 ssd of the score rows (NULL without the "lm" test), n0 / n1 the group sizes.
+ *     Same `tests`, `metap_method` and `out` as plaidhip_plaid_test, which calls it.                                     */
+int plaidhip_dev_row_group_sums(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n,
+                                const int32_t* y, double* sums);
+int plaidhip_dev_row_group_ssd(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n,
+                               const int32_t* y, const double* mean, double* ssd);
+int plaidhip_plaid_test_finish(int32_t g, int32_t m, const int32_t* Gp, const double* T, double tot1, double tot2,
+                               const double* SM, int64_t n0, int64_t n1, int tests, int metap_method, double* out);
+
 /* ---- GMT text -> 0/1 membership matrix on the host (no device involved) --------------------------
  * Replaces read.gmt() R/gmt-utils.R:99-125 and gmt2mat() R/gmt-utils.R:19-66 (50.9 s for a 50k-set
  * collection in R, experiments/benchmark/benchmark-plaid.R:42).  Objects are owned by the library

@@ -97,6 +97,9 @@ SIGNATURES = {
     "plaidhip_scse": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp, C.POINTER(_int)],
     "plaidhip_gsva": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f64, _int, _vp],
     "plaidhip_plaid_test": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _int, _int, _vp],
+    "plaidhip_dev_row_group_sums": [_vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "plaidhip_dev_row_group_ssd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "plaidhip_plaid_test_finish": [_i32, _i32, _vp, _vp, _f64, _f64, _vp, _i64, _i64, _int, _int, _vp],
     # host-only GMT text path (gmt.cpp)
     "plaidhip_gmt_read": [C.c_char_p, _int, _i64, C.POINTER(_vp)],
     "plaidhip_gmt_parse": [C.c_char_p, _i64, _int, _int, _i64, C.POINTER(_vp)],

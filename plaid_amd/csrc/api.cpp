@@ -1054,6 +1054,76 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
   return PLAIDHIP_OK;
 }
 
+// Row-wise two-group sums / sums of squared deviations on device pointers: the pieces of plaid.test that a sample-sharded
+// caller all-reduces between (plaid_amd/sharded.py: sharded_plaid_test).  A: rows x n column-major with leading dimension
+// ld; y: 0 / 1 per column; sums / ssd: [2][rows] (group 0, group 1).
+int plaidhip_dev_row_group_sums(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* y,
+                                double* sums) {
+  PH_CTX(ctx);
+  PH_REQUIRE(rows >= 0 && n >= 0 && ld >= rows, "row_group_sums: bad shape rows=%d n=%d ld=%lld", rows, n, (long long)ld);
+  if (rows == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(sums && (n == 0 || (A && y)), "row_group_sums: null argument");
+  PH_TRY(ensure_workspace(ctx, (size_t)row_group_ws_doubles(rows, n) * 8));
+  return launch_row_group_moments(ctx, A, ld, rows, n, y, 1, 1, sums, nullptr, static_cast<double*>(ctx->ws));
+}
+
+int plaidhip_dev_row_group_ssd(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* y,
+                               const double* mean, double* ssd) {
+  PH_CTX(ctx);
+  PH_REQUIRE(rows >= 0 && n >= 0 && ld >= rows, "row_group_ssd: bad shape rows=%d n=%d ld=%lld", rows, n, (long long)ld);
+  if (rows == 0) return PLAIDHIP_OK;
+  PH_REQUIRE(ssd && mean && (n == 0 || (A && y)), "row_group_ssd: null argument");
+  PH_TRY(ensure_workspace(ctx, (size_t)row_group_ws_doubles(rows, n) * 8));
+  return launch_row_group_ssd(ctx, A, ld, rows, n, y, mean, ssd, static_cast<double*>(ctx->ws));
+}
+
+// The host half of plaid.test (R/plaid.R:410-474): p-values, effect sizes, meta-p and FDR from the reduced statistics.
+// Shared by plaidhip_plaid_test and by sample-sharded callers, which all-reduce the statistics first.
+int plaidhip_plaid_test_finish(int32_t g, int32_t m, const int32_t* Gp, const double* T, double tot1, double tot2,
+                               const double* SM, int64_t n0, int64_t n1, int tests, int metap_method, double* out) {
+  PH_REQUIRE(g >= 0 && m >= 0 && (m == 0 || (Gp && out)), "plaid_test_finish: null Gp / out");
+  PH_REQUIRE((tests & 7) != 0 && (tests & ~7) == 0, "plaid_test: tests is a bit mask of 1 (one), 2 (two), 4 (lm)");
+  PH_REQUIRE(metap_method == 0 || metap_method == 1, "Invalid method: %d", metap_method);      // R/plaid.R:533
+  PH_REQUIRE(m == 0 || !(tests & 3) || T, "plaid_test_finish: null T");
+  PH_REQUIRE(m == 0 || !(tests & 4) || SM, "plaid_test_finish: null SM");
+  if (m == 0) return PLAIDHIP_OK;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  double* o_fc = out;
+  double* o_p1 = out + (size_t)m;
+  double* o_p2 = out + 2 * (size_t)m;
+  double* o_p3 = out + 3 * (size_t)m;
+  double* o_pm = out + 4 * (size_t)m;
+  double* o_q = out + 5 * (size_t)m;
+  for (int32_t j = 0; j < m; ++j) {
+    const double k = (double)(Gp[j + 1] - Gp[j]);
+    double eff = 0.0, pv[3];
+    int np = 0;
+    o_p1[j] = o_p2[j] = o_p3[j] = nan;
+    if (tests & 1) {
+      double mean1;
+      o_p1[j] = clamp_p(onesample_p(k, T[j], T[(size_t)m + j], &mean1));
+      eff += mean1;
+      pv[np++] = o_p1[j];
+    }
+    if (tests & 2) {
+      double diff;
+      o_p2[j] = clamp_p(twosample_p((double)g, k, T[j], T[(size_t)m + j], tot1, tot2, &diff));
+      eff += diff;
+      pv[np++] = o_p2[j];
+    }
+    if (tests & 4) {
+      const double m0 = SM[j], m1 = SM[(size_t)m + j];
+      o_p3[j] = clamp_p(welch_p(m0, m1, SM[2 * (size_t)m + j], SM[3 * (size_t)m + j], (double)n0, (double)n1));
+      eff += m1 - m0;                                                                           // :431
+      pv[np++] = o_p3[j];
+    }
+    o_fc[j] = eff / np;                                                                         // rowMeans(F), :453
+    o_pm[j] = np > 1 ? combine_p(pv, np, metap_method) : pv[0];                                 // :455-460
+  }
+  p_adjust_fdr(o_pm, m, o_q);                                                                   // :463
+  return PLAIDHIP_OK;
+}
+
 int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* y,
                         const int32_t* Gp, const int32_t* Gi, int32_t m, const double* gsetX, int tests,
                         int metap_method, double* out) {
@@ -1069,7 +1139,6 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
     if (y[c]) ++n1; else ++n0;
   }
   if (m == 0) return PLAIDHIP_OK;
-  const double nan = std::numeric_limits<double>::quiet_NaN();
   GenesetHolder gh;
   PH_TRY(acquire_geneset(ctx, g, m, Gp, Gi, &gh.gs));
   const int64_t ldg = even_ld(g);
@@ -1110,40 +1179,8 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   PH_HIP(hipStreamSynchronize(ctx->stream));
   double tot1 = 0.0, tot2 = 0.0;
   for (int32_t i = 0; i < g; ++i) { tot1 += F[i]; tot2 += F[(size_t)ldg + i]; }
-  double* o_fc = out;
-  double* o_p1 = out + (size_t)m;
-  double* o_p2 = out + 2 * (size_t)m;
-  double* o_p3 = out + 3 * (size_t)m;
-  double* o_pm = out + 4 * (size_t)m;
-  double* o_q = out + 5 * (size_t)m;
-  for (int32_t j = 0; j < m; ++j) {
-    const double k = (double)(Gp[j + 1] - Gp[j]);
-    double eff = 0.0, pv[3];
-    int np = 0;
-    o_p1[j] = o_p2[j] = o_p3[j] = nan;
-    if (tests & 1) {
-      double mean1;
-      o_p1[j] = clamp_p(onesample_p(k, T[j], T[(size_t)m + j], &mean1));
-      eff += mean1;
-      pv[np++] = o_p1[j];
-    }
-    if (tests & 2) {
-      double diff;
-      o_p2[j] = clamp_p(twosample_p((double)g, k, T[j], T[(size_t)m + j], tot1, tot2, &diff));
-      eff += diff;
-      pv[np++] = o_p2[j];
-    }
-    if (tests & 4) {
-      const double m0 = SM[j], m1 = SM[(size_t)m + j];
-      o_p3[j] = clamp_p(welch_p(m0, m1, SM[2 * (size_t)m + j], SM[3 * (size_t)m + j], (double)n0, (double)n1));
-      eff += m1 - m0;                                                                           // :431
-      pv[np++] = o_p3[j];
-    }
-    o_fc[j] = eff / np;                                                                         // rowMeans(F), :453
-    o_pm[j] = np > 1 ? combine_p(pv, np, metap_method) : pv[0];                                 // :455-460
-  }
-  p_adjust_fdr(o_pm, m, o_q);                                                                   // :463
-  return PLAIDHIP_OK;
+  return plaidhip_plaid_test_finish(g, m, Gp, T.data(), tot1, tot2, (tests & 4) ? SM.data() : nullptr, n0, n1, tests,
+                                    metap_method, out);
 }
 
 int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi,

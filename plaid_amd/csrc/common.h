@@ -264,6 +264,8 @@ int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, std::atomic<uint32_t>*
 int spmm_block_for_genes(int32_t g);   // workgroup size of the column-resident SpMM kernel
 
 // kernels_stats.hip / stats.cpp  (plaid.test)
+int launch_row_group_ssd(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* d_y,
+                         const double* d_mean, double* d_ssd, double* ws);
 int launch_row_group_moments(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n,
                              const int32_t* d_y, int64_t n0, int64_t n1, double* d_mean, double* d_ssd,
                              double* ws);

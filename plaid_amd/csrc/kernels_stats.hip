@@ -160,6 +160,20 @@ int launch_row_group_moments(plaidhip_ctx* ctx, const double* A, int64_t ld, int
   return PLAIDHIP_OK;
 }
 
+// pass 2 alone: sums of squared deviations from GIVEN group means (a sample-sharded caller passes the means of all shards)
+int launch_row_group_ssd(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* d_y,
+                         const double* d_mean, double* d_ssd, double* ws) {
+  if (rows == 0) return PLAIDHIP_OK;
+  const int nblk = (n + kColBlock - 1) / kColBlock;
+  const dim3 grid((rows + 255) / 256, nblk > 0 ? nblk : 1);
+  const int red_blocks = (2 * rows + 255) / 256;
+  if (n > 0) hipLaunchKernelGGL(row_group_ssd_kernel, grid, dim3(256), 0, ctx->stream, A, ld, rows, n, d_y, d_mean, ws);
+  hipLaunchKernelGGL(reduce_blocks_kernel, dim3(red_blocks), dim3(256), 0, ctx->stream, ws, rows, n > 0 ? nblk : 0, 1.0, 1.0,
+                     d_ssd);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
 int launch_fold_change(plaidhip_ctx* ctx, const double* d_mean, int32_t rows, int64_t ld2, double* d_F) {
   if (rows == 0) return PLAIDHIP_OK;
   hipLaunchKernelGGL(fold_change_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_mean, rows, ld2, d_F);

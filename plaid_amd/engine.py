@@ -217,6 +217,14 @@ class Context:
         """x - med[col] + add; with `red` (device {sum, count}) add = sum/count on the device."""
         check(self.lib.plaidhip_dev_shift_columns(self.handle, S, lds, m, n, med, float(add), red))
 
+    def dev_row_group_sums(self, A: int, ld: int, rows: int, n: int, y: int, sums: int):
+        """per-row sums over the columns with y == 0 / y == 1 -> sums[2][rows] (plaid.test, R/plaid.R:407-408, 431)"""
+        check(self.lib.plaidhip_dev_row_group_sums(self.handle, A, ld, rows, n, y, sums))
+
+    def dev_row_group_ssd(self, A: int, ld: int, rows: int, n: int, y: int, mean: int, ssd: int):
+        """per-row sums of squared deviations from the given group means -> ssd[2][rows] (R/plaid.R:429)"""
+        check(self.lib.plaidhip_dev_row_group_ssd(self.handle, A, ld, rows, n, y, mean, ssd))
+
     # ---- host-level (numpy in, numpy out; the library stages through HBM) -------------
     @staticmethod
     def _result(out, m, n):
@@ -411,6 +419,28 @@ def _plaid_test(self, X, y, Gp, Gi, gsetX=None, tests=7, metap_method=0):
     check(self.lib.plaidhip_plaid_test(self.handle, _np_ptr(X), g, n, _np_ptr(y), _np_ptr(Gp), _np_ptr(Gi), m,
                                        _np_ptr(sx) if sx is not None else None, int(tests), int(metap_method),
                                        _np_ptr(out)))
+    return out
+
+
+def plaid_test_finish(g, Gp, T, tot1, tot2, SM, n0, n1, tests=7, metap_method=0, lib=None):
+    """plaidhip_plaid_test_finish (host only): the p-values, effect sizes, meta-p and FDR of plaid.test from the reduced
+    statistics -- T (2, m) per-set sums of fc and fc^2, tot1 / tot2 their sums over all genes, SM (4, m) group means and
+    sums of squared deviations of the score rows (None without "lm").  Returns sets x 6 like Context.plaid_test."""
+    from ._lib import load
+    lib = lib or load()
+    Gp = _as_i32(Gp)
+    m = len(Gp) - 1
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    if T.shape != (2, m):
+        raise ValueError("T must be (2, sets)")
+    if SM is not None:
+        SM = np.ascontiguousarray(SM, dtype=np.float64)
+        if SM.shape != (4, m):
+            raise ValueError("SM must be (4, sets)")
+    out = np.empty((m, 6), dtype=np.float64, order="F")
+    check(lib.plaidhip_plaid_test_finish(int(g), m, _np_ptr(Gp), _np_ptr(T), float(tot1), float(tot2),
+                                         _np_ptr(SM) if SM is not None else None, int(n0), int(n1), int(tests),
+                                         int(metap_method), _np_ptr(out)))
     return out
 
 

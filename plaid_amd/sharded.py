@@ -181,6 +181,31 @@ class HipPhaseEngine:
             self.ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
 
 
+    def row_group_sums(self, A, y):
+        """A (n_local, rows) row-major == rows x n_local column-major; y int32 (n_local,) of 0 / 1 -> (2, rows) sums"""
+        self._same_stream()
+        t = self.torch
+        n, rows = A.shape
+        out = t.zeros((2, rows), dtype=t.float64, device=self.device)
+        if rows > 0:
+            self.ctx.dev_row_group_sums(A.data_ptr(), rows, rows, n, y.data_ptr(), out.data_ptr())
+        return out
+
+    def row_group_ssd(self, A, y, mean):
+        """sums of squared deviations of the rows of A from `mean` (2, rows), per group -> (2, rows)"""
+        self._same_stream()
+        t = self.torch
+        n, rows = A.shape
+        out = t.zeros((2, rows), dtype=t.float64, device=self.device)
+        if rows > 0:
+            self.ctx.dev_row_group_ssd(A.data_ptr(), rows, rows, n, y.data_ptr(), mean.data_ptr(), out.data_ptr())
+        return out
+
+    def crossprod_sum(self, F):
+        """F (k, g) -> (k, m): t(G != 0) %*% F, the plain sums (R/plaid.R:478-479)"""
+        return self.spmm(F, "sum", 1.0, 0.0, None, None)
+
+
 def _world(group):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -266,6 +291,56 @@ def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     return sharded_plaid(engine, R, "mean", True, 1.0, -0.5, gmax, group, x_is_ranks=(alpha == 0.0))
+
+
+def sharded_plaid_test(engine, X_local, y_local, Gp, tests=("one", "two", "lm"), metap_method="fisher", gsetX_local=None,
+                       group=None):
+    """plaid.test (R/plaid.R:392-474) on sample shards: every statistic it needs is a row-wise sum over the samples.
+
+        fc = rowMeans(X[, y == 1]) - rowMeans(X[, y == 0])    :407-409  -> all_reduce(SUM) of the (2, g) group sums
+        G^T fc, G^T fc^2                                       :478-479  -> computed on every rank (two columns)
+        gsetX = plaid(X, G)                                    :424-427  -> sharded_plaid (its own three scalars)
+        Welch per set over the score rows                      :429-431  -> all_reduce(SUM) of the (2, m) group sums, then of
+                                                                            the (2, m) sums of squared deviations from the
+                                                                            GLOBAL means (two passes, like the one-device call)
+
+    X_local: (n_local, g) dense shard; y_local: int32 (n_local,) of 0 / 1; gsetX_local: this rank's (n_local, m) scores or
+    None (computed).  Returns the sets x 6 table (gsetFC, p.one, p.two, p.lm, p.meta, q.meta; G's column order) as a numpy
+    array on EVERY rank.  Collective: every rank of `group` must call it."""
+    import torch
+    import torch.distributed as dist
+    from .engine import plaid_test_finish
+    world, _ = _world(group)
+    bits = sum({"one": 1, "two": 2, "lm": 4}[t_] for t_ in tests)
+    mm = {"fisher": 0, "sumlog": 0, "stouffer": 1, "sumz": 1}
+    if metap_method not in mm:
+        raise ValueError(f"Invalid method: {metap_method}")                   # R/plaid.R:533
+    y_local = y_local.to(torch.int32)
+    if y_local.numel() and not bool(((y_local == 0) | (y_local == 1)).all()):
+        raise ValueError("elements of y must be 0 or 1")                      # R/plaid.R:394
+    g = X_local.shape[1]
+    cnt = torch.stack([(y_local == 0).sum(), (y_local == 1).sum()]).to(torch.float64)
+
+    def allsum(t_):
+        if world > 1:
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM, group=group)
+        return t_
+
+    cnt = allsum(cnt)
+    inv = torch.where(cnt > 0, 1.0 / cnt, torch.full_like(cnt, float("nan")))   # (an empty group: NaN means, as in R)
+    mean = allsum(engine.row_group_sums(X_local, y_local)) * inv[:, None]
+    fc = mean[1] - mean[0]
+    F = torch.stack([fc, fc * fc]).contiguous()
+    T = engine.crossprod_sum(F)                                               # (2, m), the same on every rank
+    tot = F.sum(dim=1)
+    SM = None
+    if bits & 4:
+        S = gsetX_local if gsetX_local is not None else sharded_plaid(engine, X_local, group=group)
+        smean = allsum(engine.row_group_sums(S, y_local)) * inv[:, None]
+        ssd = allsum(engine.row_group_ssd(S, y_local, smean.contiguous()))
+        SM = torch.cat([smean, ssd]).cpu().numpy()
+    n0, n1 = (int(v) for v in cnt.cpu().numpy())
+    return plaid_test_finish(g, Gp, T.cpu().numpy(), float(tot[0]), float(tot[1]), SM, n0, n1, bits, mm[metap_method])
 
 
 class GatherRefused(RuntimeError):

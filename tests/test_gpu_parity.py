@@ -492,6 +492,59 @@ def test_device_level_chain_hip_phase_engine():
     ctx.close()
 
 
+@pytest.mark.parametrize("g,n,m", [(5000, 301, 200), (7001, 64, 1500)])
+def test_sharded_plaid_test_hip_phase_engine(g, n, m):
+    """plaid.test in its sample-sharded form (plaid_amd/sharded.py: device-side row sums / sums of squared deviations,
+    plaidhip_plaid_test_finish on the host), world size 1, against the one-call entry point plaidhip_plaid_test and the
+    oracle; an odd number of genes (the two fold-change columns have an odd leading dimension); a shard split by hand:
+    the sums of two half shards added on the host are what two ranks would all-reduce"""
+    import torch
+    import plaid_amd
+    from plaid_amd import sharded, synth as sy
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=300)
+    X = sy.dense_columns(g, 0, n, tied=True)
+    y = (np.arange(n) % 4 == 1).astype(np.int32)
+    X[:300, y == 1] += 0.7
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    eng = sharded.HipPhaseEngine(ctx, gs, dev)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+    yd = torch.from_numpy(y).to(dev)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    po = _oracle()
+    cols = ["gsetFC", "p.one", "p.two", "p.lm", "p.meta", "q.meta"]
+    with torch.cuda.stream(stream):
+        for tests, mp_ in ((("one", "two", "lm"), "fisher"), (("one", "lm"), "stouffer"), (("lm",), "fisher")):
+            got = sharded.sharded_plaid_test(eng, Xd, yd, Gp, tests, mp_)
+            exp = po.plaid_test(X, rn, y, G, rn, None, metap_method=mp_, tests=tests)
+            bits = sum({"one": 1, "two": 2, "lm": 4}[t] for t in tests)
+            one_call = ctx.plaid_test(X, y, Gp, Gi, None, bits, 0 if mp_ == "fisher" else 1)
+            for k, name in enumerate(cols):
+                if name in exp:
+                    np.testing.assert_allclose(got[:, k], exp[name], rtol=1e-7, atol=1e-300, err_msg=f"{tests} {name}")
+                    np.testing.assert_allclose(got[:, k], one_call[:, k], rtol=1e-9, atol=1e-300, err_msg=f"{tests} {name}")
+                else:
+                    assert np.isnan(got[:, k]).all()
+        # two half shards by hand: sums add up; ssd about the global means add up
+        h = n // 2
+        full = eng.row_group_sums(Xd, yd)
+        halves = eng.row_group_sums(Xd[:h].contiguous(), yd[:h].contiguous()) + eng.row_group_sums(Xd[h:].contiguous(), yd[h:].contiguous())
+        cnt = torch.tensor([(y == 0).sum(), (y == 1).sum()], dtype=torch.float64, device=dev)
+        mean = (full / cnt[:, None]).contiguous()
+        ssd_full = eng.row_group_ssd(Xd, yd, mean)
+        ssd_halves = eng.row_group_ssd(Xd[:h].contiguous(), yd[:h].contiguous(), mean) + eng.row_group_ssd(Xd[h:].contiguous(), yd[h:].contiguous(), mean)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(halves.cpu().numpy(), full.cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(full.cpu().numpy()[1], X[:, y == 1].sum(axis=1), rtol=1e-12)
+    np.testing.assert_allclose(ssd_halves.cpu().numpy(), ssd_full.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(ssd_full.cpu().numpy()[0], ((X[:, y == 0] - X[:, y == 0].mean(axis=1, keepdims=True)) ** 2).sum(axis=1), rtol=1e-10)
+    gs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("g", [300, 7728, 25000])
 def test_colranks_csc_dense_result(hip_ctx, g):
     """colranks(sparse X, keep.zero=FALSE): zeros are ranked, dense result (R/plaid.R:602-609);

@@ -93,6 +93,19 @@ class OraclePhaseEngine:
             S.sub_(med[:, None]).add_(float(red[0] / red[1]))
 
 
+    # plaid.test's row-wise reductions (HipPhaseEngine.row_group_sums / row_group_ssd / crossprod_sum)
+    def row_group_sums(self, A, y):
+        An, yn = A.numpy(), y.numpy()
+        return torch.from_numpy(np.stack([An[yn == 0].sum(axis=0), An[yn == 1].sum(axis=0)]))
+
+    def row_group_ssd(self, A, y, mean):
+        An, yn, mu = A.numpy(), y.numpy(), mean.numpy()
+        return torch.from_numpy(np.stack([((An[yn == k] - mu[k]) ** 2).sum(axis=0) for k in (0, 1)]))
+
+    def crossprod_sum(self, F):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(self.G.T @ F.numpy().T[:self.g]).T))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -195,3 +208,56 @@ def test_single_process_path_needs_no_process_group():
     rn = [str(k) for k in range(g)]
     np.testing.assert_allclose(S.numpy().T, po.plaid(X, rn, G, rn), rtol=1e-12)
     assert sharded.gather_scores(S, n) is S
+
+
+def _plaid_test_worker(rank, world, port, n, out_path):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g, m = 300, 41
+        Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=60)
+        X = np.round(synth.dense_columns(g, 0, n), 1)
+        y = (np.arange(n) % 3 == 0).astype(np.int32)
+        X[:40, y == 1] += 1.5                                           # a real group difference in the first genes
+        lo, hi = sharded.shard_bounds(n, world, rank)
+        eng = OraclePhaseEngine(g, Gp, Gi)
+        Xl = torch.from_numpy(np.ascontiguousarray(X[:, lo:hi].T))
+        yl = torch.from_numpy(y[lo:hi])
+        res = {}
+        for mp_ in ("fisher", "stouffer"):
+            res[mp_] = sharded.sharded_plaid_test(eng, Xl, yl, Gp, ("one", "two", "lm"), mp_)
+        res["one_lm"] = sharded.sharded_plaid_test(eng, Xl, yl, Gp, ("one", "lm"), "stouffer")
+        res["two"] = sharded.sharded_plaid_test(eng, Xl, yl, Gp, ("two",))
+        # scores handed in (a caller that has them already): this rank's rows of plaid(X, G)
+        S_all = sharded.sharded_plaid(eng, Xl)
+        res["given"] = sharded.sharded_plaid_test(eng, Xl, yl, Gp, ("lm",), gsetX_local=S_all)
+        np.savez(out_path + f".{rank}.npz", **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [23, 9])
+def test_sharded_plaid_test_equals_the_oracle_gloo(tmp_path, n):
+    """plaid.test over two sample shards (R/plaid.R:392-474): group sums and sums of squared deviations all-reduced, the
+    host half (plaidhip_plaid_test_finish, no device) run on every rank -- against the oracle on the whole matrix; n = 9
+    leaves the second rank 4 columns and ONE sample of group 1 on it"""
+    world = 2
+    out = str(tmp_path / "pt")
+    mp.spawn(_plaid_test_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    g, m = 300, 41
+    Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=60)
+    X = np.round(synth.dense_columns(g, 0, n), 1)
+    y = (np.arange(n) % 3 == 0).astype(np.int32)
+    X[:40, y == 1] += 1.5
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+    rn = [str(k) for k in range(g)]
+    cols = ["gsetFC", "p.one", "p.two", "p.lm", "p.meta", "q.meta"]
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    for key, tests, mp_ in (("fisher", ("one", "two", "lm"), "fisher"), ("stouffer", ("one", "two", "lm"), "stouffer"),
+                            ("one_lm", ("one", "lm"), "stouffer"), ("two", ("two",), "fisher"), ("given", ("lm",), "fisher")):
+        assert np.array_equal(r0[key], r1[key], equal_nan=True)        # every rank holds the same table
+        exp = po.plaid_test(X, rn, y, G, rn, None, metap_method=mp_, tests=tests)
+        for k, name in enumerate(cols):
+            if name in exp:
+                np.testing.assert_allclose(r0[key][:, k], exp[name], rtol=1e-8, atol=1e-300, err_msg=f"{key} {name}")
+            else:
+                assert np.isnan(r0[key][:, k]).all()
