@@ -1062,21 +1062,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_DUMP_AFTER"):   # debugging aid: every thread's Python stack after so many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_AFTER"]), exit=True)
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DIST_BACKEND=gloo is a TEST mode for a 1-GPU box: the ranks share device (local_rank mod device count) and the
+    # collectives go through gloo, so that the N > 1 code path (sharding, all-reduces, max-over-ranks timing, rank-0 line)
+    # runs on real kernels where RCCL cannot (it refuses two ranks on one GPU).  Its numbers mean nothing.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     stream = torch.cuda.Stream(device=dev)
-    ctx = plaid_amd.Context(local_rank, stream.cuda_stream)
+    ctx = plaid_amd.Context(dev_index, stream.cuda_stream)
     env = {"torch": torch, "dist": dist, "ctx": ctx, "dev": dev, "stream": stream, "world": world, "rank": rank,
            "use_dist": use_dist}
 

@@ -16,6 +16,7 @@
 //      every wavefront's tiles are laid out back to back as one contiguous stream of 16-byte
 //      chunks (8 u16 gene ids per lane), so the kernel's index prefetch never restarts.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -44,20 +45,27 @@ void color_bipartite(std::vector<Edge>& E, int D, int nV = 32) {
   if (E.empty()) return;
   std::vector<int32_t> atU((size_t)32 * D, -1), atV((size_t)nV * D, -1);
   std::vector<int32_t> path;
-  auto first_free = [&](const std::vector<int32_t>& at, int x) {
+  // smallest colour that may still be free at a vertex: colours fill from the low end, so the scan for the first free one
+  // starts here instead of at 0 (a tile with an all-genes set has D = 12,010 colours and 1.4e5 edges: the full scans
+  // were 1.4 of the 1.9 s that preparing the reference-shaped collection took)
+  int32_t loU[32], loV[64];
+  for (int k = 0; k < 32; ++k) loU[k] = 0;
+  for (int k = 0; k < 64; ++k) loV[k] = 0;
+  auto first_free = [&](const std::vector<int32_t>& at, int32_t* lo, int x) {
     const int32_t* row = &at[(size_t)x * D];
-    for (int c = 0; c < D; ++c)
-      if (row[c] < 0) return c;
-    return -1;
+    int c = lo[x];
+    while (c < D && row[c] >= 0) ++c;
+    lo[x] = c;
+    return c < D ? c : -1;
   };
   for (int32_t e = 0; e < (int32_t)E.size(); ++e) {
     const int u = E[e].u, v = E[e].v;
-    const int a = first_free(atU, u);
+    const int a = first_free(atU, loU, u);
     int c = -1;
     if (atV[(size_t)v * D + a] < 0) {
       c = a;
     } else {
-      const int b = first_free(atV, v);
+      const int b = first_free(atV, loV, v);
       if (atU[(size_t)u * D + b] < 0) {
         c = b;
       } else {
@@ -76,6 +84,8 @@ void color_bipartite(std::vector<Edge>& E, int D, int nV = 32) {
         for (int32_t pe : path) {
           atU[(size_t)E[pe].u * D + E[pe].color] = -1;
           atV[(size_t)E[pe].v * D + E[pe].color] = -1;
+          loU[E[pe].u] = std::min(loU[E[pe].u], E[pe].color);
+          loV[E[pe].v] = std::min(loV[E[pe].v], E[pe].color);
         }
         for (int32_t pe : path) {
           const int nc = (E[pe].color == a) ? b : a;
@@ -554,6 +564,15 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
   gs->tiles = (m + 63) / 64;
 
   int rc = PLAIDHIP_OK;
+#if defined(PLAIDHIP_DIAG) && defined(PLAIDHIP_KEEP_HOST_PLANS)   // tools/plan_probe: PLAIDHIP_TSW=1 prints where the preparation spends its time
+  const auto tsw0 = std::chrono::steady_clock::now();
+  auto TSW = [&](const char* tag) {
+    if (getenv("PLAIDHIP_TSW"))
+      fprintf(stderr, "[tsw] %-24s %8.1f ms\n", tag, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tsw0).count());
+  };
+#else
+  auto TSW = [](const char*) {};
+#endif
   std::vector<int32_t> total(m);
   for (int32_t j = 0; j < m; ++j) total[j] = Gp[j + 1] - Gp[j];
   if (m > 0) {
@@ -593,6 +612,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
       if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
     }
   }
+  TSW("one-column plans");
   gs->rows_in_order = true;   // tiles take the sets in decreasing-size order: identity iff already sorted
   for (int32_t j = 0; j + 1 < m; ++j)
     if (Gp[j + 2] - Gp[j + 1] > Gp[j + 1] - Gp[j]) { gs->rows_in_order = false; break; }
@@ -602,6 +622,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     std::vector<plaidhip_pair_slice_dev> hd;
     gs->pair.waves = 16;
     build_pair_plan(g, m, Gp, Gi, gs->pair.waves, pp);
+    TSW("pair plan built");
     gs->pair.chunks = pp.chunks;
     if ((rc = upload(ctx, pp.wave_tile_off, &gs->pair.d_wave_tile_off)) != PLAIDHIP_OK) goto fail;
     if ((rc = upload(ctx, pp.meta_j, &gs->pair.d_meta_j)) != PLAIDHIP_OK) goto fail;
@@ -632,6 +653,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
+  TSW("pair plan uploaded");
   if (m > 0) {
     // scatter plan (sparse X): gene-major membership in 128-id segments (one dword = 2 ids per lane) per (chunk of sets, gene)
     plaidhip_scatter_plan& sp = gs->scatter;
@@ -663,6 +685,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
         const size_t cell = (size_t)(j / sp.ch) * g + Gi[p];
         ids[(size_t)seg[cell] * 128 + cnt[cell]++] = (uint16_t)(j % sp.ch);
       }
+    TSW("scatter lists filled");
     // Bank-conflict-free order inside every (chunk, gene) list.  The kernel turns a segment into two ds_add_f64
     // wave-instructions (the low and the high u16 of each lane's dword).  Measured (tools/ubench/lds_atomics.hip): the
     // LDS executes a 64-bit atomic in four groups of 16 consecutive lanes, 2 cycles per group when the 16 accumulators
@@ -672,10 +695,17 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     // allow it (a residue with more ids than the list has groups keeps the few collisions left), and the padding
     // lanes of a group get trash accumulators on the banks the group does not use.
     {
+      // (cells are independent: a few threads, each with its own scratch, take blocks of cells -- this ordering was a third
+      // of the time plaidhip_geneset_create takes on a 61,459-set collection)
+      const size_t ncell = seg.size() - 1;
+      unsigned nt = std::thread::hardware_concurrency();
+      nt = std::max(1u, std::min(nt, 16u));
+      if (ncell < 4096) nt = 1;
+      auto order_cells = [&](size_t cell_lo, size_t cell_hi) {
       std::vector<uint16_t> byres[16];
       std::vector<int> gload, gres;    // ids per group, ids of the current residue per group
       std::vector<std::vector<uint16_t>> grp;
-      for (size_t cell = 0; cell + 1 < seg.size(); ++cell) {
+      for (size_t cell = cell_lo; cell < cell_hi; ++cell) {
         const int N = cnt[cell];
         const int nsg = seg[cell + 1] - seg[cell];
         uint16_t* base = ids.data() + (size_t)seg[cell] * 128;
@@ -730,7 +760,25 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
           }
         }
       }
+      };
+      if (nt == 1) {
+        order_cells(0, ncell);
+      } else {
+        std::atomic<size_t> next{0};
+        const size_t blk = 2048;
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nt; ++w)
+          pool.emplace_back([&]() {
+            for (;;) {
+              const size_t lo = next.fetch_add(blk);
+              if (lo >= ncell) return;
+              order_cells(lo, std::min(ncell, lo + blk));
+            }
+          });
+        for (auto& th : pool) th.join();
+      }
     }
+    TSW("scatter lists ordered");
     std::vector<double> w(m), k(m);
     for (int32_t j = 0; j < m; ++j) {
       k[j] = (double)(Gp[j + 1] - Gp[j]);
@@ -774,6 +822,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
+  TSW("done");
   *out = gs;
   return PLAIDHIP_OK;
 fail:
