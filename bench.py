@@ -842,10 +842,10 @@ def run_c4(a, env):
 # experiments/benchmark/benchmark-plaid.R:18-35 scores playdata::GSETxGENE (61,459 real gene sets) on 10,000 cells / samples;
 # the published wall times (single R process, unknown CPU "p14") are the only numbers the reference holds at any shape:
 REF_PUBLISHED = {
-    "pbmc3k": {"genes": 12010, "sets": 61459, "sparse": True, "plaid_s": 110.029, "sing_s": 77.353,
-               "source": "experiments/benchmark/benchmark-pbmc3k@p14.csv:133 (plaid), :132 (replaid.sing)"},
-    "brca": {"genes": 17713, "sets": 61510, "sparse": False, "plaid_s": 126.416, "sing_s": 110.004,
-             "source": "experiments/benchmark/benchmark-brca@p14.csv:133 (plaid), :132 (replaid.sing)"},
+    "pbmc3k": {"genes": 12010, "sets": 61459, "sparse": True, "plaid_s": 110.029, "sing_s": 77.353, "scse_s": 69.052,
+               "source": "experiments/benchmark/benchmark-pbmc3k@p14.csv:133 (plaid), :132 (replaid.sing), :131 (replaid.scse)"},
+    "brca": {"genes": 17713, "sets": 61510, "sparse": False, "plaid_s": 126.416, "sing_s": 110.004, "scse_s": 90.407,
+             "source": "experiments/benchmark/benchmark-brca@p14.csv:133 (plaid), :132 (replaid.sing), :131 (replaid.scse)"},
 }
 
 
@@ -1045,8 +1045,35 @@ def run_ref_shape(a, env, name):
                                  "note": "pageable host X in, the 4.9 GB score matrix back over PCIe: everything an R caller waits "
                                          "for, against the reference's published wall time of the same call"}
             del Sh
+            # replaid.scse (R/plaid.R:155-190), the third call the reference publishes a wall time for at this shape: host
+            # entry only (X in, scores back), probe columns against the oracle under the removeLog2 decision the device took
+            import scipy.sparse as sps
+            from oracle import plaid_oracle as po
+            Xarg = sps.csc_matrix((hx, hi_, hp), shape=(g, n)) if sparse else Xhost
+            ctx.scse(Xarg, Gp, Gi)
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                Ss = ctx.scse(Xarg, Gp, Gi)
+                ts.append(time.perf_counter() - t0)
+            removed = bool(ctx.last_scse_removed_log2)
+            pc = sorted({0, 1, n // 3, n // 2, n - 2, n - 1})
+            Gm = sps.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, m))
+            rn = [str(k) for k in range(g)]
+            exp = po.replaid_scse(Xarg[:, pc], rn, Gm, rn, remove_log2=removed)
+            got = Ss[:, pc]
+            out["scse"] = {"entry": "plaidhip_scse", "ms": round(1e3 * min(ts), 1), "scores_per_s": round(scores / min(ts), 1),
+                           "reference_seconds": pub["scse_s"] * (n / 10000.0),
+                           "vs_baseline": round(pub["scse_s"] * (n / 10000.0) / min(ts), 1), "removed_log2": removed,
+                           "parity": {"columns": len(pc), "max_rel_err_vs_oracle": _rel_err(got, exp),
+                                      "ok": bool(np.allclose(got, exp, rtol=1e-5, atol=1e-9))},
+                           "note": "host entry (pageable X in, 4.9 GB of scores back) against the reference's published wall "
+                                   "time of replaid.scse at this shape"}
+            del Ss
         except Exception as exc:  # pragma: no cover
-            out["host_entry"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+            out.setdefault("host_entry", {"error": f"{type(exc).__name__}: {str(exc)[:200]}"})
+            if "scse_s" in pub and "scse" not in out:
+                out["scse"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
     gs.close()
     torch.cuda.empty_cache()
     return out
@@ -1137,7 +1164,7 @@ def main():
             # `vs_baseline` above stays null: BASELINE.md holds no published number for THIS metric's configuration (20k genes
             # x 10k x 5k).  The reference's only published timings are at its own shapes; the ratios there:
             out["vs_baseline_at_reference_shapes"] = {k: {"plaid": v.get("vs_baseline"), "plaid_host_entry": v.get("host_entry", {}).get("vs_baseline"),
-                                                          "sing": v.get("sing", {}).get("vs_baseline"), "source": REF_PUBLISHED[k]["source"]}
+                                                          "sing": v.get("sing", {}).get("vs_baseline"), "scse_host_entry": v.get("scse", {}).get("vs_baseline"), "source": REF_PUBLISHED[k]["source"]}
                                                       for k, v in rs.items() if isinstance(v, dict) and "vs_baseline" in v}
     ctx.close()
     if use_dist:

@@ -178,9 +178,9 @@ int acquire_geneset(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp, 
 }  // namespace plaidhip
 namespace {
 
+// (pageable memory: through the pinned staging ring once it is worth it, multi.cpp)
 int h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  return PLAIDHIP_OK;
+  return upload_host(ctx, dst, 1, src, 1, (int64_t)bytes);
 }
 
 // Dense host matrix (g x n, column-major) -> device with an EVEN leading dimension, so that both
@@ -189,9 +189,7 @@ inline int64_t even_ld(int32_t g) { return (int64_t)g + (g & 1); }
 int h2d_cols(plaidhip_ctx* ctx, void* dst, int64_t ldd, const double* src, int32_t g, int32_t n) {
   if ((int64_t)g * n == 0) return PLAIDHIP_OK;
   if (ldd == g) return h2d(ctx, dst, src, (size_t)g * n * 8);
-  PH_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)g * 8, (size_t)g * 8, (size_t)n, hipMemcpyHostToDevice,
-                          ctx->stream));
-  return PLAIDHIP_OK;
+  return upload_host(ctx, dst, (size_t)ldd * 8, src, (size_t)g * 8, n);
 }
 
 // normalize_medians on a device-resident S (R/plaid.R:554-575), fully enqueued: ignore.zero is

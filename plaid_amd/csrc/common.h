@@ -253,6 +253,10 @@ class HomeBuffer {
 };
 // prepare + copy + finish
 int copy_home(plaidhip_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+// the other direction (multi.cpp): `cols` rows of row_bytes bytes from pageable host memory to device rows ldd_bytes apart
+// (a flat array: row_bytes = ldd_bytes = 1, cols = bytes), through the context's pinned staging ring; stream-ordered for
+// consumers on the context's stream, returns when the host side is done with `src`
+int upload_host(plaidhip_ctx* ctx, void* dst, size_t ldd_bytes, const void* src, size_t row_bytes, int64_t cols);
 // opt a kernel into the full 160 KiB of dynamic LDS, once per (kernel, device)
 int allow_full_lds(plaidhip_ctx* ctx, const void* kernel, std::atomic<uint32_t>* done_mask);
 #define PH_FULL_LDS(ctx, kernel)                                                          \

@@ -525,6 +525,12 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
 
 namespace plaidhip {
 
+// pageable host memory -> device through the pinned staging ring (the other host entry points' uploads: a plain
+// hipMemcpy from pageable memory runs at ~21 GB/s, the ring at the link rate)
+int upload_host(plaidhip_ctx* ctx, void* dst, size_t ldd_bytes, const void* src, size_t row_bytes, int64_t cols) {
+  return upload_pipelined(ctx, static_cast<char*>(dst), ldd_bytes, static_cast<const char*>(src), row_bytes, cols, nullptr);
+}
+
 int run_sharded(plaidhip_ctx* const* ctxs, int ndev, int method, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                 int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double alpha,
                 double* S_out) {
