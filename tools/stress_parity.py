@@ -74,6 +74,19 @@ def run_case(ctx, seed):
             if not np.array_equal(Rd, po.colranks(X, signed=sg, ties_method=tm)):
                 out.append(f"{tag}: DENSE-FROM-SPARSE RANK MISMATCH ties={tm} signed={sg}")
             checks.append(("sing_csc", ctx.sing_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi), po.replaid_sing(X, rn, G, rn)))
+            # ties.method passed through (first / last / dense: composed from min-rank passes, R/plaid.R:593,614-617)
+            tm2 = str(rng.choice(["first", "last", "dense"]))
+            R2 = ctx.colranks_dense(X, tm2, sg)
+            if not np.array_equal(R2, po.colranks(X, signed=sg, ties_method=tm2)):
+                out.append(f"{tag}: RANK MISMATCH ties={tm2} signed={sg}")
+            # the thin callers: replaid.scse (R/plaid.R:155-190) and replaid.ucell (:276-282), dense or sparse input
+            Xin = Xs if bool(rng.integers(0, 2)) else X
+            rl = [None, True, False][int(rng.integers(0, 3))]
+            smn = bool(rng.integers(0, 2))
+            checks.append(("scse", ctx.scse(Xin, Gp, Gi, rl, smn), po.replaid_scse(Xin, rn, G, rn, remove_log2=rl, score_mean=smn)))
+            if m > 0 and int(sizes.max()) > 0:
+                rmax = float(rng.choice([50, 1500]))
+                checks.append(("ucell", ctx.ucell(Xin, Gp, Gi, sizes.astype(np.float64), rmax), po.replaid_ucell(Xin, rn, G, rn, rmax=rmax)))
         # t(x) %*% y with per-entry weights (chunked_crossprod's general case), y dense and sparse
         W = sp.csc_matrix((rng.normal(size=len(Gi)), Gi, Gp), shape=(g, m))
         Y = np.nan_to_num(X, nan=0.5)
