@@ -173,7 +173,8 @@ int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
  * The scatter kernel sums in u64 fixed point -- scores that do not depend on the order in which its LDS atomics arrive,
  * bit-identical from run to run -- when a sweep over the stored values finds them all finite and >= 0 AND their dynamic
  * range small enough for every score to stay within 2^-40 (9.1e-13) relative of the exact sum: each value is rounded once
- * to a grid of 2^-(e+1) <= 2^-40 x (smallest stored value > 0).  Anything else (a negative, NaN or infinite value, raw
+ * to a grid of 2^-(e+1) <= 2^-40 x (smallest stored value > 0), e = 63 bits minus those of the largest possible sum
+ * ((largest set size) x (largest value), or -- where that is too coarse -- the largest sum of a column's values).  Anything else (a negative, NaN or infinite value, raw
  * counts next to values near 1, one huge outlier) takes fp64 atomics.  Decided on the device; both launches are enqueued. */
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                               const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,

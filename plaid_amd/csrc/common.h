@@ -77,7 +77,7 @@ struct plaidhip_ctx {
   int opt_scatter_fixed = 1;   // scatter kernel: u64 fixed-point accumulators for inputs declared bounded (rank weights)
   int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
   int opt_fused_medians = 0;   // medians selected inside the sparse crossprod: 0 by size (>= 1e9 scores) | 1 whenever possible | 2 never
-  double* d_sel = nullptr;        // {0 or -1, max, smallest > 0} of the stored values of a sparse X (scatter kernel's choice of accumulators)
+  double* d_sel = nullptr;        // {0 or -1, max, smallest > 0, largest column sum or +inf} of the stored values of a sparse X (scatter kernel's choice of accumulators)
   uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
   uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
   // medians selected inside the last sparse crossprod launch (launch_spmm_csc_fused_f64): what plaidhip_dev_col_medians_resume
@@ -319,6 +319,7 @@ int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, i
                               const uint32_t* flags, double* med);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)
 int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, int64_t nnz_hint, double* out);
+int launch_colsum_max(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, double* out);
 int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int32_t* Xp,
                         const int32_t* Xi, const double* Xx, int32_t n, int64_t nnz /* -1: unknown */, int stat, double alpha,
                         const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,

@@ -676,7 +676,21 @@ nonneg_range_final_kernel(const double* __restrict__ part, int nb, double* out) 
   if (threadIdx.x == 0) { out[0] = omn; out[1] = omx; }
   __syncthreads();
   block_minmax_1024(mnz, 0.0, s_mn, s_mx, omn, omx);
-  if (threadIdx.x == 0) out[2] = omn;
+  if (threadIdx.x == 0) { out[2] = omn; out[3] = INFINITY; }   // out[3]: the largest column sum, when launch_colsum_max follows
+}
+
+// the largest sum of a column's stored values (all >= 0 where it matters): no score can exceed it, whatever the size of its set
+__global__ void __launch_bounds__(256)
+colsum_kernel(const double* __restrict__ v, const int32_t* __restrict__ Xp, int32_t n, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n; c += nw) {
+    const int64_t q0 = Xp[c], q1 = Xp[c + 1];
+    double s = 0.0;
+    for (int64_t i = q0 + lane; i < q1; i += 64) s += v[i];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[c] = s;
+  }
 }
 
 // nnz_hint only sizes the grid (< 0: unknown); the swept range is Xx[Xp[0] .. Xp[n]) whatever it says
@@ -691,6 +705,17 @@ int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, 
   hipLaunchKernelGGL(nonneg_range_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nb, out);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
+}
+
+// out[0] = max over the columns of the sum of their stored values (per-column sums in the workspace, then one reduction)
+int launch_colsum_max(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, double* out) {
+  if (n <= 0) return PLAIDHIP_OK;
+  int rc = ensure_workspace(ctx, (size_t)n * sizeof(double));
+  if (rc != PLAIDHIP_OK) return rc;
+  double* sums = reinterpret_cast<double*>(ctx->ws);
+  const int need = (n + 3) / 4, cap = ctx->num_cu * 16;
+  hipLaunchKernelGGL(colsum_kernel, dim3(need < cap ? need : cap), dim3(256), 0, ctx->stream, Xx, Xp, n, sums);
+  return launch_max(ctx, sums, n, out);
 }
 
 int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar) {

@@ -813,7 +813,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // What the rounding costs, rigorously: a stored value v > 0 moves by at most 2^-(e+1) and contributes at least
 // min_nz = the smallest stored value > 0 to any sum it is part of (all terms are >= 0), so EVERY score is within
 // 2^-(e+1) / min_nz relative of the exact sum.  Fixed point is used only when that bound is <= 2^-40 (9.1e-13), i.e. when
-// the dynamic range xmax / min_nz of the input is below ~2^(23 - kbits); raw counts next to values near 1, one huge outlier,
+// the dynamic range xmax / min_nz of the input is below ~2^(23 - kbits) (or the column-sum form of it, below); raw counts next to values near 1, one huge outlier,
 // xmax >= 2^1000, a negative, NaN or infinite stored value, or (bounded callers) a value above the declared xmax all take
 // the fp64 accumulators instead.  The predicate is evaluated on the device by both launches of a call (one of them
 // returns at once); nothing about it is left to the caller.
@@ -824,12 +824,25 @@ __device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded,
   bool ok = seen_ok >= 0.0 && xmax >= 0.0 && xmax < 0x1p1000 && seen_max <= xmax;   // (false for a NaN xmax)
   int q = 0;
   if (xmax > 0.0 && xmax < 0x1p1000) (void)frexp(xmax, &q);     // xmax < 2^q
-  const int e = 63 - q - kbits;
-  if (min_nz < INFINITY) {
-    int qm = 0;
-    (void)frexp(min_nz, &qm);                                    // min_nz >= 2^(qm - 1)
-    ok = ok && (qm - 1 + e + 1 >= 40);                           // 2^-(e+1) / min_nz <= 2^-40
+  // Bits of the largest possible sum: (largest set size) x xmax.  Where that bound leaves the grid too few bits -- ONE set
+  // with thousands of genes next to rank weights up to 2^13 needs 28 bits, e = 35 -- the largest sum of a whole column's
+  // stored values takes its place (sel[3], launch_colsum_max: all terms are >= 0, so no set's sum exceeds its column's;
+  // the ~1,000 stored values of a cell sum to 2^22; one more bit for the roundings).  Only THEN: a call the first bound
+  // serves keeps its grid, which depends on nothing but the declared xmax and the collection -- the same on every shard.
+  int e = 63 - (q + kbits);
+  int qm = 1;
+  if (min_nz < INFINITY) (void)frexp(min_nz, &qm);               // min_nz >= 2^(qm - 1)
+  bool fine = min_nz == INFINITY || (qm - 1 + e + 1 >= 40);      // 2^-(e+1) / min_nz <= 2^-40
+  const double colsum = sel[3];
+  if (!fine && colsum > 0.0 && colsum < 0x1p1000) {
+    int qs = 0;
+    (void)frexp(colsum, &qs);                                    // colsum < 2^qs
+    if (qs + 1 < q + kbits) {
+      e = 63 - (qs + 1);
+      fine = qm - 1 + e + 1 >= 40;
+    }
   }
+  ok = ok && fine;
   e_out = e;
   xmax_out = xmax;
   return ok;
@@ -1248,8 +1261,14 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   // whether fixed point is safe (a NaN rank weight, e.g., takes the fp64 kernel and propagates as in the reference).
   const bool try_fixed = ctx->opt_scatter_fixed != 0 && ctx->d_sel != nullptr;
   if (try_fixed) {
-    const int rc = launch_nonneg_range(ctx, Xx, Xp, n, nnz, ctx->d_sel);
+    int rc = launch_nonneg_range(ctx, Xx, Xp, n, nnz, ctx->d_sel);
     if (rc != PLAIDHIP_OK) return rc;
+    // a collection with a set of more than 1,024 genes: the bound (set size) x xmax may leave the grid too few bits where
+    // the largest column sum does not (scatter_fixed_ok) -- one more pass over the stored values (~0.2 ms per 1e8)
+    if (sp.kbits > 10) {
+      rc = launch_colsum_max(ctx, Xx, Xp, n, ctx->d_sel + 3);
+      if (rc != PLAIDHIP_OK) return rc;
+    }
   }
   a.chunk_major = ctx->opt_scatter_order;
   a.xmax_dev = xmax_dev;

@@ -219,3 +219,58 @@ def test_geneset_create_at_the_reference_size_stays_within_its_budget(hip_ctx):
     assert dt < 20.0, dt
     eff1, eff2 = z / info["padded_slots"], z / info["padded_slots_pair"]          # slot efficiency: one-column / pair plan
     assert eff1 > 0.70 and eff2 > 0.64, (eff1, eff2)
+
+
+def test_rank_weights_keep_fixed_point_sums_next_to_an_all_genes_set():
+    """replaid.ssgsea on a dgCMatrix with the reference-shaped collection: (largest set size) x max weight would leave the u64
+    grid 35 fraction bits (a 12,010-gene set: kbits = 14) and the sums would go to fp64 atomics, whose last bits depend on
+    the arrival order; the largest COLUMN sum bounds every score as well (all weights >= 0) and leaves 41: the scores are
+    bit-identical between runs and between the kernel's two item orders, and within 1e-12 of the fp64-atomic sums.  A
+    collection the first bound serves keeps its grid (same bits as with the column-sum pass switched off by a small
+    collection: the synthetic one, kbits = 9, takes no column-sum pass at all)"""
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    g, m, n, alpha = 12010, 30000, 900, 0.25
+    Gp, Gi = sy.geneset_csc_real(g, m)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n, density=0.07)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    gs = ctx.geneset(g, Gp, Gi)
+    outs = {}
+    with torch.cuda.stream(stream):
+        dp, di, dx = (torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (Xp.astype(np.int32), Xi.astype(np.int32), Xx))
+        Rx = torch.empty_like(dx)
+        colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+        gmax = torch.zeros(1, dtype=torch.float64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.dev_colranks_csc(dp.data_ptr(), dx.data_ptr(), n, int(np.diff(Xp).max()), Rx.data_ptr(), "average", False, 1.0 + alpha,
+                             colmax.data_ptr())
+        ctx.dev_max(colmax.data_ptr(), n, gmax.data_ptr())
+        ctx.set_option("spmm_sparse_kernel", "scatter")
+        for key, fixed, order in (("fx_chunk", "on", "chunk"), ("fx_chunk2", "on", "chunk"), ("fx_col", "on", "column"),
+                                  ("f64", "off", "chunk")):
+            ctx.set_option("scatter_fixed", fixed)
+            ctx.set_option("scatter_order", order)
+            S = torch.empty((n, m), dtype=torch.float64, device=dev)
+            ctx.dev_spmm_csc_ranks(gs, dp.data_ptr(), di.data_ptr(), Rx.data_ptr(), n, S.data_ptr(), m, gmax.data_ptr(), "mean",
+                                   1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+            outs[key] = S
+    torch.cuda.synchronize()
+    assert torch.equal(outs["fx_chunk"], outs["fx_chunk2"]) and torch.equal(outs["fx_chunk"], outs["fx_col"])
+    assert float((outs["f64"] - outs["fx_chunk"]).abs().max()) < 1e-12
+    # against the oracle on a few cells
+    from oracle import c_oracle
+    cols = [0, 1, n - 1]
+    Rh = Rx.cpu().numpy() / float(gmax[0])
+    sub_p = np.zeros(len(cols) + 1, np.int32)
+    sub_i, sub_x = [], []
+    for k, c in enumerate(cols):
+        sub_i.append(Xi[Xp[c]:Xp[c + 1]]); sub_x.append(Rh[Xp[c]:Xp[c + 1]])
+        sub_p[k + 1] = sub_p[k] + Xp[c + 1] - Xp[c]
+    exp = c_oracle.crossprod_csc(sub_p, np.concatenate(sub_i), np.concatenate(sub_x), g, Gp, Gi, "mean", threads=4) - \
+        0.5 * (np.diff(Gp) * (1.0 / (1e-8 + np.diff(Gp))))[:, None]
+    np.testing.assert_allclose(outs["fx_chunk"].cpu().numpy()[cols].T, exp, rtol=1e-9, atol=1e-12)
+    gs.close()
+    ctx.close()

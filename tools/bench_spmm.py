@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ties", default="average")
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"])
+    ap.add_argument("--real-sets", action="store_true", help="a collection with the shape of the reference's (synth.geneset_csc_real: sizes 3..5,000 + an all-genes set, hub genes)")
     ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..7 (wrong results by design; needs PLAIDHIP_LIB=<the make diag library>)")
     ap.add_argument("--fused", action="store_true", help="c3: medians selected inside the crossprod launch (dev_spmm_csc_fused + dev_col_medians_resume)")
@@ -51,7 +52,7 @@ def main():
         ctx.lib.plaidhip_debug_set_ablation(a.ablate if a.ablate else 100, dbg.data_ptr())
     g, n, m = a.genes, a.samples, a.sets
     t0 = time.perf_counter()
-    Gp, Gi = synth.geneset_csc(g, m, sort_by_size=not a.unsorted)
+    Gp, Gi = synth.geneset_csc_real(g, m) if a.real_sets else synth.geneset_csc(g, m, sort_by_size=not a.unsorted)
     t1 = time.perf_counter()
     gs = ctx.geneset(g, Gp, Gi)
     t2 = time.perf_counter()
