@@ -827,7 +827,7 @@ __device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded,
   // Bits of the largest possible sum: (largest set size) x xmax.  Where that bound leaves the grid too few bits -- ONE set
   // with thousands of genes next to rank weights up to 2^13 needs 28 bits, e = 35 -- the largest sum of a whole column's
   // stored values takes its place (sel[3], launch_colsum_max: all terms are >= 0, so no set's sum exceeds its column's;
-  // the ~1,000 stored values of a cell sum to 2^22; one more bit for the roundings).  Only THEN: a call the first bound
+  // the ~1,000 stored values of a cell sum to 2^22).  Only THEN: a call the first bound
   // serves keeps its grid, which depends on nothing but the declared xmax and the collection -- the same on every shard.
   int e = 63 - (q + kbits);
   int qm = 1;
@@ -837,8 +837,8 @@ __device__ __forceinline__ bool scatter_fixed_ok(const double* sel, int bounded,
   if (!fine && colsum > 0.0 && colsum < 0x1p1000) {
     int qs = 0;
     (void)frexp(colsum, &qs);                                    // colsum < 2^qs
-    if (qs + 1 < q + kbits) {
-      e = 63 - (qs + 1);
+    if (qs < q + kbits) {   // sums < 2^(e + qs) = 2^63, the roundings of <= 2^31 values add < 2^30: no u64 wraps
+      e = 63 - qs;
       fine = qm - 1 + e + 1 >= 40;
     }
   }
