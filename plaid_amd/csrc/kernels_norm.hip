@@ -1824,6 +1824,37 @@ median_calibrate_kernel(const double* __restrict__ medK, const double* __restric
 //    (bracket missed, a slice overflowed, empty column, or the matrix as a whole follows the other ignore.zero rule than
 //    the calibration sample did).
 constexpr int kFmedItems = 64;   // candidates per lane: 4,096 per column
+template <int ITEMS>
+__device__ __forceinline__ void fmed_select_from(const unsigned long long* __restrict__ cand, int c, int32_t nslice, int32_t capc,
+                                                 const uint32_t* s_off, uint32_t total, int64_t k1, int64_t k2, uint32_t below,
+                                                 uint32_t* s_hist, int lane, double* __restrict__ med, int32_t* __restrict__ status) {
+  // gather the candidates: flat index f -> slice by binary search in the offsets
+  uint64_t key[ITEMS];
+  uint64_t kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const uint32_t f = (uint32_t)t * 64u + (uint32_t)lane;
+    uint64_t kk = ~0ull;
+    if (f < total) {
+      int lo = 0, hi = nslice;              // largest s with s_off[s] <= f
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= f) lo = mid; else hi = mid; }
+      const double v = __longlong_as_double((long long)cand[((int64_t)c * nslice + lo) * capc + (f - s_off[lo])]);
+      kk = masked_key(v, 0);
+      kmin = kk < kmin ? kk : kmin;
+      kmax = kk > kmax ? kk : kmax;
+    }
+    key[t] = kk;
+  }
+  kmin = wave_min_u64(kmin);
+  kmax = wave_max_u64(kmax);
+  const uint64_t a1 = wave_radix_select<ITEMS>(key, (uint32_t)(k1 - below), total, kmin, kmax, s_hist, lane);
+  const uint64_t a2 = (k2 == k1) ? a1 : wave_radix_select<ITEMS>(key, (uint32_t)(k2 - below), total, kmin, kmax, s_hist, lane);
+  if (lane == 0) {
+    med[c] = (a1 == a2) ? key_to_f64(a1) : 0.5 * (key_to_f64(a1) + key_to_f64(a2));
+    status[c] = 1;
+  }
+}
+
 __global__ void __launch_bounds__(64)
 median_select_kernel(const unsigned long long* __restrict__ cand, const uint4* __restrict__ cnt, int32_t n, int32_t nslice,
                      int32_t capc, int32_t m, const double* __restrict__ cal, int ignore_zero_mode,
@@ -1866,31 +1897,12 @@ median_select_kernel(const unsigned long long* __restrict__ cand, const uint4* _
       wave_lds_sync();
       continue;
     }
-    // gather the candidates: flat index f -> slice by binary search in the offsets
-    uint64_t key[kFmedItems];
-    uint64_t kmin = ~0ull, kmax = 0ull;
-#pragma unroll
-    for (int t = 0; t < kFmedItems; ++t) {
-      const uint32_t f = (uint32_t)t * 64u + (uint32_t)lane;
-      uint64_t kk = ~0ull;
-      if (f < total) {
-        int lo = 0, hi = nslice;              // largest s with s_off[s] <= f
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= f) lo = mid; else hi = mid; }
-        const double v = __longlong_as_double((long long)cand[((int64_t)c * nslice + lo) * capc + (f - s_off[lo])]);
-        kk = masked_key(v, 0);
-        kmin = kk < kmin ? kk : kmin;
-        kmax = kk > kmax ? kk : kmax;
-      }
-      key[t] = kk;
-    }
-    kmin = wave_min_u64(kmin);
-    kmax = wave_max_u64(kmax);
-    const uint64_t a1 = wave_radix_select<kFmedItems>(key, (uint32_t)(k1 - below), total, kmin, kmax, s_hist, lane);
-    const uint64_t a2 = (k2 == k1) ? a1 : wave_radix_select<kFmedItems>(key, (uint32_t)(k2 - below), total, kmin, kmax, s_hist, lane);
-    if (lane == 0) {
-      med[c] = (a1 == a2) ? key_to_f64(a1) : 0.5 * (key_to_f64(a1) + key_to_f64(a2));
-      status[c] = 1;
-    }
+    // (ITEMS candidates per lane, by how many there are: the gather and the selection passes cost in proportion, and a
+    // bracket of 1-5 % of 50,000 scores holds 500 ... 2,500 candidates, not the 4,096 the lists could hold)
+    if (total <= 8u * 64u) fmed_select_from<8>(cand, c, nslice, capc, s_off, total, k1, k2, below, s_hist, lane, med, status);
+    else if (total <= 16u * 64u) fmed_select_from<16>(cand, c, nslice, capc, s_off, total, k1, k2, below, s_hist, lane, med, status);
+    else if (total <= 32u * 64u) fmed_select_from<32>(cand, c, nslice, capc, s_off, total, k1, k2, below, s_hist, lane, med, status);
+    else fmed_select_from<kFmedItems>(cand, c, nslice, capc, s_off, total, k1, k2, below, s_hist, lane, med, status);
     wave_lds_sync();
   }
 }

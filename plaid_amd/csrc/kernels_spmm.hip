@@ -2213,7 +2213,8 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
   const int32_t kCapC = std::max<int32_t>(64, (8192 / std::max<int32_t>(nslice, 1)) & ~15);
   // worth it from ~1e9 scores on (measured: the classifying epilogue costs 0.4 ms per 1e9 scores and the calibration
   // ~0.45 ms per call, the standalone median kernel 1.4 ms per 1e9 scores -- but it has a floor of ~1 ms as soon as a few
-  // hundred columns are left to it; at 6e8 scores, the reference's pbmc3k shape, the plain pair is faster)
+  // hundred columns are left to it; at 6e8 scores, the reference's pbmc3k shape, the plain pair is faster: 6.5 against
+  // 7.7 ms for plaid() on counts, also with the selection kernel of late round 4; rank weights break even at 2e8)
   const bool big_enough = ctx->opt_fused_medians == 1 || (int64_t)gs->m * n >= 1000000000ll;
   const bool eligible = ctx->opt_fused_medians != 2 && big_enough && sm == 1 && nnz >= 0 && gs->m > 6144 && n >= 4 * K &&
                         flags != nullptr && nslice <= 256 && g_ablate == 0 && pair_kernel_mode(ctx) != 0 && !gs->pair.slices.empty();
@@ -2279,6 +2280,8 @@ int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, i
   ctx->fmed.valid = false;   // (consumed: S is about to be shifted)
   const int rc = launch_median_select(ctx, f.cand, f.cnt, n, f.nslice, f.capc, m, f.cal, ignore_zero, flags, med, f.status);
   if (rc != PLAIDHIP_OK) return rc;
+  // (a workgroup per open column -- 17 short sweeps each -- instead of the streaming kernel's wavefront per column was
+  // measured for the few dozen columns usually left: 1.36 against 1.18 ms for the whole phase at C3; not kept)
   return launch_col_medians(ctx, S, lds, m, n, ignore_zero, flags, med, f.status);
 }
 
