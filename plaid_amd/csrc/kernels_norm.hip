@@ -2067,10 +2067,22 @@ int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, i
                          const double* med, double add, const double* red) {
   ctx->fmed.valid = false;   // (S changes: the candidates of a fused crossprod are history)
   if (n == 0 || m == 0) return PLAIDHIP_OK;
-  int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);   // workgroups per column: one trip of 2,048 values each, up to 16
+  // workgroups per column: one trip of 2,048 values each, up to 32 -- a 50,000-set column is one trip for every workgroup.
+  // One grid row per column while the grid allows it (65,535 rows); beyond that 2,048 rows that each walk ~n / 2,048
+  // columns (with 65,535 rows a third of them would walk two columns and the rest one).  Measured, late round 4
+  // (tools/bench_shift.py big, PLAIDHIP_SHIFT_BX / _BY in the tools build; it was 16 workgroups and 32,768 rows):
+  // same box, old -> new: 100,000 x 50,000: 14.44 -> 14.23 ms (13.1 on another box); 8,192 x 50,000: 1.183 -> 1.14 ms;
+  // 8,192 x 49,999 (every other column misaligned): 1.325 -> 1.16 ms; 10,000 x 61,459: 1.94 -> 1.82 ms; 10,000 x 5,000:
+  // unchanged (three workgroups per column either way).
+  int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);
   if (bx < 1) bx = 1;
-  if (bx > 16) bx = 16;                         // (32 measured equal on 8k columns x 50k sets and 7 % slower on 100k)
-  int by = n < 32768 ? n : 32768;
+  int bx_cap = 32;
+  int by = n <= 65535 ? n : 2048;
+#ifdef PLAIDHIP_DIAG
+  if (const char* e = getenv("PLAIDHIP_SHIFT_BX")) bx_cap = atoi(e);
+  if (const char* e = getenv("PLAIDHIP_SHIFT_BY")) by = n < atoi(e) ? n : atoi(e);   // (rows = min(n, value))
+#endif
+  if (bx > bx_cap) bx = bx_cap;
   hipLaunchKernelGGL(shift_columns_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, S, lds, m, n, med, add, red);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;

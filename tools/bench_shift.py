@@ -12,9 +12,13 @@ def main():
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     ctx = plaid_amd.Context(0, stream.cuda_stream)
-    for n, m in ((10000, 5000), (8192, 50000), (8192, 49999)):
+    shapes = ((10000, 5000), (8192, 50000), (8192, 49999))
+    if len(sys.argv) > 1 and sys.argv[1] == "big":   # + the reference's published shape and config 3's full size (40 GB)
+        shapes += ((10000, 61459), (100000, 50000))
+    for n, m in shapes:
         with torch.cuda.stream(stream):
-            S = torch.randn((n, m), dtype=torch.float64, device=dev)
+            S = torch.empty((n, m), dtype=torch.float64, device=dev)
+            S.zero_()
             med = torch.randn(n, dtype=torch.float64, device=dev)
             red = torch.tensor([1.0, 2.0], dtype=torch.float64, device=dev)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
