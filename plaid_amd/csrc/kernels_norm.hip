@@ -1764,8 +1764,21 @@ colmean_predict_kernel(const int32_t* __restrict__ Xp, const int32_t* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double al = alpha_div != nullptr ? alpha / *alpha_div : alpha;
   for (int c = blockIdx.x * 4 + wave; c < n; c += gridDim.x * 4) {
-    double s = 0.0;
-    for (int q = Xp[c] + lane; q < Xp[c + 1]; q += 64) s += Xx[q] * u[Xi[q]];
+    // (four independent chains: the loop is a load, a dependent gather and an add -- one round trip per 64 values when
+    // rolled, 0.54 ms for the 1e8 stored values of config 3)
+    const int q1 = Xp[c + 1];
+    int q = Xp[c] + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (; q + 192 < q1; q += 256) {
+      const int i0 = Xi[q], i1 = Xi[q + 64], i2 = Xi[q + 128], i3 = Xi[q + 192];
+      const double x0 = Xx[q], x1 = Xx[q + 64], x2 = Xx[q + 128], x3 = Xx[q + 192];
+      s0 += x0 * u[i0];
+      s1 += x1 * u[i1];
+      s2 += x2 * u[i2];
+      s3 += x3 * u[i3];
+    }
+    for (; q < q1; q += 64) s0 += Xx[q] * u[Xi[q]];
+    double s = (s0 + s1) + (s2 + s3);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) pred[c] = al * s + beta_kappa;
   }
