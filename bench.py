@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--genes", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=10000, help="C2 samples per GPU")
     ap.add_argument("--sets", type=int, default=5000, help="C2 gene sets")
-    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4", "ref"],
+    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4", "ref", "c3real"],
                     help="N = 1: which blocks to run next to the C2 headline (default: all)")
     ap.add_argument("--profile", action="store_true",
                     help="profiling run (tools/profile_round.sh): ONLY the block --config names, no C2 headline, no pre-heat, "
@@ -483,13 +483,15 @@ def ssgsea_dense_oracle(c_oracle, np, X, Gp, Gi, alpha, threads):
 
 
 # ----------------------------------------------------------------------------------------- C3 / C5 (sparse ssGSEA)
-def run_sparse_ssgsea(a, env, n, label, collective):
+def run_sparse_ssgsea(a, env, n, label, collective, real_sets=False):
+    """`real_sets`: the collection has the shape of the reference's own (synth.geneset_csc_real: sizes 3 ... 5,000 + an
+    all-genes set, hub genes, duplicated sets) instead of 15 ... 500 uniformly chosen genes; no CPU-baseline leg then"""
     import numpy as np
     torch, dist, ctx, dev, stream = env["torch"], env["dist"], env["ctx"], env["dev"], env["stream"]
     world, rank = env["world"], env["rank"]
     from plaid_amd import synth
     g, m, alpha = a.genes, a.big_sets, 0.25
-    Gp, Gi = synth.geneset_csc(g, m)
+    Gp, Gi = synth.geneset_csc_real(g, m) if real_sets else synth.geneset_csc(g, m)
     z = int(Gp[-1])
     t0 = time.perf_counter()
     gs = ctx.geneset(g, Gp, Gi)
@@ -559,6 +561,7 @@ def run_sparse_ssgsea(a, env, n, label, collective):
     out = {
         "workload": f"{label}: replaid.ssgsea(alpha={alpha}) on sparse {g} genes x {n} cells"
                     f"{'/GPU' if collective else ''} ({nnz} stored values, {100.0 * nnz / (g * n):.2f} %) x {m} gene sets "
+                    f"{'of realistic shape (sizes 3..' + str(g) + ', Zipf gene popularity, an all-genes set, duplicated sets) ' if real_sets else ''}"
                     f"(z={z}), fp64, inputs resident in HBM",
         "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
         "scores_per_s": round(float(world if collective else 1) * n * m / (elapsed / steps), 1),
@@ -587,14 +590,15 @@ def run_sparse_ssgsea(a, env, n, label, collective):
         ph = Xp[:nc + 1].cpu().numpy()
         zc = int(ph[-1])
         ih, xh = Xi[:zc].cpu().numpy(), Xx[:zc].cpu().numpy()
-        S1, t1 = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, 1)
-        nt = _cpu_threads()
-        _, tn = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, nt)
-        out["cpu_baseline"] = {
-            "value": round(m * nc / sum(t1), 1), "unit": "scores/s", "cores": 1, "kind": "port",
-            "sample": f"first {nc} of {n} cells x {m} sets, plain-C oracle: sparse_colranks+pow {t1[0]:.2f} s, crossprod "
-                      f"(Gustavson order) {t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
-            "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
+        if not real_sets:
+            S1, t1 = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, 1)
+            nt = _cpu_threads()
+            _, tn = ssgsea_csc_oracle(c_oracle, np, ph, ih, xh, g, Gp, Gi, alpha, nt)
+            out["cpu_baseline"] = {
+                "value": round(m * nc / sum(t1), 1), "unit": "scores/s", "cores": 1, "kind": "port",
+                "sample": f"first {nc} of {n} cells x {m} sets, plain-C oracle: sparse_colranks+pow {t1[0]:.2f} s, crossprod "
+                          f"(Gustavson order) {t1[1]:.2f} s, normalize_medians {t1[2]:.2f} s",
+                "all_cores": {"value": round(m * nc / sum(tn), 1), "cores": nt}, "cpu_count": os.cpu_count()}
         # checker: probe cells of the launch that was timed (first / around element offset 2^31 / last), phase by phase
         from oracle import fullsize
         try:
@@ -1118,7 +1122,7 @@ def main():
     env = {"torch": torch, "dist": dist, "ctx": ctx, "dev": dev, "stream": stream, "world": world, "rank": rank,
            "use_dist": use_dist}
 
-    profile_only = a.profile and a.config in ("c3", "c4", "ref") and world == 1
+    profile_only = a.profile and a.config in ("c3", "c4", "ref", "c3real") and world == 1
     if a.profile:
         a.preheat_steps = 0
     c2 = None if profile_only else run_c2(a, env)
@@ -1127,8 +1131,9 @@ def main():
         def ref_blocks():
             return {nm: run_ref_shape(a, env, nm) for nm in REF_PUBLISHED}
         for name, fn in (("c3", lambda: run_sparse_ssgsea(a, env, a.c3_cells, "C3", False)), ("c4", lambda: run_c4(a, env)),
-                         ("ref_shape", ref_blocks)):
-            if a.config in ("all", name) or (name == "ref_shape" and a.config == "ref"):
+                         ("ref_shape", ref_blocks),
+                         ("c3_real", lambda: run_sparse_ssgsea(a, env, a.c3_cells, "C3 on a reference-shaped collection", False, True))):
+            if a.config in ("all", name) or (name == "ref_shape" and a.config == "ref") or (name == "c3_real" and a.config == "c3real"):
                 try:
                     blocks[name] = fn()
                 except Exception as exc:  # a failing secondary block must not take the headline line with it
