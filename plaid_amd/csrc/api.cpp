@@ -236,23 +236,23 @@ extern "C" {
 
 int plaidhip_version(void) { return PLAIDHIP_VERSION; }
 
-int plaidhip_set_precision(plaidhip_ctx* ctx, int mode) {
+int plaidhip_set_precision(plaidhip_ctx* ctx, int mode) try {
   PH_CTX(ctx);
   PH_REQUIRE(mode == PLAIDHIP_PRECISION_F64 || mode == PLAIDHIP_PRECISION_MIXED, "set_precision: unknown mode %d", mode);
   ctx->precision = mode;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_set_stream(plaidhip_ctx* ctx, void* stream) {
+int plaidhip_set_stream(plaidhip_ctx* ctx, void* stream) try {
   PH_CTX(ctx);
   PH_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream) PH_HIP(hipStreamDestroy(ctx->stream));
   ctx->stream = reinterpret_cast<hipStream_t>(stream);   // nullptr: the null stream
   ctx->own_stream = false;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
+int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) try {
   PH_CTX(ctx);
   switch (option) {
     case PLAIDHIP_OPT_SPMM_DENSE_KERNEL:
@@ -291,7 +291,7 @@ int plaidhip_set_option(plaidhip_ctx* ctx, int option, int value) {
       PH_REQUIRE(false, "set_option: unknown option %d", option);
   }
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 #ifdef PLAIDHIP_DIAG
 int plaidhip_debug_set_ablation(int mode, void* dbg) { debug_set_ablation(mode, dbg); return PLAIDHIP_OK; }
@@ -301,7 +301,7 @@ int plaidhip_debug_set_median_stamps(void* dbg) { debug_set_median_stamps(dbg); 
 
 const char* plaidhip_last_error_string(void) { return g_err; }
 
-int plaidhip_device_count(int* count) {
+int plaidhip_device_count(int* count) try {
   PH_REQUIRE(count != nullptr, "device_count: null out pointer");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -311,9 +311,9 @@ int plaidhip_device_count(int* count) {
   }
   *count = n;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_init(int device, void* stream, plaidhip_ctx** out) {
+int plaidhip_init(int device, void* stream, plaidhip_ctx** out) try {
   PH_REQUIRE(out != nullptr, "init: null out pointer");
   *out = nullptr;
   int n = 0;
@@ -357,18 +357,18 @@ int plaidhip_init(int device, void* stream, plaidhip_ctx** out) {
   }
   *out = ctx;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_limit(int which, int64_t* value) {
+int plaidhip_limit(int which, int64_t* value) try {
   PH_REQUIRE(value != nullptr, "limit: null value");
   switch (which) {
     case PLAIDHIP_LIMIT_SPARSE_RANK_COLUMN: *value = max_sparse_rank_column(); return PLAIDHIP_OK;
     case PLAIDHIP_LIMIT_LDS_GENES: *value = kMaxLdsGenes; return PLAIDHIP_OK;
     default: set_error("limit: unknown id %d", which); return PLAIDHIP_EINVAL;
   }
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_finalize(plaidhip_ctx* ctx) {
+int plaidhip_finalize(plaidhip_ctx* ctx) try {
   if (!ctx) return PLAIDHIP_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
@@ -389,46 +389,46 @@ int plaidhip_finalize(plaidhip_ctx* ctx) {
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_synchronize(plaidhip_ctx* ctx) {
+int plaidhip_synchronize(plaidhip_ctx* ctx) try {
   PH_CTX(ctx);
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr) {
+int plaidhip_malloc(plaidhip_ctx* ctx, size_t bytes, void** dptr) try {
   PH_CTX(ctx);
   PH_REQUIRE(dptr != nullptr, "malloc: null out pointer");
   PH_HIP(hipMalloc(dptr, bytes ? bytes : 16));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_free(plaidhip_ctx* ctx, void* dptr) {
+int plaidhip_free(plaidhip_ctx* ctx, void* dptr) try {
   PH_CTX(ctx);
   if (dptr) PH_HIP(hipFree(dptr));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_memcpy_h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+int plaidhip_memcpy_h2d(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) try {
   PH_CTX(ctx);
   if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_memcpy_d2h(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+int plaidhip_memcpy_d2h(plaidhip_ctx* ctx, void* dst, const void* src, size_t bytes) try {
   PH_CTX(ctx);
   if (bytes) PH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // ---- device-level ---------------------------------------------------------------------
 
 int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
                                 int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
-                                double beta, void* S, int64_t lds, void* flags) {
+                                double beta, void* S, int64_t lds, void* flags) try {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm: null geneset");
   PH_REQUIRE(n >= 0, "spmm: n=%d", n);
@@ -439,11 +439,11 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(X), ldx, n, stat, alpha,
                                static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                                static_cast<uint32_t*>(flags));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,
                                 int64_t ldr, int32_t n, int stat, double alpha, const void* alpha_div,
-                                double beta, void* S, int64_t lds, void* flags) {
+                                double beta, void* S, int64_t lds, void* flags) try {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm_ranks: null geneset");
   PH_REQUIRE(n >= 0, "spmm_ranks: n=%d", n);
@@ -454,11 +454,11 @@ int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(R), ldr, n, stat, alpha,
                                static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                                static_cast<uint32_t*>(flags), PLAIDHIP_X_RANKS);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                               const void* Xi, const void* Xx, int32_t n, int64_t nnz, int stat, double alpha,
-                              const void* alpha_div, double beta, void* S, int64_t lds, void* flags) {
+                              const void* alpha_div, double beta, void* S, int64_t lds, void* flags) try {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm_csc: null geneset");
   PH_REQUIRE(n >= 0, "spmm_csc: n=%d", n);
@@ -469,10 +469,10 @@ int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                              static_cast<const double*>(Xx), n, nnz, stat, alpha,
                              static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                              static_cast<uint32_t*>(flags));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_crossprod_weighted_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
-                                        int32_t m, const void* Y, int64_t ldy, int32_t n, void* S, int64_t lds) {
+                                        int32_t m, const void* Y, int64_t ldy, int32_t n, void* S, int64_t lds) try {
   PH_CTX(ctx);
   PH_REQUIRE(g > 0 && m >= 0 && n >= 0, "crossprod_weighted: bad dims g=%d m=%d n=%d", g, m, n);
   PH_REQUIRE(Wp != nullptr, "crossprod_weighted: null x@p");
@@ -482,11 +482,11 @@ int plaidhip_dev_crossprod_weighted_f64(plaidhip_ctx* ctx, const void* Wp, const
   return launch_crossprod_weighted_f64(ctx, static_cast<const int32_t*>(Wp), static_cast<const int32_t*>(Wi),
                                        static_cast<const double*>(Wx), g, m, static_cast<const double*>(Y), ldy, nullptr,
                                        nullptr, nullptr, n, static_cast<double*>(S), lds);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_crossprod_weighted_csc_f64(plaidhip_ctx* ctx, const void* Wp, const void* Wi, const void* Wx, int32_t g,
                                             int32_t m, const void* Yp, const void* Yi, const void* Yx, int32_t n,
-                                            void* S, int64_t lds) {
+                                            void* S, int64_t lds) try {
   PH_CTX(ctx);
   PH_REQUIRE(g > 0 && m >= 0 && n >= 0, "crossprod_weighted_csc: bad dims g=%d m=%d n=%d", g, m, n);
   PH_REQUIRE(Wp != nullptr, "crossprod_weighted_csc: null x@p");
@@ -496,7 +496,7 @@ int plaidhip_dev_crossprod_weighted_csc_f64(plaidhip_ctx* ctx, const void* Wp, c
                                        static_cast<const double*>(Wx), g, m, nullptr, 0, static_cast<const int32_t*>(Yp),
                                        static_cast<const int32_t*>(Yi), static_cast<const double*>(Yx), n,
                                        static_cast<double*>(S), lds);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // which: 0 dense columns (matrixStats::colRanks: average / min / max / first / last / dense), 1 the stored values of a
 // dgCMatrix (base::rank, R/plaid.R:639-642: no "dense"), 2 a dgCMatrix with its zeros ranked (sparseMatrixStats::colRanks,
@@ -520,7 +520,7 @@ static int check_ties(int ties, int which = 0, double power = 1.0, const void* c
 
 int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp,
                                     const void* Xi, const void* Rx, int32_t n, int64_t nnz, int stat, double alpha,
-                                    const void* rmax, double beta, void* S, int64_t lds, void* flags) {
+                                    const void* rmax, double beta, void* S, int64_t lds, void* flags) try {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm_csc_ranks: null geneset");
   PH_REQUIRE(n >= 0, "spmm_csc_ranks: n=%d", n);
@@ -532,11 +532,11 @@ int plaidhip_dev_spmm_csc_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
                              static_cast<const double*>(Rx), n, nnz, stat, alpha, static_cast<const double*>(rmax), beta,
                              static_cast<double*>(S), lds, static_cast<uint32_t*>(flags), /*bounded=*/true,
                              static_cast<const double*>(rmax), 0.0);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp, const void* Xi,
                                     const void* Xx, int32_t n, int64_t nnz, int stat, double alpha, const void* alpha_div,
-                                    double beta, void* S, int64_t lds, void* flags, const void* rmax) {
+                                    double beta, void* S, int64_t lds, void* flags, const void* rmax) try {
   PH_CTX(ctx);
   PH_REQUIRE(gs != nullptr, "spmm_csc_fused: null geneset");
   PH_REQUIRE(n >= 0, "spmm_csc_fused: n=%d", n);
@@ -548,10 +548,10 @@ int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
   return launch_spmm_csc_fused_f64(ctx, gs, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
                                    static_cast<const double*>(Xx), n, nnz, stat, alpha, div, beta, static_cast<double*>(S), lds,
                                    static_cast<uint32_t*>(flags), rmax != nullptr, static_cast<const double*>(rmax), 0.0);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
-                                    const void* flags, void* med) {
+                                    const void* flags, void* med) try {
   PH_CTX(ctx);
   PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "col_medians_resume: bad dims m=%d n=%d lds=%lld", m, n, (long long)lds);
   PH_REQUIRE(n == 0 || (S != nullptr && med != nullptr), "col_medians_resume: null S/med");
@@ -559,9 +559,9 @@ int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t ld
   PH_REQUIRE(ignore_zero >= 0 || flags != nullptr, "col_medians_resume: ignore_zero = auto needs the flag words");
   return launch_col_medians_resume(ctx, static_cast<const double*>(S), lds, m, n, ignore_zero,
                                    static_cast<const uint32_t*>(flags), static_cast<double*>(med));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]) {
+int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]) try {
   PH_CTX(ctx);
   PH_REQUIRE(info != nullptr, "fused_medians_info: null info");
   info[0] = ctx->fmed.n;
@@ -569,11 +569,11 @@ int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]) {
   info[2] = (int64_t)reinterpret_cast<intptr_t>(ctx->fmed.cal);
   info[3] = ctx->fmed.valid ? 1 : 0;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ldx, int32_t g,
                                     int32_t n, int ties, int is_signed, double power, void* R,
-                                    int64_t ldr, void* colmax) {
+                                    int64_t ldr, void* colmax) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 0, power, colmax));
   PH_REQUIRE(g >= 0 && n >= 0, "colranks: bad dims g=%d n=%d", g, n);
@@ -581,11 +581,11 @@ int plaidhip_dev_colranks_dense_f64(plaidhip_ctx* ctx, const void* X, int64_t ld
   PH_REQUIRE(ldx >= g && ldr >= g, "colranks: leading dims below g");
   return launch_colranks_dense_f64(ctx, static_cast<const double*>(X), ldx, g, n, ties, is_signed,
                                    power, static_cast<double*>(R), ldr, static_cast<double*>(colmax));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xx, int32_t n,
                                   int32_t max_col_nnz, int ties, int is_signed, double power, void* Rx,
-                                  void* colmax) {
+                                  void* colmax) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 1, power, colmax));
   PH_REQUIRE(n >= 0 && max_col_nnz >= 0, "colranks_csc: n=%d max_col_nnz=%d", n, max_col_nnz);
@@ -593,11 +593,11 @@ int plaidhip_dev_colranks_csc_f64(plaidhip_ctx* ctx, const void* Xp, const void*
   return launch_colranks_csc_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const double*>(Xx),
                                  n, max_col_nnz, ties, is_signed, power, static_cast<double*>(Rx),
                                  static_cast<double*>(colmax));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx,
                                         int32_t g, int32_t n, int ties, int is_signed, double power,
-                                        void* R, int64_t ldr, void* colmax) {
+                                        void* R, int64_t ldr, void* colmax) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
@@ -605,11 +605,11 @@ int plaidhip_dev_colranks_csc_dense_f64(plaidhip_ctx* ctx, const void* Xp, const
   return launch_colranks_csc_dense_f64(ctx, static_cast<const int32_t*>(Xp), static_cast<const int32_t*>(Xi),
                                        static_cast<const double*>(Xx), g, n, ties, is_signed, power,
                                        static_cast<double*>(R), ldr, static_cast<double*>(colmax));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, const void* Xi, const void* Xx, int32_t g,
                                            int32_t n, int32_t max_col_nnz, int ties, int is_signed, double power,
-                                           void* Rx_scratch, void* R, int64_t ldr, void* colmax) {
+                                           void* Rx_scratch, void* R, int64_t ldr, void* colmax) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && ldr >= g, "colranks_csc_dense_nz: bad dims g=%d n=%d ldr=%lld", g, n, (long long)ldr);
@@ -625,16 +625,16 @@ int plaidhip_dev_colranks_csc_dense_nz_f64(plaidhip_ctx* ctx, const void* Xp, co
                                           static_cast<const double*>(Xx), g, n, max_col_nnz, ties, is_signed, power,
                                           static_cast<double*>(Rx_scratch), static_cast<double*>(R), ldr,
                                           static_cast<double*>(colmax));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags) {
+int plaidhip_dev_minflags(plaidhip_ctx* ctx, const void* S, int64_t count, void* flags) try {
   PH_CTX(ctx);
   PH_REQUIRE(flags != nullptr && count >= 0, "minflags: bad arguments");
   return launch_minflags(ctx, static_cast<const double*>(S), count, static_cast<uint32_t*>(flags));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n,
-                             int ignore_zero, const void* flags, void* med) {
+                             int ignore_zero, const void* flags, void* med) try {
   PH_CTX(ctx);
   PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "col_medians: bad dims m=%d n=%d lds=%lld", m, n, (long long)lds);
   PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "col_medians: bad ignore_zero %d", ignore_zero);
@@ -642,49 +642,49 @@ int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int3
   PH_REQUIRE(n == 0 || med != nullptr, "col_medians: null med");
   return launch_col_medians(ctx, static_cast<const double*>(S), lds, m, n, ignore_zero,
                             static_cast<const uint32_t*>(flags), static_cast<double*>(med));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) {
+int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) try {
   PH_CTX(ctx);
   PH_REQUIRE(out != nullptr && count >= 0, "sum: bad arguments");
   return launch_sum(ctx, static_cast<const double*>(v), count, static_cast<double*>(out));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_dev_max(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) {
+int plaidhip_dev_max(plaidhip_ctx* ctx, const void* v, int64_t count, void* out) try {
   PH_CTX(ctx);
   PH_REQUIRE(out != nullptr && count >= 0, "max: bad arguments");
   return launch_max(ctx, static_cast<const double*>(v), count, static_cast<double*>(out));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,
-                               const void* med, double add, const void* red) {
+                               const void* med, double add, const void* red) try {
   PH_CTX(ctx);
   PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "shift_columns: bad dims");
   return launch_shift_columns(ctx, static_cast<double*>(S), lds, m, n, static_cast<const double*>(med), add,
                               static_cast<const double*>(red));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // ---- host-level pipelines ---------------------------------------------------------------
 
 
 int plaidhip_plaid_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                          const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize,
-                         double* S_out) {
+                         double* S_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_dense: bad stat %d", stat);
   PH_REQUIRE(n == 0 || (X && S_out), "plaid_dense: null X/S_out");
   // one shard on this context: pipelined upload, crossprod per column panel, normalize_medians, download (multi.cpp)
   return run_sharded(&ctx, 1, 0, nullptr, nullptr, X, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_plaid_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                        int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                       int stat, int normalize, double* S_out) {
+                       int stat, int normalize, double* S_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_csc: bad stat %d", stat);
   PH_REQUIRE(Xp != nullptr && (n == 0 || S_out), "plaid_csc: null Xp/S_out");
   return run_sharded(&ctx, 1, 0, Xp, Xi, Xx, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // chunked_crossprod with a general sparse x: upload the slots, one launch, download (host pointers)
 static int crossprod_weighted_host(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx, int32_t g,
@@ -733,21 +733,21 @@ static int crossprod_weighted_host(plaidhip_ctx* ctx, const int32_t* Wp, const i
 }
 
 int plaidhip_crossprod_weighted_dense(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
-                                      int32_t g, int32_t m, const double* Y, int32_t n, double* S_out) {
+                                      int32_t g, int32_t m, const double* Y, int32_t n, double* S_out) try {
   PH_CTX(ctx);
   return crossprod_weighted_host(ctx, Wp, Wi, Wx, g, m, Y, nullptr, nullptr, nullptr, n, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_crossprod_weighted_csc(plaidhip_ctx* ctx, const int32_t* Wp, const int32_t* Wi, const double* Wx,
                                     int32_t g, int32_t m, const int32_t* Yp, const int32_t* Yi, const double* Yx,
-                                    int32_t n, double* S_out) {
+                                    int32_t n, double* S_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(Yp != nullptr, "crossprod_weighted_csc: null y@p");
   return crossprod_weighted_host(ctx, Wp, Wi, Wx, g, m, nullptr, Yp, Yi, Yx, n, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t n, int ignore_zero,
-                               double* med_out) {
+                               double* med_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(m >= 0 && n >= 0, "normalize_medians: bad dims");
   PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "normalize_medians: bad ignore_zero %d", ignore_zero);
@@ -765,10 +765,10 @@ int plaidhip_normalize_medians(plaidhip_ctx* ctx, double* S, int32_t m, int32_t 
   if (med_out) PH_HIP(hipMemcpyAsync(med_out, d_med, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, int ties,
-                            int is_signed, double* R_out) {
+                            int is_signed, double* R_out) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 0));
   PH_REQUIRE(g >= 0 && n >= 0, "colranks_dense: bad dims");
@@ -782,10 +782,10 @@ int plaidhip_colranks_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32
   PH_TRY(copy_home(ctx, R_out, dR.p, (size_t)g * n * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx, int32_t n,
-                          int ties, int is_signed, double* Rx_out) {
+                          int ties, int is_signed, double* Rx_out) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 1));
   PH_REQUIRE(n >= 0 && Xp != nullptr, "colranks_csc: bad arguments");
@@ -804,10 +804,10 @@ int plaidhip_colranks_csc(plaidhip_ctx* ctx, const int32_t* Xp, const double* Xx
   PH_TRY(copy_home(ctx, Rx_out, dR.p, (size_t)zx * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
-                                int32_t g, int32_t n, int ties, int is_signed, double* R_out) {
+                                int32_t g, int32_t n, int ties, int is_signed, double* R_out) try {
   PH_CTX(ctx);
   PH_TRY(check_ties(ties, 2));
   PH_REQUIRE(g >= 0 && n >= 0 && Xp != nullptr, "colranks_csc_dense: bad arguments");
@@ -840,14 +840,14 @@ int plaidhip_colranks_csc_dense(plaidhip_ctx* ctx, const int32_t* Xp, const int3
   PH_TRY(copy_home(ctx, R_out, dR.p, (size_t)g * n * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
-                        const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+                        const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) try {
   PH_CTX(ctx);
   // rX = colranks(X, ties.method="min") / nrow(X) - 0.5 ; plaid(rX, normalize=FALSE)  (R/plaid.R:215-217)
   return run_sharded(&ctx, 1, 1, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // replaid.sing for a dgCMatrix X: colranks(X, ties.method = "min") ranks the zeros too (sparse branch without keep.zero,
 // R/plaid.R:602-609), / nrow(X) - 0.5, plaid(normalize = FALSE) (:215-217).  The reference densifies X to rank it; here
@@ -855,29 +855,29 @@ int plaidhip_sing_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
 // stored values (zeros tie), and the rank crossprod runs on each panel (multi.cpp: shard_worker): neither the host nor
 // the PCIe link sees a dense X.
 int plaidhip_sing_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g, int32_t n,
-                      const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+                      const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(Xp != nullptr, "sing_csc: null Xp");
   return run_sharded(&ctx, 1, 1, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_ssgsea_dense(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n,
                           const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha,
-                          double* S_out) {
+                          double* S_out) try {
   PH_CTX(ctx);
   // rX = colranks(X, ties="average")^(1+alpha) ; rX/max(rX) - 0.5 ; plaid(mean, normalize=TRUE)  (R/plaid.R:245-253)
   return run_sharded(&ctx, 1, 2, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 1, alpha, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_ssgsea_csc(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* Xx,
                         int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                        double alpha, double* S_out) {
+                        double alpha, double* S_out) try {
   PH_CTX(ctx);
   PH_REQUIRE(Xp != nullptr, "ssgsea_csc: null Xp");
   // sparse branch: ranks of the non-zeros only, zeros stay 0 (R/plaid.R:600-601, 631-650); the "- 0.5" of
   // R/plaid.R:251 applies to the zeros too, which the (alpha, beta) epilogue covers
   return run_sharded(&ctx, 1, 2, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 1, alpha, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 }  // extern "C"
 
@@ -946,7 +946,7 @@ extern "C" {
 
 int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                    int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                   const double* k_full, double rmax, double* S_out) {
+                   const double* k_full, double rmax, double* S_out) try {
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(rmax > 0, "ucell: rmax must be positive");
@@ -971,11 +971,11 @@ int plaidhip_ucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, cons
   PH_TRY(copy_home(ctx, S_out, dS.p, (size_t)m * n * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                     int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                    double auc_max_rank, double* S_out) {
+                    double auc_max_rank, double* S_out) try {
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(auc_max_rank > 0, "aucell: aucMaxRank must be positive");
@@ -992,11 +992,11 @@ int plaidhip_aucell(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, con
   PH_TRY(copy_home(ctx, S_out, dS.p, (size_t)m * n * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const double* X_or_x,
                   int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m,
-                  int remove_log2, int score_mean, double* S_out, int* removed_log2) {
+                  int remove_log2, int score_mean, double* S_out, int* removed_log2) try {
   PH_CTX(ctx);
   if (removed_log2 != nullptr) *removed_log2 = remove_log2 > 0 ? 1 : 0;
   PH_TRY(check_host_common(Gp, g, n, m));
@@ -1050,35 +1050,35 @@ int plaidhip_scse(plaidhip_ctx* ctx, const int32_t* Xp, const int32_t* Xi, const
     *removed_log2 = (mn == 0.0 && mx < 20.0) ? 1 : 0;
   }
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // Row-wise two-group sums / sums of squared deviations on device pointers: the pieces of plaid.test that a sample-sharded
 // caller all-reduces between (plaid_amd/sharded.py: sharded_plaid_test).  A: rows x n column-major with leading dimension
 // ld; y: 0 / 1 per column; sums / ssd: [2][rows] (group 0, group 1).
 int plaidhip_dev_row_group_sums(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* y,
-                                double* sums) {
+                                double* sums) try {
   PH_CTX(ctx);
   PH_REQUIRE(rows >= 0 && n >= 0 && ld >= rows, "row_group_sums: bad shape rows=%d n=%d ld=%lld", rows, n, (long long)ld);
   if (rows == 0) return PLAIDHIP_OK;
   PH_REQUIRE(sums && (n == 0 || (A && y)), "row_group_sums: null argument");
   PH_TRY(ensure_workspace(ctx, (size_t)row_group_ws_doubles(rows, n) * 8));
   return launch_row_group_moments(ctx, A, ld, rows, n, y, 1, 1, sums, nullptr, static_cast<double*>(ctx->ws));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_row_group_ssd(plaidhip_ctx* ctx, const double* A, int64_t ld, int32_t rows, int32_t n, const int32_t* y,
-                               const double* mean, double* ssd) {
+                               const double* mean, double* ssd) try {
   PH_CTX(ctx);
   PH_REQUIRE(rows >= 0 && n >= 0 && ld >= rows, "row_group_ssd: bad shape rows=%d n=%d ld=%lld", rows, n, (long long)ld);
   if (rows == 0) return PLAIDHIP_OK;
   PH_REQUIRE(ssd && mean && (n == 0 || (A && y)), "row_group_ssd: null argument");
   PH_TRY(ensure_workspace(ctx, (size_t)row_group_ws_doubles(rows, n) * 8));
   return launch_row_group_ssd(ctx, A, ld, rows, n, y, mean, ssd, static_cast<double*>(ctx->ws));
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // The host half of plaid.test (R/plaid.R:410-474): p-values, effect sizes, meta-p and FDR from the reduced statistics.
 // Shared by plaidhip_plaid_test and by sample-sharded callers, which all-reduce the statistics first.
 int plaidhip_plaid_test_finish(int32_t g, int32_t m, const int32_t* Gp, const double* T, double tot1, double tot2,
-                               const double* SM, int64_t n0, int64_t n1, int tests, int metap_method, double* out) {
+                               const double* SM, int64_t n0, int64_t n1, int tests, int metap_method, double* out) try {
   PH_REQUIRE(g >= 0 && m >= 0 && (m == 0 || (Gp && out)), "plaid_test_finish: null Gp / out");
   PH_REQUIRE((tests & 7) != 0 && (tests & ~7) == 0, "plaid_test: tests is a bit mask of 1 (one), 2 (two), 4 (lm)");
   PH_REQUIRE(metap_method == 0 || metap_method == 1, "Invalid method: %d", metap_method);      // R/plaid.R:533
@@ -1120,11 +1120,11 @@ int plaidhip_plaid_test_finish(int32_t g, int32_t m, const int32_t* Gp, const do
   }
   p_adjust_fdr(o_pm, m, o_q);                                                                   // :463
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* y,
                         const int32_t* Gp, const int32_t* Gi, int32_t m, const double* gsetX, int tests,
-                        int metap_method, double* out) {
+                        int metap_method, double* out) try {
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   PH_REQUIRE(m == 0 || out, "plaid_test: null out");
@@ -1179,10 +1179,10 @@ int plaidhip_plaid_test(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n
   for (int32_t i = 0; i < g; ++i) { tot1 += F[i]; tot2 += F[(size_t)ldg + i]; }
   return plaidhip_plaid_test_finish(g, m, Gp, T.data(), tot1, tot2, (tests & 4) ? SM.data() : nullptr, n0, n1, tests,
                                     metap_method, out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, const int32_t* Gp, const int32_t* Gi,
-                  int32_t m, double tau, int rowtf, double* S_out) {
+                  int32_t m, double tau, int rowtf, double* S_out) try {
   PH_CTX(ctx);
   PH_TRY(check_host_common(Gp, g, n, m));
   if ((int64_t)m * n == 0) return PLAIDHIP_OK;
@@ -1233,6 +1233,6 @@ int plaidhip_gsva(plaidhip_ctx* ctx, const double* X, int32_t g, int32_t n, cons
   PH_TRY(copy_home(ctx, S_out, dS.p, (size_t)m * n * 8));
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 }  // extern "C"

@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -39,6 +41,23 @@ constexpr int kScatterChunk = 17 * kScatterBlock;
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
+// Every `int plaidhip_*` entry point is a function-try-block that ends here: a C++ exception (std::bad_alloc from a host-side
+// plan, std::system_error from a thread the system refuses) becomes an error code and a message -- it never unwinds into
+// the caller's C stack (R's, ctypes').  Exceptions inside the library's own worker threads are not covered by this.
+inline int on_exception() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    set_error("out of host memory");
+    return PLAIDHIP_ENOMEM;
+  } catch (const std::exception& e) {
+    set_error("unexpected C++ exception: %s", e.what());
+    return PLAIDHIP_EHIP;
+  } catch (...) {
+    set_error("unexpected C++ exception");
+    return PLAIDHIP_EHIP;
+  }
+}
 
 #define PH_HIP(call)                                                              \
   do {                                                                            \

@@ -540,7 +540,7 @@ int spmm_block_for_genes(int32_t g) {
 }  // namespace plaidhip
 
 extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, const int32_t* Gp,
-                                       const int32_t* Gi, plaidhip_geneset** out) {
+                                       const int32_t* Gi, plaidhip_geneset** out) try {
   PH_REQUIRE(ctx && out, "geneset_create: null ctx/out");
   PH_REQUIRE(g > 0 && m >= 0, "geneset_create: bad dims g=%d m=%d", g, m);
   PH_REQUIRE(Gp != nullptr, "geneset_create: Gp is null");
@@ -828,9 +828,9 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
 fail:
   plaidhip_geneset_destroy(gs);
   return rc;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
+extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) try {
   if (!gs) return PLAIDHIP_OK;
   for (plaidhip_slice& d : gs->slices) {
     hipFree(d.d_tile_idx);
@@ -861,9 +861,9 @@ extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) {
   }
   delete gs;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]) {
+extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]) try {
   PH_REQUIRE(gs && info, "geneset_info: null argument");
   std::memset(info, 0, 8 * sizeof(int64_t));
   info[0] = gs->g;
@@ -875,14 +875,14 @@ extern "C" int plaidhip_geneset_info(const plaidhip_geneset* gs, int64_t info[8]
   info[6] = gs->slices.empty() ? 0 : gs->slices[0].waves;
   info[7] = gs->pair.chunks * 64 * 8;     // padded index slots of the pair plan (dense-X kernel)
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 // Diagnostic / test hook (not part of include/plaidhip.h): builds the pair plan on the host only
 // and checks it.  out[0]=slices out[1]=chunks (all slices) out[2]=memberships found in the plan
 // out[3]=conflicts (two lanes of one ds_read_b128 lane group on the same 16-byte slot in one
 // step) out[4]=memberships scheduled for the wrong set / twice / out of slice.
 extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
-                                              int32_t waves, int64_t out[8]) {
+                                              int32_t waves, int64_t out[8]) try {
   PairPlanHost pp;
   build_pair_plan(g, m, Gp, Gi, waves, pp);
   int64_t found = 0, conflicts = 0, wrong = 0;
@@ -921,7 +921,7 @@ extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_
   out[3] = conflicts;
   out[4] = wrong;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 #ifdef PLAIDHIP_KEEP_HOST_PLANS
 // Test hook of the host-only tools build: checks the scatter plan (gene-major id segments per chunk of sets) against the
@@ -929,7 +929,7 @@ extern "C" int plaidhip_debug_pair_plan_check(int32_t g, int32_t m, const int32_
 // chunk), out[3] = wrong / repeated / out-of-chunk ids, out[4] = LDS atomic wave-instructions over all lists, two per
 // segment (what a stored value of that gene costs), out[5] = ids that share their 8-byte bank (id mod 16) with an earlier id of the same
 // 16-lane group of an instruction (each costs one more 2-cycle pass of that group).
-extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int64_t out[8]) {
+extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int64_t out[8]) try {
   PH_REQUIRE(gs && out, "scatter_plan_check: null argument");
   const plaidhip_scatter_plan& sp = gs->scatter;
   const int32_t g = gs->g, m = gs->m;
@@ -969,5 +969,5 @@ extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int
   out[4] = instr;
   out[5] = coll;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 #endif

@@ -137,7 +137,7 @@ void join_names(const std::vector<std::string>& v, std::string& out) {
 
 extern "C" {
 
-int plaidhip_gmt_read(const char* path, int add_source, int64_t nrows, plaidhip_gmt** out) {
+int plaidhip_gmt_read(const char* path, int add_source, int64_t nrows, plaidhip_gmt** out) try {
   PH_REQUIRE(path && out, "gmt_read: null path/out");
   *out = nullptr;
   FILE* fh = fopen(path, "rb");
@@ -154,9 +154,9 @@ int plaidhip_gmt_read(const char* path, int add_source, int64_t nrows, plaidhip_
   parse_text(*g, add_source, nrows, false);
   *out = g;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_gmt_parse(const char* text, int64_t nbytes, int raw, int add_source, int64_t nrows, plaidhip_gmt** out) {
+int plaidhip_gmt_parse(const char* text, int64_t nbytes, int raw, int add_source, int64_t nrows, plaidhip_gmt** out) try {
   PH_REQUIRE(out && (text || nbytes == 0) && nbytes >= 0, "gmt_parse: bad arguments");
   plaidhip_gmt* g = new plaidhip_gmt();
   if (nbytes) g->buf.assign(text, (size_t)nbytes);
@@ -164,7 +164,7 @@ int plaidhip_gmt_parse(const char* text, int64_t nbytes, int raw, int add_source
   parse_text(*g, add_source, nrows, raw != 0);
   *out = g;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int64_t plaidhip_gmt_nsets(const plaidhip_gmt* g) { return g ? (int64_t)g->names.size() : 0; }
 
@@ -199,13 +199,13 @@ const char* plaidhip_gmt_text(plaidhip_gmt* g, int64_t* nbytes) {
   return o.c_str();
 }
 
-int plaidhip_gmt_destroy(plaidhip_gmt* g) {
+int plaidhip_gmt_destroy(plaidhip_gmt* g) try {
   delete g;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_gmt2mat(const plaidhip_gmt* gmt, int64_t max_genes, int64_t ntop, const char* const* bg, int64_t nbg,
-                     plaidhip_gmtmat** out) {
+                     plaidhip_gmtmat** out) try {
   PH_REQUIRE(gmt && out, "gmt2mat: null gmt/out");
   PH_REQUIRE(nbg <= 0 || bg, "gmt2mat: null bg");
   *out = nullptr;
@@ -303,15 +303,15 @@ int plaidhip_gmt2mat(const plaidhip_gmt* gmt, int64_t max_genes, int64_t ntop, c
   }
   *out = M;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_gmtmat_dims(const plaidhip_gmtmat* M, int64_t dims[3]) {
+int plaidhip_gmtmat_dims(const plaidhip_gmtmat* M, int64_t dims[3]) try {
   PH_REQUIRE(M && dims, "gmtmat_dims: null argument");
   dims[0] = M->g;
   dims[1] = M->m;
   dims[2] = M->z;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 const int32_t* plaidhip_gmtmat_p(const plaidhip_gmtmat* M) { return M ? M->p.data() : nullptr; }
 const int32_t* plaidhip_gmtmat_i(const plaidhip_gmtmat* M) { return M ? M->i.data() : nullptr; }
@@ -324,9 +324,9 @@ const char* plaidhip_gmtmat_names(plaidhip_gmtmat* M, int axis, int64_t* nbytes)
   return M->joined[axis].c_str();
 }
 
-int plaidhip_gmtmat_destroy(plaidhip_gmtmat* M) {
+int plaidhip_gmtmat_destroy(plaidhip_gmtmat* M) try {
   delete M;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 }  // extern "C"

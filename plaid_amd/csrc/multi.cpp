@@ -33,14 +33,14 @@ using namespace plaidhip;
     if (rc_ != PLAIDHIP_OK) return rc_;   \
   } while (0)
 
-extern "C" int plaidhip_shard_bounds(int64_t n, int ndev, int k, int64_t* lo, int64_t* hi) {
+extern "C" int plaidhip_shard_bounds(int64_t n, int ndev, int k, int64_t* lo, int64_t* hi) try {
   PH_REQUIRE(n >= 0 && ndev > 0 && k >= 0 && k < ndev && lo && hi, "shard_bounds: bad arguments n=%lld ndev=%d k=%d",
              (long long)n, ndev, k);
   const int64_t per = (n + ndev - 1) / ndev;
   *lo = std::min(n, (int64_t)k * per);
   *hi = std::min(n, *lo + per);
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 namespace plaidhip {
 
@@ -75,8 +75,14 @@ void HomeBuffer::prepare(void* dst, size_t bytes) {
   unsigned hw = std::thread::hardware_concurrency();
   const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)kHomeThreads, nchunk, hw > 1 ? hw / 2 : 1}));
   State* st = st_;
+  auto spawn = [&](auto&& body) {   // (a thread the system refuses is one helper less, not an exception through a C ABI)
+    try {
+      st_->th.emplace_back(body);
+    } catch (...) {
+    }
+  };
   for (int t = 0; t < nt; ++t)
-    st_->th.emplace_back([st] {
+    spawn([st] {
       for (;;) {
         const size_t k = st->next.fetch_add(1);
         if (k >= st->nchunk) return;
@@ -87,6 +93,7 @@ void HomeBuffer::prepare(void* dst, size_t bytes) {
         st->done[k].store(1, std::memory_order_release);
       }
     });
+  if (st_->th.empty()) st_->nchunk = 0;   // no helper at all: one plain copy (copy() below)
 }
 
 int HomeBuffer::copy(plaidhip_ctx* ctx, const void* src_dev) {
@@ -605,7 +612,7 @@ extern "C" {
 // error, not hang).
 int plaidhip_debug_sharded_on_one_device(int device, int nshards, int fail_shard, int method, const int32_t* Xp,
                                          const int32_t* Xi, const double* X_or_x, int32_t g, int32_t n, const int32_t* Gp,
-                                         const int32_t* Gi, int32_t m, int stat, int normalize, double alpha, double* S_out) {
+                                         const int32_t* Gi, int32_t m, int stat, int normalize, double alpha, double* S_out) try {
   PH_REQUIRE(nshards >= 1 && nshards <= 64, "debug_sharded: nshards = %d", nshards);
   std::vector<plaidhip_ctx*> ctxs((size_t)nshards, nullptr);
   int rc = PLAIDHIP_OK;
@@ -620,50 +627,50 @@ int plaidhip_debug_sharded_on_one_device(int device, int nshards, int fail_shard
     if (c) plaidhip_finalize(c);
   if (rc != PLAIDHIP_OK) set_error("%s", err.c_str());
   return rc;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_multi_set_precision(int mode) {
+int plaidhip_multi_set_precision(int mode) try {
   PH_REQUIRE(mode == PLAIDHIP_PRECISION_F64 || mode == PLAIDHIP_PRECISION_MIXED, "multi_set_precision: bad mode %d", mode);
   std::lock_guard<std::mutex> lk(g_multi_mu);
   g_multi_precision = mode;
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
-int plaidhip_multi_finalize(void) {
+int plaidhip_multi_finalize(void) try {
   std::lock_guard<std::mutex> lk(g_multi_mu);
   for (plaidhip_ctx*& c : g_multi_ctx)
     if (c) { plaidhip_finalize(c); c = nullptr; }
   return PLAIDHIP_OK;
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_plaid_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x, int32_t g,
-                         int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double* S_out) {
+                         int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, int stat, int normalize, double* S_out) try {
   std::vector<plaidhip_ctx*> ctxs;
   PH_TRY(multi_contexts(devices, ndev, ctxs));
   PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "plaid_multi: bad stat %d", stat);
   return run_sharded(ctxs.data(), ndev, 0, Xp, Xi, X_or_x, g, n, Gp, Gi, m, stat, normalize, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_sing_multi(const int* devices, int ndev, const double* X, int32_t g, int32_t n, const int32_t* Gp,
-                        const int32_t* Gi, int32_t m, double* S_out) {
+                        const int32_t* Gi, int32_t m, double* S_out) try {
   std::vector<plaidhip_ctx*> ctxs;
   PH_TRY(multi_contexts(devices, ndev, ctxs));
   return run_sharded(ctxs.data(), ndev, 1, nullptr, nullptr, X, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_sing_csc_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t g,
-                            int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) {
+                            int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double* S_out) try {
   PH_REQUIRE(Xp != nullptr, "sing_csc_multi: null Xp");
   std::vector<plaidhip_ctx*> ctxs;
   PH_TRY(multi_contexts(devices, ndev, ctxs));
   return run_sharded(ctxs.data(), ndev, 1, Xp, Xi, Xx, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 0, 0.0, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_ssgsea_multi(const int* devices, int ndev, const int32_t* Xp, const int32_t* Xi, const double* X_or_x, int32_t g,
-                          int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha, double* S_out) {
+                          int32_t n, const int32_t* Gp, const int32_t* Gi, int32_t m, double alpha, double* S_out) try {
   std::vector<plaidhip_ctx*> ctxs;
   PH_TRY(multi_contexts(devices, ndev, ctxs));
   return run_sharded(ctxs.data(), ndev, 2, Xp, Xi, X_or_x, g, n, Gp, Gi, m, PLAIDHIP_STAT_MEAN, 1, alpha, S_out);
-}
+} catch (...) { return plaidhip::on_exception(); }
 
 }  // extern "C"

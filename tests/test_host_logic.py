@@ -463,3 +463,25 @@ def test_planners_take_the_reference_shaped_collection(tmp_path):
             assert z / d["slots_pair"] > (0.60 if real else 0.78), d
         assert d["pair_conflicts"] < 0.01 * z                            # deliberate two-way conflicts of over-full slots only
         assert d["scatter_collisions"] < 0.08 * z                        # ids sharing an LDS bank inside a 16-lane group
+
+
+def test_a_cpp_exception_becomes_an_error_code():
+    """every `int plaidhip_*` entry point is a function-try-block (common.h: on_exception): a C++ exception inside the
+    library -- here std::length_error from a string of 2^62 bytes, thrown before anything is read -- comes back as a code
+    and a message instead of unwinding into the caller's C stack (an R session would be gone)"""
+    import ctypes as C
+    from plaid_amd import _lib
+    lib = _lib.load()
+    out = C.c_void_p()
+    rc = lib.plaidhip_gmt_parse(C.c_char_p(b"a\tb\tc\n"), C.c_int64(1 << 62), 0, 0, C.c_int64(-1), C.byref(out))
+    assert rc != 0 and not out.value
+    msg = lib.plaidhip_last_error_string().decode()
+    assert "exception" in msg or "memory" in msg, msg
+    # and the sources: no int entry point without the handler
+    import re
+    csrc = os.path.join(ROOT, "plaid_amd", "csrc")
+    for name in ("api.cpp", "multi.cpp", "geneset.cpp", "gmt.cpp"):
+        text = open(os.path.join(csrc, name)).read()
+        for m_ in re.finditer(r'^(?:extern "C" )?int (plaidhip_\w+)\([^;{]*\)\s*(try\s*)?\{', text, flags=re.M):
+            body_one_line = text[m_.end():text.index("\n", m_.end())].strip().endswith("}")
+            assert m_.group(2) or body_one_line, f"{name}: {m_.group(1)} has no function-try-block"
