@@ -270,12 +270,18 @@ void build_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi, cons
     nt = std::max(1u, std::min(nt, 16u));
     if (tiles < 8) nt = 1;
     std::vector<std::thread> pool;
+    std::atomic<int> pool_failed{0};
     for (unsigned w = 0; w < nt; ++w)
       pool.emplace_back([&, w]() {
-        for (int32_t t = (int32_t)w; t < tiles; t += (int32_t)nt)
-          plan_tile(g, Gp, Gi, &hp.lane_set[(size_t)t * 64], plans[t]);
+        try {
+          for (int32_t t = (int32_t)w; t < tiles; t += (int32_t)nt)
+            plan_tile(g, Gp, Gi, &hp.lane_set[(size_t)t * 64], plans[t]);
+        } catch (...) {   // (out of memory inside a helper thread: reported by the caller's thread, below)
+          pool_failed.store(1);
+        }
       });
     for (auto& th : pool) th.join();
+    if (pool_failed.load()) throw std::bad_alloc();
   }
 
   // longest-processing-time assignment of tiles to wavefronts
@@ -435,15 +441,21 @@ void build_pair_plan(int32_t g, int32_t m, const int32_t* Gp, const int32_t* Gi,
     nt = std::max(1u, std::min(nt, 16u));
     if ((int64_t)tiles * S < 8) nt = 1;
     std::vector<std::thread> pool;
+    std::atomic<int> pool_failed{0};
     for (unsigned w = 0; w < nt; ++w)
       pool.emplace_back([&, w]() {
-        for (int64_t u = (int64_t)w; u < (int64_t)tiles * S; u += nt) {
-          const int si = (int)(u / tiles);
-          const int32_t t = (int32_t)(u % tiles);
-          plan_tile_b128(starts[si], std::min(width, g - starts[si]), Gp, Gi, &lane_set[(size_t)t * 64], plans[si][t]);
+        try {
+          for (int64_t u = (int64_t)w; u < (int64_t)tiles * S; u += nt) {
+            const int si = (int)(u / tiles);
+            const int32_t t = (int32_t)(u % tiles);
+            plan_tile_b128(starts[si], std::min(width, g - starts[si]), Gp, Gi, &lane_set[(size_t)t * 64], plans[si][t]);
+          }
+        } catch (...) {
+          pool_failed.store(1);
         }
       });
     for (auto& th : pool) th.join();
+    if (pool_failed.load()) throw std::bad_alloc();
   }
   // longest-processing-time on the steps summed over slices
   std::vector<int64_t> tot(tiles, 0);
@@ -555,6 +567,10 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
 
   auto* gs = new (std::nothrow) plaidhip_geneset();
   if (!gs) { set_error("out of host memory"); return PLAIDHIP_ENOMEM; }
+  struct Guard {   // (an exception on the way -- std::bad_alloc from a plan -- must not leak what exists so far)
+    plaidhip_geneset* p;
+    ~Guard() { if (p) plaidhip_geneset_destroy(p); }
+  } guard{gs};
   gs->ctx = ctx;
   gs->g = g;
   gs->m = m;
@@ -765,17 +781,23 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
         order_cells(0, ncell);
       } else {
         std::atomic<size_t> next{0};
+        std::atomic<int> pool_failed{0};
         const size_t blk = 2048;
         std::vector<std::thread> pool;
         for (unsigned w = 0; w < nt; ++w)
           pool.emplace_back([&]() {
-            for (;;) {
-              const size_t lo = next.fetch_add(blk);
-              if (lo >= ncell) return;
-              order_cells(lo, std::min(ncell, lo + blk));
+            try {
+              for (;;) {
+                const size_t lo = next.fetch_add(blk);
+                if (lo >= ncell) return;
+                order_cells(lo, std::min(ncell, lo + blk));
+              }
+            } catch (...) {
+              pool_failed.store(1);
             }
           });
         for (auto& th : pool) th.join();
+        if (pool_failed.load()) throw std::bad_alloc();
       }
     }
     TSW("scatter lists ordered");
@@ -823,11 +845,11 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = PLAIDHIP_EHIP; goto fail; }
   }
   TSW("done");
+  guard.p = nullptr;
   *out = gs;
   return PLAIDHIP_OK;
 fail:
-  plaidhip_geneset_destroy(gs);
-  return rc;
+  return rc;   // (the guard destroys gs)
 } catch (...) { return plaidhip::on_exception(); }
 
 extern "C" int plaidhip_geneset_destroy(plaidhip_geneset* gs) try {

@@ -325,7 +325,11 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
   auto live = [&] { return rc == PLAIDHIP_OK && sh.abort.load() == 0; };
   auto step = [&](const std::function<int()>& fn) {
     if (!live()) return;
-    rc = fn();
+    try {
+      rc = fn();
+    } catch (...) {   // (a worker thread has no function-try-block above it; the rendezvous points must still be reached)
+      rc = on_exception();
+    }
     if (rc != PLAIDHIP_OK) sh.abort.store(1);
   };
   int64_t lo64 = 0, hi64 = 0;
