@@ -215,13 +215,26 @@ int upload_pipelined(plaidhip_ctx* ctx, char* dst, size_t ldd_bytes, const char*
       if (freeb[b] != nullptr) { hipEventSynchronize(freeb[b]); hipEventDestroy(freeb[b]); }
   };
   std::vector<std::thread> th;
-  for (int t = 0; t < T && t < npan; ++t) th.emplace_back(feeder, t);
+  th.reserve((size_t)T);
+  for (int t = 0; t < T && t < npan; ++t) {
+    try {
+      th.emplace_back(feeder, t);
+    } catch (...) {   // (a thread the system refuses: its panels are staged by this thread, before the loop below waits)
+      feeder(t);
+    }
+  }
   int rc = PLAIDHIP_OK;
-  for (int64_t p = 0; p < npan; ++p) {
-    while (ready[(size_t)p].load(std::memory_order_acquire) == 0) std::this_thread::yield();
-    if (failed.load() != 0 || rc != PLAIDHIP_OK) continue;
-    if (hipStreamWaitEvent(ctx->stream, done[(size_t)p], 0) != hipSuccess) { failed.store(1); continue; }
-    if (on_panel) rc = on_panel(pb[(size_t)p], pb[(size_t)p + 1]);
+  try {
+    for (int64_t p = 0; p < npan; ++p) {
+      while (ready[(size_t)p].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+      if (failed.load() != 0 || rc != PLAIDHIP_OK) continue;
+      if (hipStreamWaitEvent(ctx->stream, done[(size_t)p], 0) != hipSuccess) { failed.store(1); continue; }
+      if (on_panel) rc = on_panel(pb[(size_t)p], pb[(size_t)p + 1]);
+    }
+  } catch (...) {   // (the feeders hold references into this frame: they are joined before anything unwinds)
+    failed.store(1);
+    for (auto& t : th) t.join();
+    throw;
   }
   for (auto& t : th) t.join();
   if (failed.load() != 0 && rc == PLAIDHIP_OK) {
