@@ -441,6 +441,113 @@ def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "de
     return full
 
 
+class _StitchedFiles:
+    """One shared host matrix made of ONE /dev/shm FILE PER RANK.  A single file is a single inode, and every first touch of
+    a page of it takes that inode's lock: however many ranks and threads write, a fresh shm file fills at 3.5-6 GB/s in
+    total, and slower the more writers there are (tools/ubench/shm_fill.cpp: 0.5 GB/s with 4 x 32 threads); files of their
+    own fill at 13-20 GB/s with four processes.  File k holds the bytes [cut[k], cut[k + 1]) of the matrix, the cuts being
+    the ranks' first bytes rounded DOWN to a page: a rank's block lies in its own file except for its last partial page,
+    which is the head of the next file.  The root maps the files back to back (MAP_FIXED into one reserved address range),
+    which is one contiguous matrix again."""
+    PAGE = 4096
+
+    def __init__(self, base_path, n_total, m, itemsize, world):
+        self.base_path, self.world = base_path, world
+        self.row_bytes = m * itemsize
+        self.total = n_total * self.row_bytes
+        firsts = [shard_bounds(n_total, world, r)[0] * self.row_bytes for r in range(world)]
+        self.cut = [0] + [(b // self.PAGE) * self.PAGE for b in firsts[1:]] + [-(-self.total // self.PAGE) * self.PAGE]
+        self.maps = {}
+
+    def path(self, k):
+        return f"{self.base_path}.{k}"
+
+    def size(self, k):
+        return self.cut[k + 1] - self.cut[k]
+
+    def create(self, k):
+        """(rank k) its file, sized and with its pages allocated by the kernel in one go (posix_fallocate: 20 instead of
+        13 GB/s for the fill that follows)"""
+        import os
+        if self.size(k) <= 0:
+            return
+        fd = os.open(self.path(k), os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+        try:
+            os.ftruncate(fd, self.size(k))
+            try:
+                os.posix_fallocate(fd, 0, self.size(k))
+            except OSError:
+                pass
+        finally:
+            os.close(fd)
+
+    def _map(self, k):
+        if k not in self.maps:
+            self.maps[k] = np.memmap(self.path(k), mode="r+", dtype=np.uint8, shape=(self.size(k),))
+        return self.maps[k]
+
+    def write(self, byte_off, src_u8):
+        """src_u8 (a flat uint8 view) -> bytes [byte_off, byte_off + len) of the matrix, across file boundaries"""
+        pos, end = byte_off, byte_off + src_u8.shape[0]
+        k = max(0, min(self.world - 1, np.searchsorted(self.cut, pos, side="right") - 1))
+        while pos < end:
+            while self.size(k) <= 0 or self.cut[k + 1] <= pos:
+                k += 1
+            stop = min(end, self.cut[k + 1])
+            self._map(k)[pos - self.cut[k]:stop - self.cut[k]] = src_u8[pos - byte_off:stop - byte_off]
+            pos = stop
+
+    def close_maps(self):
+        self.maps.clear()
+
+    def stitch(self, np_dtype, shape):
+        """(root) every file mapped at its place in one reserved address range -> one ndarray; the files are unlinked (the
+        mappings outlive the names), the range is unmapped when the array is collected"""
+        import ctypes
+        import mmap as _mmap
+        import os
+        import weakref
+        libc = ctypes.CDLL(None, use_errno=True)
+        libc.mmap.restype = ctypes.c_void_p
+        libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        libc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        span = max(self.cut[-1], self.PAGE)
+        MAP_FAILED = ctypes.c_void_p(-1).value
+        base = libc.mmap(None, span, 0, _mmap.MAP_PRIVATE | _mmap.MAP_ANONYMOUS, -1, 0)
+        if base in (None, MAP_FAILED):
+            raise OSError(ctypes.get_errno(), "mmap (address range of the gathered matrix)")
+        MAP_FIXED = 0x10
+        try:
+            for k in range(self.world):
+                if self.size(k) <= 0:
+                    continue
+                fd = os.open(self.path(k), os.O_RDWR)
+                try:
+                    got = libc.mmap(base + self.cut[k], self.size(k), _mmap.PROT_READ | _mmap.PROT_WRITE,
+                                    _mmap.MAP_SHARED | MAP_FIXED, fd, 0)
+                finally:
+                    os.close(fd)
+                if got in (None, MAP_FAILED):
+                    raise OSError(ctypes.get_errno(), f"mmap of {self.path(k)}")
+        except BaseException:
+            libc.munmap(base, span)
+            raise
+        finally:
+            self.unlink()
+        buf = (ctypes.c_char * max(self.total, 1)).from_address(base)
+        arr = np.frombuffer(buf, dtype=np_dtype, count=shape[0] * shape[1]).reshape(shape)
+        weakref.finalize(buf, libc.munmap, base, span)   # (arr -> buf: the range lives as long as any view of it)
+        return arr
+
+    def unlink(self):
+        import os
+        for k in range(self.world):
+            try:
+                os.unlink(self.path(k))
+            except OSError:
+                pass
+
+
 def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, shm_dir, need):
     import os
     import time
@@ -449,73 +556,73 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
     world, rank = _world(group)
     m = int(S_local.shape[1])
     np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[out_dtype]
-    # the root creates the shared file (or refuses), everyone maps it
+    itemsize = np.dtype(np_dtype).itemsize
+    # the root names the files (or refuses), every rank creates its own
     msg = [None]
     if rank == dst:
         have = max_bytes if max_bytes is not None else _free_shm_bytes(shm_dir)
         if need > have:
             msg[0] = ("refused", need, have)
         else:
-            path = os.path.join(shm_dir, f"plaidhip_gather_{os.getpid()}_{time.time_ns()}")
-            mm = np.memmap(path, mode="w+", dtype=np_dtype, shape=(int(n_total), m))
-            msg[0] = ("ok", path)
+            msg[0] = ("ok", os.path.join(shm_dir, f"plaidhip_gather_{os.getpid()}_{time.time_ns()}"))
     if world > 1:
         dist.broadcast_object_list(msg, src=dst, group=group)
     if msg[0][0] == "refused":
         raise GatherRefused(f"gather_scores(to='host'): the {n_total} x {m} matrix needs {msg[0][1] / 1e9:.1f} GB of shared host "
                             f"memory under {shm_dir}, {msg[0][2] / 1e9:.1f} GB are free", msg[0][1], msg[0][2])
-    path = msg[0][1]
-    if rank != dst:
-        mm = np.memmap(path, mode="r+", dtype=np_dtype, shape=(int(n_total), m))
+    files = _StitchedFiles(msg[0][1], int(n_total), m, itemsize, world)
+    files.create(rank)
+    if world > 1:
+        dist.barrier(group=group)                  # (a block's last partial page lives in the NEXT rank's file)
     lo, hi = shard_bounds(n_total, world, rank)
     nloc = hi - lo
-    if nloc > 0:
-        if S_local.is_cuda:
-            # two pinned slabs: the copy of slab k+1 runs on the bus while slab k is moved into the shared matrix
-            side = torch.cuda.Stream(device=S_local.device)
-            side.wait_stream(torch.cuda.current_stream(S_local.device))
-            pin = [torch.empty((min(rows, nloc), m), dtype=out_dtype).pin_memory() for _ in range(2)]
-            evs = [None, None]
-            slabs = [(r0, min(nloc, r0 + rows)) for r0 in range(0, nloc, rows)]
+    try:
+        if nloc > 0:
+            if S_local.is_cuda:
+                # two pinned slabs: the copy of slab k+1 runs on the bus while slab k is moved into the shared matrix
+                side = torch.cuda.Stream(device=S_local.device)
+                side.wait_stream(torch.cuda.current_stream(S_local.device))
+                pin = [torch.empty((min(rows, nloc), m), dtype=out_dtype).pin_memory() for _ in range(2)]
+                evs = [None, None]
+                slabs = [(r0, min(nloc, r0 + rows)) for r0 in range(0, nloc, rows)]
 
-            def issue(k):
-                r0, r1 = slabs[k]
-                with torch.cuda.stream(side):
-                    pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
-                    evs[k & 1] = torch.cuda.Event()
-                    evs[k & 1].record(side)
-            # the move into the shared matrix takes first-touch page faults (fresh shm pages) and is a plain memcpy: several
-            # threads per rank (numpy releases the GIL while it copies) -- the host's cores divided among the ranks,
-            # between 4 and 16 (measured on a 256-thread host, 8 GB, one rank: 4 threads 5.3 GB/s)
-            from concurrent.futures import ThreadPoolExecutor
-            try:
-                ncpu = len(os.sched_getaffinity(0))
-            except AttributeError:
-                ncpu = os.cpu_count() or 4
-            nthr = int(os.environ.get("PLAIDHIP_GATHER_THREADS", max(4, min(16, ncpu // max(1, world)))))
-            pool = ThreadPoolExecutor(nthr)
+                def issue(k):
+                    r0, r1 = slabs[k]
+                    with torch.cuda.stream(side):
+                        pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
+                        evs[k & 1] = torch.cuda.Event()
+                        evs[k & 1].record(side)
+                # the move into the shared matrix is a plain memcpy into fresh shm pages (numpy releases the GIL while it
+                # copies): FOUR threads per rank -- more threads fill a shm file more slowly, not faster (shm_fill.cpp)
+                from concurrent.futures import ThreadPoolExecutor
+                nthr = int(os.environ.get("PLAIDHIP_GATHER_THREADS", 4))
+                pool = ThreadPoolExecutor(nthr)
 
-            def move(dst_rows, src_arr):
-                k4 = max(1, (src_arr.shape[0] + nthr - 1) // nthr)
-                futs = [pool.submit(lambda a=a: mm.__setitem__(slice(dst_rows + a, dst_rows + min(src_arr.shape[0], a + k4)),
-                                                               src_arr[a:a + k4]))
-                        for a in range(0, src_arr.shape[0], k4)]
-                for f_ in futs:
-                    f_.result()
-            issue(0)
-            for k, (r0, r1) in enumerate(slabs):
-                evs[k & 1].synchronize()
-                if k + 1 < len(slabs):
-                    issue(k + 1)                                   # the other pinned slab
-                move(lo + r0, pin[k & 1][:r1 - r0].numpy())
-            pool.shutdown()
-        else:
-            src = S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
-            mm[lo:hi] = src.numpy()
-    if world > 1:
-        dist.barrier(group=group)
+                def move(dst_row, src_arr):
+                    flat = src_arr.reshape(-1).view(np.uint8)
+                    k4 = -(-flat.shape[0] // nthr)
+                    k4 = -(-k4 // 4096) * 4096
+                    off = dst_row * files.row_bytes
+                    futs = [pool.submit(files.write, off + a, flat[a:a + k4]) for a in range(0, flat.shape[0], k4)]
+                    for f_ in futs:
+                        f_.result()
+                issue(0)
+                for k, (r0, r1) in enumerate(slabs):
+                    evs[k & 1].synchronize()
+                    if k + 1 < len(slabs):
+                        issue(k + 1)                                   # the other pinned slab
+                    move(lo + r0, pin[k & 1][:r1 - r0].numpy())
+                pool.shutdown()
+            else:
+                src = S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+                files.write(lo * files.row_bytes, np.ascontiguousarray(src.numpy()).reshape(-1).view(np.uint8))
+        files.close_maps()
+    except BaseException:
+        files.unlink()                              # (no names are left behind in /dev/shm when a rank fails)
+        raise
+    finally:
+        if world > 1:
+            dist.barrier(group=group)
     if rank == dst:
-        os.unlink(path)            # the mapping outlives the name: the memory goes when the array does
-        return mm
-    del mm
+        return files.stitch(np_dtype, (int(n_total), m))
     return None
