@@ -451,13 +451,28 @@ class _StitchedFiles:
     which is one contiguous matrix again."""
     PAGE = 4096
 
-    def __init__(self, base_path, n_total, m, itemsize, world):
-        self.base_path, self.world = base_path, world
+    def __init__(self, base_path, n_total, m, itemsize, world, parts=1):
+        """`parts` files per rank: a rank's block is cut into that many runs of rows, each a file (and a writer) of its own"""
+        self.base_path, self.ranks, self.parts = base_path, world, parts
+        self.world = world * parts                   # number of files
         self.row_bytes = m * itemsize
         self.total = n_total * self.row_bytes
-        firsts = [shard_bounds(n_total, world, r)[0] * self.row_bytes for r in range(world)]
+        self.first_row = []                          # first row of file k (rank k // parts, part k % parts)
+        for r in range(world):
+            lo, hi = shard_bounds(n_total, world, r)
+            per = -(-(hi - lo) // parts) if hi > lo else 0
+            self.first_row += [min(hi, lo + j * per) for j in range(parts)]
+        firsts = [r0 * self.row_bytes for r0 in self.first_row]
         self.cut = [0] + [(b // self.PAGE) * self.PAGE for b in firsts[1:]] + [-(-self.total // self.PAGE) * self.PAGE]
         self.maps = {}
+
+    def rows_of(self, k, n_total):
+        """the rows [r0, r1) file k's writer is responsible for"""
+        r0 = self.first_row[k]
+        rank = k // self.parts
+        hi = shard_bounds(n_total, self.ranks, rank)[1]
+        r1 = self.first_row[k + 1] if (k + 1) % self.parts != 0 else hi
+        return r0, max(r0, r1)
 
     def path(self, k):
         return f"{self.base_path}.{k}"
@@ -465,26 +480,40 @@ class _StitchedFiles:
     def size(self, k):
         return self.cut[k + 1] - self.cut[k]
 
+    def create_rank(self, rank):
+        for k in range(rank * self.parts, (rank + 1) * self.parts):
+            self.create(k)
+
     def create(self, k):
-        """(rank k) its file, sized and with its pages allocated by the kernel in one go (posix_fallocate: 20 instead of
-        13 GB/s for the fill that follows)"""
+        """file k, sized (its pages come with allocate(): posix_fallocate, 20 instead of 13 GB/s for the fill that follows)"""
         import os
         if self.size(k) <= 0:
             return
         fd = os.open(self.path(k), os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
         try:
             os.ftruncate(fd, self.size(k))
-            try:
-                os.posix_fallocate(fd, 0, self.size(k))
-            except OSError:
-                pass
+        finally:
+            os.close(fd)
+
+    def allocate(self, k):
+        """(file k's writer, before it writes) the file's pages in one go; the writers of a rank do this side by side"""
+        import os
+        if self.size(k) <= 0:
+            return
+        fd = os.open(self.path(k), os.O_RDWR)
+        try:
+            os.posix_fallocate(fd, 0, self.size(k))
+        except OSError:
+            pass
         finally:
             os.close(fd)
 
     def _map(self, k):
-        if k not in self.maps:
-            self.maps[k] = np.memmap(self.path(k), mode="r+", dtype=np.uint8, shape=(self.size(k),))
-        return self.maps[k]
+        mm = self.maps.get(k)
+        if mm is None:                               # (two writers may meet at a file's head page: the later mapping wins, both work)
+            mm = np.memmap(self.path(k), mode="r+", dtype=np.uint8, shape=(self.size(k),))
+            self.maps[k] = mm
+        return mm
 
     def write(self, byte_off, src_u8):
         """src_u8 (a flat uint8 view) -> bytes [byte_off, byte_off + len) of the matrix, across file boundaries"""
@@ -570,51 +599,68 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
     if msg[0][0] == "refused":
         raise GatherRefused(f"gather_scores(to='host'): the {n_total} x {m} matrix needs {msg[0][1] / 1e9:.1f} GB of shared host "
                             f"memory under {shm_dir}, {msg[0][2] / 1e9:.1f} GB are free", msg[0][1], msg[0][2])
-    files = _StitchedFiles(msg[0][1], int(n_total), m, itemsize, world)
-    files.create(rank)
+    # eight files (and writers) per rank when the block is large: a writer moves ~2.4 GB/s into fresh shm pages, and one
+    # file takes ~5.5 GB/s whoever writes it
+    # (about sixteen writers on the node: 4 ranks x 8 writers filled 96 GB at 23 GB/s, 4 x 4 at 34 GB/s -- past that the
+    # kernel's page allocation is what they wait for)
+    parts = int(os.environ.get("PLAIDHIP_GATHER_PARTS",
+                               max(2, min(8, 16 // max(world, 1))) if S_local.is_cuda and need // max(world, 1) >= (1 << 30) else 1))
+    if world > 1:                                   # (every rank must cut alike)
+        pl = [parts]
+        dist.broadcast_object_list(pl, src=dst, group=group)
+        parts = pl[0]
+    files = _StitchedFiles(msg[0][1], int(n_total), m, itemsize, world, parts)
+    files.create_rank(rank)
     if world > 1:
-        dist.barrier(group=group)                  # (a block's last partial page lives in the NEXT rank's file)
+        dist.barrier(group=group)                  # (a block's last partial page lives in the NEXT file)
     lo, hi = shard_bounds(n_total, world, rank)
     nloc = hi - lo
     try:
         if nloc > 0:
             if S_local.is_cuda:
-                # two pinned slabs: the copy of slab k+1 runs on the bus while slab k is moved into the shared matrix
-                side = torch.cuda.Stream(device=S_local.device)
-                side.wait_stream(torch.cuda.current_stream(S_local.device))
-                pin = [torch.empty((min(rows, nloc), m), dtype=out_dtype).pin_memory() for _ in range(2)]
-                evs = [None, None]
-                slabs = [(r0, min(nloc, r0 + rows)) for r0 in range(0, nloc, rows)]
-
-                def issue(k):
-                    r0, r1 = slabs[k]
-                    with torch.cuda.stream(side):
-                        pin[k & 1][:r1 - r0].copy_(S_local[r0:r1], non_blocking=True)
-                        evs[k & 1] = torch.cuda.Event()
-                        evs[k & 1].record(side)
-                # the move into the shared matrix is a plain memcpy into fresh shm pages (numpy releases the GIL while it
-                # copies): FOUR threads per rank -- more threads fill a shm file more slowly, not faster (shm_fill.cpp)
+                # one lane per file of this rank: its own side stream and two pinned slabs -- the copy of slab k+1 runs on
+                # the bus while slab k is moved into the lane's file (numpy releases the GIL while it copies, the event wait
+                # does too); the lanes run side by side
                 from concurrent.futures import ThreadPoolExecutor
-                nthr = int(os.environ.get("PLAIDHIP_GATHER_THREADS", 4))
-                pool = ThreadPoolExecutor(nthr)
+                cur = torch.cuda.current_stream(S_local.device)
+                dev = S_local.device
 
-                def move(dst_row, src_arr):
-                    flat = src_arr.reshape(-1).view(np.uint8)
-                    k4 = -(-flat.shape[0] // nthr)
-                    k4 = -(-k4 // 4096) * 4096
-                    off = dst_row * files.row_bytes
-                    futs = [pool.submit(files.write, off + a, flat[a:a + k4]) for a in range(0, flat.shape[0], k4)]
-                    for f_ in futs:
-                        f_.result()
-                issue(0)
-                for k, (r0, r1) in enumerate(slabs):
-                    evs[k & 1].synchronize()
-                    if k + 1 < len(slabs):
-                        issue(k + 1)                                   # the other pinned slab
-                    move(lo + r0, pin[k & 1][:r1 - r0].numpy())
-                pool.shutdown()
+                def lane(k):
+                    r0f, r1f = files.rows_of(k, int(n_total))
+                    if r1f <= r0f:
+                        return
+                    torch.cuda.set_device(dev)
+                    files.allocate(k)
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(cur)
+                    nr = min(max(1, rows // parts), r1f - r0f)
+                    pin = [torch.empty((nr, m), dtype=out_dtype).pin_memory() for _ in range(2)]
+                    evs = [None, None]
+                    slabs = [(a0, min(r1f, a0 + nr)) for a0 in range(r0f, r1f, nr)]
+
+                    def issue(i):
+                        a0, a1 = slabs[i]
+                        with torch.cuda.stream(side):
+                            pin[i & 1][:a1 - a0].copy_(S_local[a0 - lo:a1 - lo], non_blocking=True)
+                            evs[i & 1] = torch.cuda.Event()
+                            evs[i & 1].record(side)
+                    issue(0)
+                    for i, (a0, a1) in enumerate(slabs):
+                        evs[i & 1].synchronize()
+                        if i + 1 < len(slabs):
+                            issue(i + 1)
+                        files.write(a0 * files.row_bytes, pin[i & 1][:a1 - a0].numpy().reshape(-1).view(np.uint8))
+                mine = list(range(rank * parts, (rank + 1) * parts))
+                if parts == 1:
+                    lane(mine[0])
+                else:
+                    with ThreadPoolExecutor(parts) as pool:
+                        for f_ in [pool.submit(lane, k) for k in mine]:
+                            f_.result()
             else:
                 src = S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+                for k in range(rank * parts, (rank + 1) * parts):
+                    files.allocate(k)
                 files.write(lo * files.row_bytes, np.ascontiguousarray(src.numpy()).reshape(-1).view(np.uint8))
         files.close_maps()
     except BaseException:
