@@ -235,6 +235,35 @@ def _plaid_test_worker(rank, world, port, n, out_path):
         dist.destroy_process_group()
 
 
+def _gather3_worker(rank, world, port, n, m, out_path):
+    os.environ["PLAIDHIP_GATHER_PARTS"] = "3"          # three files per rank: page cuts inside and between the blocks
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        lo, hi = sharded.shard_bounds(n, world, rank)
+        S = torch.from_numpy(np.arange(lo, hi, dtype=np.float64)[:, None] * 1000.0 + np.arange(m, dtype=np.float64)[None, :])
+        full = sharded.gather_scores(S, n, dst=1, to="host", chunk_rows=5)
+        f32 = sharded.gather_scores(S, n, dst=1, to="host", dtype=torch.float32)
+        assert (full is None) == (rank != 1)
+        if rank == 1:
+            np.savez(out_path, full=np.asarray(full), f32=np.asarray(f32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,m", [(1000, 1037), (7, 513), (2, 4099)])
+def test_host_gather_three_ranks_three_files_each(tmp_path, n, m):
+    """gather_scores(to="host") with world size 3, a root that is not rank 0, and three /dev/shm files per rank: rows of
+    8,296 / 4,104 / 32,792 bytes put every cut inside a page and some blocks inside one page; n = 2 leaves a rank empty"""
+    world = 3
+    out = str(tmp_path / "g3.npz")
+    mp.spawn(_gather3_worker, args=(world, _free_port(), n, m, out), nprocs=world, join=True)
+    got = np.load(out)
+    exp = np.arange(n, dtype=np.float64)[:, None] * 1000.0 + np.arange(m, dtype=np.float64)[None, :]
+    assert np.array_equal(got["full"], exp)
+    assert np.array_equal(got["f32"], exp.astype(np.float32))
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("plaidhip_gather_")]
+
+
 @pytest.mark.parametrize("n", [23, 9])
 def test_sharded_plaid_test_equals_the_oracle_gloo(tmp_path, n):
     """plaid.test over two sample shards (R/plaid.R:392-474): group sums and sums of squared deviations all-reduced, the
