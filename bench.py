@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Headline benchmark: sample x geneset scores/sec of the plaid hot path at 20k genes on MI355X.
 
 A "step" is one pass of the hot path over one resident batch of synthetic input.
@@ -17,10 +17,14 @@ A "step" is one pass of the hot path over one resident batch of synthetic input.
   "c5_shard" block (N > 1)      configs[4] per GPU: the c3 pipeline on a 125,000-cell CSC shard per rank with the
                                 three scalar all-reduces of plaid_amd/sharded.py (sharded_ssgsea_csc).
 
-Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel's algorithmic HBM bytes / its HIP-event time (plus
-the LDS-return roof the fp64 gather kernels actually sit on); `cpu_baseline` times the plain-C oracle (the reference is
-R and cannot run here) on a bounded column sample of the same workload: one core (reference-faithful) and all cores
-(OpenMP over columns).  Every block carries its own roofline / cpu_baseline / parity entries.
+Prints ONE COMPACT JSON line (rank 0, < 4 KB: `compact_line`), the last thing on stdout; the full record (every block's
+roofline / cpu_baseline / parity entries) goes to bench_detail.json beside this file (BENCH_DETAIL=path moves it).  `roofline` = the
+dominant kernel's algorithmic HBM bytes / its HIP-event time (`frac`), with the LDS-return roof the fp64 gather kernels
+actually sit on beside it (`lds_frac`); `cpu_baseline` times the plain-C oracle (the reference is R and cannot run here)
+on a bounded column sample of the same workload: one core (reference-faithful) and all cores (OpenMP over columns).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (torch.distributed.run as a CHILD
+process, before anything here touches the GPU) and forwards the child's line and exit status.
 """
 from __future__ import annotations
 
@@ -37,9 +41,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LDS_PEAK_GBPS = 157286.4    # 256 CUs x 256 B/clk x 2.4 GHz (MI355X_MICROARCH.md, LDS: ds_read_b64/b128)
 FP64_PEAK_TFLOPS = 78.6     # vector FP64, FMA counted as 2 flop
+METRIC = "sample x geneset scores/sec at 20k genes (plaid(): crossprod + median normalisation)"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -63,7 +68,198 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=2048, help="C2 columns timed on the CPU oracle (0 = skip all CPU legs)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-mixed", action="store_true", help="skip the secondary mixed-precision (fp32-staged) measurement")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: rendezvous (gloo), the max-over-ranks reduction and the output line only (CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------- the line the driver parses
+LINE_LIMIT = 4096   # bytes: the driver stopped parsing the line when it grew to ~23 KB (BENCH_r04.json: parsed = null)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _parity_ok(p):
+    """one boolean out of a parity report: a report without an explicit verdict exists only because every assertion of
+    the checker held (oracle/fullsize.py raises otherwise; the except arms store ok = False)"""
+    if not isinstance(p, dict):
+        return None
+    if "ok" in p:
+        return bool(p["ok"])
+    return "error" not in p
+
+
+def _block_summary(b):
+    """{"ms", "scores_per_s", "kernel", "frac", "parity_ok"} of one secondary block (everything else: bench_detail.json)"""
+    if not isinstance(b, dict):
+        return None
+    if "error" in b and "ms_per_step" not in b:
+        return {"error": str(b["error"])[:120]}
+    o = {"ms": b.get("ms_per_step"), "scores_per_s": b.get("scores_per_s")}
+    k = (b.get("kernels") or {}).get("crossprod")
+    if isinstance(k, dict):
+        o.update({"kernel": str(k.get("kernel"))[:40], "kernel_ms": k.get("kernel_ms"), "frac": k.get("frac")})
+        if isinstance(k.get("lds_roof"), dict):
+            o["lds_frac"] = k["lds_roof"].get("frac")
+    if "phases_ms" in b:
+        o["phases_ms"] = {kk[:24]: round(v, 3) for kk, v in b["phases_ms"].items()}
+    if isinstance(b.get("cpu_baseline"), dict):
+        o["cpu_1core"] = b["cpu_baseline"].get("value")
+    if "vs_baseline" in b:
+        o["vs_published"] = b["vs_baseline"]
+    if isinstance(b.get("mfma_backend"), dict) and "frac" in b["mfma_backend"]:
+        o["mfma"] = _pick(b["mfma_backend"], ("ms", "achieved", "frac"))
+    o["parity_ok"] = _parity_ok(b.get("parity"))
+    return o
+
+
+def compact_line(full, detail_path="bench_detail.json"):
+    """The ONE stdout line: the contract's keys, `roofline` (HBM `frac` and the LDS roof `lds_frac` side by side),
+    `cpu_baseline`, one small summary object per secondary block.  Never longer than LINE_LIMIT bytes: block summaries are
+    dropped (largest first) before anything of the contract is.  The complete record is `full` (bench_detail.json)."""
+    if full.get("profile_only"):
+        line = {"profile_only": True, "config": full.get("config"), "detail": detail_path}
+        return json.dumps(line, separators=(",", ":"))
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "preheat_steps", "ms_per_step",
+                        "ms_per_step_cold", "value_cold", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(full.get("config", {}), ("workload", "genes", "samples_per_gpu", "sets", "memberships", "parallelism"))
+    r = full.get("roofline") or {}
+    roof = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel_ms",
+                     "traffic_source"))
+    if isinstance(r.get("lds_roof"), dict):      # the roof the exact-fp64 LDS gather sits on (DESIGN 4.1), beside the HBM one
+        roof["lds_frac"] = r["lds_roof"].get("frac")
+        roof["lds_achieved"] = r["lds_roof"].get("achieved")
+        roof["lds_peak"] = r["lds_roof"].get("peak")
+    line["roofline"] = roof
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        cb = _pick(c, ("value", "unit", "cores", "kind"))
+        cb["sample"] = str(c.get("sample", ""))[:200]
+        if isinstance(c.get("all_cores"), dict):
+            cb["all_cores_value"], cb["all_cores"] = c["all_cores"].get("value"), c["all_cores"].get("cores")
+        line["cpu_baseline"] = cb
+    else:
+        line["cpu_baseline"] = None
+    if "phases_ms" in full:
+        line["phases_ms"] = full["phases_ms"]
+    line["parity_ok"] = _parity_ok(full.get("parity"))
+    if isinstance(full.get("host_entry"), dict):
+        line["host_entry_ms"] = full["host_entry"].get("ms")          # PCIe-inclusive, never `value` (DESIGN 7)
+    if isinstance(full.get("gather"), dict):
+        line["gather"] = {k: _pick(v, ("completed", "ms", "GB/s")) for k, v in full["gather"].items() if isinstance(v, dict)}
+    blocks = {}
+    for name in ("c3", "c4", "c5_shard", "c3_real"):
+        if name in full:
+            blocks[name] = _block_summary(full[name])
+    for name, b in (full.get("ref_shape") or {}).items() if isinstance(full.get("ref_shape"), dict) else ():
+        blocks["ref_" + name] = _block_summary(b)
+    line["blocks"] = blocks
+    line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text.encode()) >= LINE_LIMIT and line["blocks"]:
+        worst = max(line["blocks"], key=lambda k: len(json.dumps(line["blocks"][k])))
+        for k in ("phases_ms", "mfma", "kernel"):                      # thin it first, drop it only then
+            if isinstance(line["blocks"][worst], dict) and k in line["blocks"][worst]:
+                del line["blocks"][worst][k]
+                break
+        else:
+            del line["blocks"][worst]
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text.encode()) >= LINE_LIMIT:                               # cannot happen with the keys above; never print it
+        line["config"]["workload"] = line["config"].get("workload", "")[:120]
+        line["cpu_baseline"] = _pick(line["cpu_baseline"] or {}, ("value", "unit", "cores", "kind"))
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text.encode()) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(full, detail_path=None):
+    """full record -> bench_detail.json (stderr too with BENCH_DETAIL_STDERR=1), compact line -> the LAST line of stdout"""
+    detail_path = detail_path or os.environ.get("BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    shown = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    try:
+        with open(detail_path, "w") as fh:
+            json.dump(full, fh, indent=1)
+            fh.write("\n")
+    except OSError as exc:
+        shown = f"(not written: {exc})"
+    if os.environ.get("BENCH_DETAIL_STDERR") == "1":      # opt-in: a box whose files do not come back
+        print("[bench detail] " + json.dumps(full), file=sys.stderr, flush=True)
+    else:
+        print(f"[bench] full record: {shown}", file=sys.stderr, flush=True)
+    try:    # whatever native libraries (RCCL's version banner) still hold in the C stdio buffer goes out first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(compact_line(full, shown), flush=True)
+
+
+# ----------------------------------------------------------------------------------------- N > 1: start the ranks
+def launcher_argv(gpus, argv, port=None):
+    """the command `bench.py --gpus N` starts when nothing launched it as a rank (the driver's own form, SCALE runs)"""
+    port = port or os.environ.get("MASTER_PORT") or str(29500 + (os.getpid() % 400))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(a, argv):
+    """Start N ranks as a CHILD process (never exec: this may run under a profiler that already initialised the GPU) and
+    hand back its exit status; the child's rank 0 prints the line, which is forwarded untouched."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _cpu_threads() // max(1, a.gpus))))
+    cmd = launcher_argv(a.gpus, argv)
+    print("[bench] starting ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode == 0 and lines:
+        try:
+            got = json.loads(lines[-1]).get("n_gpus")
+        except ValueError:
+            got = None
+        if got != a.gpus:
+            print(f"[bench] the ranks reported n_gpus = {got}, --gpus asked for {a.gpus}", file=sys.stderr)
+            return 3
+    return proc.returncode
+
+
+def dry_run(a):
+    """--dry-run: no GPU, no kernels.  Every rank joins the process group (gloo), the max-over-ranks reduction of a made-up
+    elapsed time runs, rank 0 prints a line through the same `emit` -- so the launcher, the rendezvous and the line format can
+    be tested on a CPU-only box.  The line says data = "dry-run" and carries no measurement."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, seen = float(t.item()), dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        elapsed, seen = 1.0, 1
+    if rank == 0:
+        g, n, m = a.genes, a.samples, a.sets
+        emit({"metric": METRIC, "value": 0.0, "unit": "scores/s", "n_gpus": seen, "steps": a.steps, "warmup": a.warmup,
+              "preheat_steps": a.preheat_steps, "ms_per_step": 1e3 * elapsed / max(1, a.steps), "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "dry-run (no GPU work, no measurement)",
+              "config": {"workload": f"DRY RUN of C2 dense plaid(): {g} x {n}/GPU x {m}", "genes": g, "samples_per_gpu": n,
+                         "sets": m, "parallelism": f"sample-shard x{seen}"},
+              "roofline": None, "cpu_baseline": None})
+    return 0
 
 
 def _traffic(kernel, shape, columns=None):
@@ -1085,6 +1281,11 @@ def run_ref_shape(a, env, name):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing launched this process as a rank: start the N ranks ourselves, BEFORE anything here touches the GPU
+        return launch_ranks(a, sys.argv[1:])
+    if a.dry_run:
+        return dry_run(a)
     import torch
     import torch.distributed as dist
 
@@ -1096,8 +1297,8 @@ def main():
     if os.environ.get("BENCH_DUMP_AFTER"):   # debugging aid: every thread's Python stack after so many seconds, then exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_AFTER"]), exit=True)
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     # BENCH_DIST_BACKEND=gloo is a TEST mode for a 1-GPU box: the ranks share device (local_rank mod device count) and the
@@ -1117,6 +1318,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    seen_world = dist.get_world_size() if use_dist else 1      # what the process group reports, not what was asked for
+    if seen_world != a.gpus and os.environ.get("BENCH_FORCE_DIST") != "1":
+        raise SystemExit(f"bench.py: the process group has {seen_world} ranks, --gpus asked for {a.gpus}")
     stream = torch.cuda.Stream(device=dev)
     ctx = plaid_amd.Context(dev_index, stream.cuda_stream)
     env = {"torch": torch, "dist": dist, "ctx": ctx, "dev": dev, "stream": stream, "world": world, "rank": rank,
@@ -1150,8 +1354,8 @@ def main():
         out.update(blocks)
     elif rank == 0:
         out = {
-            "metric": "sample x geneset scores/sec at 20k genes (plaid(): crossprod + median normalisation)",
-            "value": round(c2["value"], 1), "unit": "scores/s", "n_gpus": world, "steps": a.steps,
+            "metric": METRIC,
+            "value": round(c2["value"], 1), "unit": "scores/s", "n_gpus": seen_world, "steps": a.steps,
             "warmup": a.warmup, "preheat_steps": a.preheat_steps, "ms_per_step": round(c2["ms_per_step"], 4),
             "ms_per_step_cold": round(c2["ms_per_step_cold"], 4),
             "value_cold": round(c2["config"]["samples_per_gpu"] * c2["config"]["sets"] * world / (c2["ms_per_step_cold"] * 1e-3), 1),
@@ -1175,16 +1379,9 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        # the ONE JSON line is the last thing on stdout: whatever native libraries (RCCL's version banner) still hold in
-        # the C stdio buffer goes out first
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
