@@ -183,7 +183,10 @@ int plaidhip_dev_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
 /* The sparse crossprod for RANK WEIGHTS: Rx is what plaidhip_dev_colranks_csc_f64 wrote (rank^power of the stored values,
  * so 0 <= Rx <= *rmax, rmax = their maximum on the device -- the max(rX) replaid.ssgsea divides by, R/plaid.R:251: alpha is
  * divided by it as by alpha_div).  The fixed-point grid of the scatter kernel then follows *rmax -- the maximum over the
- * WHOLE matrix, so every shard of a sharded call rounds alike and the scores do not depend on the sharding -- with the same
+ * WHOLE matrix -- so while the first bound applies ((largest set size) x *rmax: collections whose largest set has at most
+ * 1,024 genes) every shard of a sharded call rounds alike and the scores do not depend on the sharding.  Collections with a
+ * larger set fall back to the bound from the largest column sum OF THE SHARD (and the fixed-point / fp64 choice looks at the
+ * shard's own smallest value): there the scores of different shardings agree to 2^-40 relative, not bit for bit.  Same
  * device-side guard as plaidhip_dev_spmm_csc_f64: a stored value outside [0, *rmax], a NaN (the rank weight of a NaN
  * input) or too wide a dynamic range takes the fp64 accumulators, which propagate it as the reference does.  rmax is
  * required.                                                                                                          */
@@ -267,10 +270,19 @@ int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
                                     double beta, void* S, int64_t lds, void* flags, const void* rmax);
 int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
                                     const void* flags, void* med);
+/* plaidhip_dev_col_medians_resume recognises "that S" by (pointer, lds, m, n) only: right for a caller that resumes directly
+ * after the fused crossprod.  A caller that may free and re-allocate S in between (an allocator that reuses addresses)
+ * takes the TOKEN of the fused launch (plaidhip_dev_fused_medians_info, info[3], right after the crossprod; 0 = the plain
+ * route ran, nothing is pending) and resumes with it: the candidates are used only if they are still the pending ones of
+ * exactly that launch; any other token (0, stale) runs plaidhip_dev_col_medians -- always correct -- and drops what was
+ * pending.  plaidhip_dev_fused_medians_discard drops it explicitly (a caller that will not normalise after all).       */
+int plaidhip_dev_col_medians_resume_token(plaidhip_ctx* ctx, int64_t token, const void* S, int64_t lds, int32_t m, int32_t n,
+                                          int ignore_zero, const void* flags, void* med);
+int plaidhip_dev_fused_medians_discard(plaidhip_ctx* ctx);
 /* what the last fused crossprod of this context left behind (tests, tools): info[0] = its number of columns (0: it ran the
  * plain route), info[1] = device pointer to int32 status[n] (after ..._resume: 1 = median selected from the candidates,
  * 0 = the standalone kernel computed it), info[2] = device pointer to the calibration {offset, half width, ignore-zero},
- * info[3] = 1 while a resume is pending.                                                                              */
+ * info[3] = the launch's token (> 0) while a resume is pending, else 0.                                               */
 int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]);
 int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[2]: sum, #non-NaN */);
 int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,

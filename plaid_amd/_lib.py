@@ -68,6 +68,8 @@ SIGNATURES = {
     "plaidhip_dev_col_medians": [_vp, _vp, _i64, _i32, _i32, _int, _vp, _vp],
     "plaidhip_dev_spmm_csc_fused_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp, _vp],
     "plaidhip_dev_col_medians_resume": [_vp, _vp, _i64, _i32, _i32, _int, _vp, _vp],
+    "plaidhip_dev_col_medians_resume_token": [_vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],
+    "plaidhip_dev_fused_medians_discard": [_vp],
     "plaidhip_dev_fused_medians_info": [_vp, C.POINTER(_i64)],
     "plaidhip_dev_sum": [_vp, _vp, _i64, _vp],
     "plaidhip_dev_shift_columns": [_vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp],

@@ -561,13 +561,32 @@ int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t ld
                                    static_cast<const uint32_t*>(flags), static_cast<double*>(med));
 } catch (...) { return plaidhip::on_exception(); }
 
+int plaidhip_dev_col_medians_resume_token(plaidhip_ctx* ctx, int64_t token, const void* S, int64_t lds, int32_t m, int32_t n,
+                                          int ignore_zero, const void* flags, void* med) try {
+  PH_CTX(ctx);
+  PH_REQUIRE(token >= 0, "col_medians_resume_token: token=%lld (0 = none, > 0 = what fused_medians_info returned)", (long long)token);
+  PH_REQUIRE(m >= 0 && n >= 0 && lds >= m, "col_medians_resume_token: bad dims m=%d n=%d lds=%lld", m, n, (long long)lds);
+  PH_REQUIRE(n == 0 || (S != nullptr && med != nullptr), "col_medians_resume_token: null S/med");
+  PH_REQUIRE(ignore_zero >= -1 && ignore_zero <= 1, "col_medians_resume_token: ignore_zero=%d", ignore_zero);
+  PH_REQUIRE(ignore_zero >= 0 || flags != nullptr, "col_medians_resume_token: ignore_zero = auto needs the flag words");
+  return launch_col_medians_resume(ctx, static_cast<const double*>(S), lds, m, n, ignore_zero,
+                                   static_cast<const uint32_t*>(flags), static_cast<double*>(med), token);
+} catch (...) { return plaidhip::on_exception(); }
+
+int plaidhip_dev_fused_medians_discard(plaidhip_ctx* ctx) try {
+  PH_CTX(ctx);
+  ctx->fmed.valid = false;
+  ctx->fmed.token = 0;
+  return PLAIDHIP_OK;
+} catch (...) { return plaidhip::on_exception(); }
+
 int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]) try {
   PH_CTX(ctx);
   PH_REQUIRE(info != nullptr, "fused_medians_info: null info");
   info[0] = ctx->fmed.n;
   info[1] = (int64_t)reinterpret_cast<intptr_t>(ctx->fmed.status);
   info[2] = (int64_t)reinterpret_cast<intptr_t>(ctx->fmed.cal);
-  info[3] = ctx->fmed.valid ? 1 : 0;
+  info[3] = ctx->fmed.valid ? (int64_t)ctx->fmed.token : 0;
   return PLAIDHIP_OK;
 } catch (...) { return plaidhip::on_exception(); }
 

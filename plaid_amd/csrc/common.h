@@ -104,8 +104,10 @@ struct plaidhip_ctx {
   // four counts and a slice of candidate scores.
   void* fmed_buf = nullptr;
   size_t fmed_bytes = 0;
+  uint64_t fmed_gen = 0;          // generation counter of the fused launches: the token a caller hands back to resume
   struct fused_medians {
     bool valid = false;
+    uint64_t token = 0;           // generation of the launch that left this state (0: none)
     const double* S = nullptr;
     int64_t lds = 0;
     int32_t m = 0, n = 0, nslice = 0, capc = 0;
@@ -335,7 +337,7 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                               int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host,
                               int64_t nnz_choice = -1 /* what picks scatter / gather when it is not nnz itself */);
 int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
-                              const uint32_t* flags, double* med);
+                              const uint32_t* flags, double* med, int64_t token = -1);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)
 int launch_nonneg_range(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, int64_t nnz_hint, double* out);
 int launch_colsum_max(plaidhip_ctx* ctx, const double* Xx, const int32_t* Xp, int32_t n, double* out);

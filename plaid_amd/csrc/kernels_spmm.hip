@@ -556,15 +556,25 @@ spmm_colpair_f64(SpmmPairArgs a) {
         // pointers read from memory are generic to the compiler: say "global" or it emits flat loads
         const cptr_i32 wtile_end = (cptr_i32)sl->wtile_end;
         gptr_u8 ibase = (gptr_u8)sl->tile_idx + (int64_t)ch_begin * 1024;  // uniform
+#ifdef PLAIDHIP_DIAG
         const gptr_u8 ibase0 = ibase;
+#endif
         uint32_t lane_o = (uint32_t)lane;
         asm volatile("" : "+v"(lane_o));
         const uint32_t ioff = lane_o * 16u;
+#ifdef PLAIDHIP_DIAG   /* tools/ build only: ABL 2 = synthetic ids (no index stream), 6 = the same 2 KiB again (L1-resident) */
 #define PLAIDHIP_LOADQ(rel)                                                                          \
   (ABL == 2 ? u32x4{lane_o | ((lane_o + 64u) << 16), (lane_o + 128u) | ((lane_o + 192u) << 16),       \
                     (lane_o + 256u) | ((lane_o + 320u) << 16), (lane_o + 384u) | ((lane_o + 448u + (rel)) << 16)} \
-            : (ABL == 6 ? *(gptr_u32x4)(ibase0 + (int64_t)((rel) & 1) * 1024 + ioff)   /* L1-resident: same 2 KiB again */ \
+            : (ABL == 6 ? *(gptr_u32x4)(ibase0 + (int64_t)((rel) & 1) * 1024 + ioff)                   \
                         : *(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff)))
+#define PH_PAIR_PARTIALS (ABL != 5)   /* 5: no partial-sum round trip between slices (wrong scores) */
+#define PH_PAIR_META (ABL != 7)       /* 7: no per-tile metadata loads (wrong scores) */
+#else
+#define PLAIDHIP_LOADQ(rel) (*(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff))
+#define PH_PAIR_PARTIALS true
+#define PH_PAIR_META true
+#endif
 #define PLAIDHIP_GATHER4A(q)                                                   \
   va0 = lds_pair_at(off16_lo((q).x)); va1 = lds_pair_at(off16_hi((q).x));       \
   va2 = lds_pair_at(off16_lo((q).y)); va3 = lds_pair_at(off16_hi((q).y));
@@ -589,19 +599,19 @@ spmm_colpair_f64(SpmmPairArgs a) {
     const double sumA = ((a0 + a1) + (a2 + a3)) + old.x;                                       \
     const double sumB = ((b0 + b1) + (b2 + b3)) + old.y;                                       \
     if (!last) {                                                                               \
-      if (ABL != 5) *reinterpret_cast<f64x2*>(const_cast<char*>(part) + (int64_t)k * 1024 + ioff) = f64x2{sumA, sumB};  \
+      if (PH_PAIR_PARTIALS) *reinterpret_cast<f64x2*>(const_cast<char*>(part) + (int64_t)k * 1024 + ioff) = f64x2{sumA, sumB};  \
     } else if (mj >= 0) {                                                                      \
       PLAIDHIP_EPI(sumA, cA)                                                                   \
       if (hasB) PLAIDHIP_EPI(sumB, cB)                                                         \
     }                                                                                          \
     ++k;                                                                                       \
     next_end = wtile_end[k];                                   \
-    if (last && ABL != 7) {                                                                    \
+    if (last && PH_PAIR_META) {                                                                    \
       mj = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.meta_j) + (int64_t)k * 256 + moff4);  \
       mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
       mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
     }                                                                                          \
-    if (!first && ABL != 5) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);        \
+    if (!first && PH_PAIR_PARTIALS) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);        \
     a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = 0.0;                                               \
   }
         // 8 index chunks (8 KiB per wave) in flight: the lists come from L2 (~1 us away under load)
@@ -625,7 +635,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
           mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
         }
         f64x2 old = f64x2{0.0, 0.0};
-        if (!first && ABL != 5) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);
+        if (!first && PH_PAIR_PARTIALS) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);
         f64x2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
 
         // Half-chunk software pipeline: the four gathers of the next half are in the LDS queue
@@ -671,6 +681,8 @@ spmm_colpair_f64(SpmmPairArgs a) {
 #undef PLAIDHIP_TILE_END
 #undef PLAIDHIP_EPI
 #undef PLAIDHIP_LOADQ
+#undef PH_PAIR_PARTIALS
+#undef PH_PAIR_META
       }
       if (want_pf) {
         PLAIDHIP_PREFETCH(np, nsi);
@@ -2201,6 +2213,7 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                               int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host,
                               int64_t nnz_choice) {
   ctx->fmed.valid = false;
+  ctx->fmed.token = 0;
   ctx->fmed.n = 0;
   constexpr int K = 256;                         // calibration columns
   const plaidhip_scatter_plan& sp = gs->scatter;
@@ -2259,6 +2272,7 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                                    xmax_host, nnz, &med);
   if (rc != PLAIDHIP_OK) return rc;
   ctx->fmed.valid = true;
+  ctx->fmed.token = ++ctx->fmed_gen;
   ctx->fmed.S = S;
   ctx->fmed.lds = lds;
   ctx->fmed.m = gs->m;
@@ -2273,10 +2287,17 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
   return PLAIDHIP_OK;
 }
 
+// `token`: < 0 = the caller vouches that S is what the last fused launch on this context wrote and nothing touched it since
+// (the library's own pipelines, which call the two back to back); otherwise the value plaidhip_dev_fused_medians_info gave
+// after the fused call -- a stale or zero token takes the standalone kernels (always correct, one more pass over S).
 int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
-                              const uint32_t* flags, double* med) {
+                              const uint32_t* flags, double* med, int64_t token) {
   const auto& f = ctx->fmed;
-  if (!(f.valid && f.S == S && f.lds == lds && f.m == m && f.n == n)) return launch_col_medians(ctx, S, lds, m, n, ignore_zero, flags, med);
+  const bool mine = f.valid && f.S == S && f.lds == lds && f.m == m && f.n == n && (token < 0 || (uint64_t)token == f.token);
+  if (!mine) {
+    ctx->fmed.valid = false;   // (whatever was pending describes another S, or one the caller no longer vouches for)
+    return launch_col_medians(ctx, S, lds, m, n, ignore_zero, flags, med);
+  }
   ctx->fmed.valid = false;   // (consumed: S is about to be shifted)
   const int rc = launch_median_select(ctx, f.cand, f.cnt, n, f.nslice, f.capc, m, f.cal, ignore_zero, flags, med, f.status);
   if (rc != PLAIDHIP_OK) return rc;

@@ -479,7 +479,8 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
     if (sparse) {
       // scatter or gather is chosen from the density of the WHOLE matrix, not of the shard: every sharding of the same
       // call takes the same kernel (the gather kernels are then bit-identical across shardings; the scatter kernel adds
-      // in arrival order and agrees to the last bits only, as it does from run to run)
+      // in arrival order and agrees to the last bits only, as it does from run to run -- and its fixed-point grid, where
+      // the column-sum bound picks it, follows the SHARD's largest column sum: 2^-40 relative across shardings)
       const int64_t nnz_choice = (int64_t)((double)c.Xp[c.n] / (double)c.n * (double)nloc);
       // replaid.ssgsea: the values are rank weights in [0, max(rX)] (the scatter kernel may sum them in fixed point)
       // (normalised results: the crossprod also classifies its scores for the medians below, launch_col_medians_resume)

@@ -156,17 +156,32 @@ class Context:
         over S (plaidhip_dev_spmm_csc_fused_f64)"""
         check(self.lib.plaidhip_dev_spmm_csc_fused_f64(self.handle, gs.handle, Xp, Xi, Xx, n, int(nnz), STAT[stat], alpha,
                                                        alpha_div, beta, S, lds, flags, rmax))
+        return self.dev_fused_medians_token()
 
-    def dev_col_medians_resume(self, S: int, lds: int, m: int, n: int, ignore_zero, med: int, flags: int | None = None):
-        """dev_col_medians for the S the last dev_spmm_csc_fused on this context wrote"""
+    def dev_col_medians_resume(self, S: int, lds: int, m: int, n: int, ignore_zero, med: int, flags: int | None = None,
+                               token: int | None = None):
+        """dev_col_medians for the S the last dev_spmm_csc_fused on this context wrote.  `token` (what dev_spmm_csc_fused
+        returned): the candidates are used only while they are the pending ones of that very launch; None = the caller
+        resumes directly after the crossprod (S recognised by pointer and shape)"""
         iz = -1 if ignore_zero is None else int(bool(ignore_zero))
-        check(self.lib.plaidhip_dev_col_medians_resume(self.handle, S, lds, m, n, iz, flags, med))
+        if token is None:
+            check(self.lib.plaidhip_dev_col_medians_resume(self.handle, S, lds, m, n, iz, flags, med))
+        else:
+            check(self.lib.plaidhip_dev_col_medians_resume_token(self.handle, int(token), S, lds, m, n, iz, flags, med))
+
+    def dev_fused_medians_discard(self):
+        check(self.lib.plaidhip_dev_fused_medians_discard(self.handle))
+
+    def dev_fused_medians_token(self) -> int:
+        """token of the pending fused launch (0: none -- the plain route ran, or it was consumed / superseded)"""
+        return self.dev_fused_medians_info()[3]
 
     def dev_fused_medians_info(self):
-        """(columns of the last fused crossprod or 0, device pointer of status[n], device pointer of the calibration, pending)"""
+        """(columns of the last fused crossprod or 0, device pointer of status[n], device pointer of the calibration,
+        token of the pending launch or 0)"""
         buf = (C.c_int64 * 4)()
         check(self.lib.plaidhip_dev_fused_medians_info(self.handle, buf))
-        return int(buf[0]), int(buf[1]), int(buf[2]), bool(buf[3])
+        return int(buf[0]), int(buf[1]), int(buf[2]), int(buf[3])
 
     def dev_crossprod_weighted(self, Wp: int, Wi: int, Wx: int, g: int, m: int, Y: int, ldy: int, n: int, S: int,
                                lds: int):

@@ -77,22 +77,27 @@ class HipPhaseEngine:
                                "stream=<that stream>.cuda_stream and call inside `with torch.cuda.stream(<that stream>)`")
 
     def spmm_csc(self, X: CscShard, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None,
-                 rank_weights=False):
+                 rank_weights=False, normalize=False):
         """crossprod with a CSC shard; `values` replaces X.x (e.g. the ranks of the stored values).  `rank_weights`: the
-        values lie in [0, *alpha_div] (rank^power and their global maximum): order-independent fixed-point sums"""
+        values lie in [0, *alpha_div] (rank^power and their global maximum): order-independent fixed-point sums.
+        `normalize`: the caller will call medians(S, flags) on the result: the crossprod may classify its scores for them"""
         self._same_stream()
         t = self.torch
         S = t.empty((X.n, self.gs.m), dtype=t.float64, device=self.device)
+        self._fused = None
         if X.n > 0:
             xx = X.x if values is None else values
             fl = flags.data_ptr() if flags is not None else None
             div = alpha_div.data_ptr() if alpha_div is not None else None
-            if fl is not None:
-                # a normalising caller (flag words wanted): the crossprod also classifies its scores for the medians
+            if fl is not None and normalize:
+                # a normalising caller: the crossprod also classifies its scores for the medians
                 # (plaidhip_dev_spmm_csc_fused_f64; the plain kernels when the shapes do not call for it) -- medians() below
-                # finishes them after the flag words have been all-reduced
-                self.ctx.dev_spmm_csc_fused(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(), self.gs.m,
-                                            stat, alpha, beta, fl, div, div if rank_weights else None, nnz=X.nnz)
+                # finishes them after the flag words have been all-reduced.  The token ties the pending candidates to THIS
+                # launch and the weak reference to THIS tensor: an S that merely sits at the same address never matches.
+                import weakref
+                token = self.ctx.dev_spmm_csc_fused(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(),
+                                                    self.gs.m, stat, alpha, beta, fl, div, div if rank_weights else None, nnz=X.nnz)
+                self._fused = (weakref.ref(S), token) if token else None
             elif rank_weights and alpha_div is not None:
                 self.ctx.dev_spmm_csc_ranks(self.gs, X.p.data_ptr(), X.i.data_ptr(), xx.data_ptr(), X.n, S.data_ptr(),
                                             self.gs.m, div, stat, alpha, beta, fl, nnz=X.nnz)
@@ -169,8 +174,11 @@ class HipPhaseEngine:
         med = t.empty(max(n, 1), dtype=t.float64, device=self.device)
         red = t.zeros(2, dtype=t.float64, device=self.device)
         if n > 0:
-            # (= dev_col_medians unless this S came out of a fused crossprod: then only unresolved columns are swept)
-            self.ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
+            # dev_col_medians -- unless this very tensor came out of a fused crossprod whose candidates are still pending on the
+            # context: then only unresolved columns are swept
+            fused, self._fused = getattr(self, "_fused", None), None
+            token = fused[1] if (fused is not None and fused[0]() is S) else 0
+            self.ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr(), token=token)
             self.ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
         return med, red
 
@@ -238,8 +246,7 @@ def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, 
     import torch.distributed as dist
     world, _ = _world(group)
     flags = engine.new_flags()
-    S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values, rank_weights=True) if rank_weights else \
-        engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values)
+    S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values, rank_weights=rank_weights, normalize=normalize)
     if normalize:
         if world > 1:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
@@ -315,9 +322,15 @@ def sharded_plaid_test(engine, X_local, y_local, Gp, tests=("one", "two", "lm"),
     mm = {"fisher": 0, "sumlog": 0, "stouffer": 1, "sumz": 1}
     if metap_method not in mm:
         raise ValueError(f"Invalid method: {metap_method}")                   # R/plaid.R:533
-    y_local = y_local.to(torch.int32)
-    if y_local.numel() and not bool(((y_local == 0) | (y_local == 1)).all()):
+    # checked on the caller's dtype (0.5 or NaN must not be truncated into a legal label), and by all ranks together: the
+    # rank holding the bad label must not be the only one that leaves before the collectives below
+    y_ok = torch.tensor([1 if (y_local.numel() == 0 or bool(((y_local == 0) | (y_local == 1)).all())) else 0], dtype=torch.int32,
+                        device=y_local.device)
+    if world > 1:
+        dist.all_reduce(y_ok, op=dist.ReduceOp.MIN, group=group)
+    if not bool(y_ok.item()):
         raise ValueError("elements of y must be 0 or 1")                      # R/plaid.R:394
+    y_local = y_local.to(torch.int32)
     g = X_local.shape[1]
     cnt = torch.stack([(y_local == 0).sum(), (y_local == 1).sum()]).to(torch.float64)
 
@@ -352,6 +365,11 @@ class GatherRefused(RuntimeError):
     def __init__(self, message: str, needed: int, available: int):
         super().__init__(f"plaidhip error 4: {message}")
         self.needed, self.available = int(needed), int(available)
+
+
+class GatherError(RuntimeError):
+    """A rank failed while the score matrix was being assembled on the host: raised on EVERY rank (the ranks exchange an ok
+    flag before the root maps the files), the files are gone."""
 
 
 def _free_device_bytes(t):
@@ -605,16 +623,33 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
     # kernel's page allocation is what they wait for)
     parts = int(os.environ.get("PLAIDHIP_GATHER_PARTS",
                                max(2, min(8, 16 // max(world, 1))) if S_local.is_cuda and need // max(world, 1) >= (1 << 30) else 1))
+    parts = max(1, parts)
     if world > 1:                                   # (every rank must cut alike)
         pl = [parts]
         dist.broadcast_object_list(pl, src=dst, group=group)
         parts = pl[0]
     files = _StitchedFiles(msg[0][1], int(n_total), m, itemsize, world, parts)
-    files.create_rank(rank)
-    if world > 1:
-        dist.barrier(group=group)                  # (a block's last partial page lives in the NEXT file)
     lo, hi = shard_bounds(n_total, world, rank)
     nloc = hi - lo
+    failure = None
+
+    def all_ok(err):
+        """collective: every rank learns whether any rank failed (and why) -- nobody is left in a barrier"""
+        if world <= 1:
+            return err
+        seen = [None] * world
+        dist.all_gather_object(seen, None if err is None else f"rank {rank}: {type(err).__name__}: {err}", group=group)
+        bad = [s for s in seen if s is not None]
+        return bad[0] if bad else None
+
+    try:
+        files.create_rank(rank)
+    except Exception as exc:
+        failure = exc
+    bad = all_ok(failure)                            # (doubles as the barrier: a block's last partial page lives in the NEXT file)
+    if bad is not None:
+        files.unlink()
+        raise GatherError(f"gather_scores(to='host'): creating the files failed ({bad})") from failure
     try:
         if nloc > 0:
             if S_local.is_cuda:
@@ -663,12 +698,12 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
                     files.allocate(k)
                 files.write(lo * files.row_bytes, np.ascontiguousarray(src.numpy()).reshape(-1).view(np.uint8))
         files.close_maps()
-    except BaseException:
-        files.unlink()                              # (no names are left behind in /dev/shm when a rank fails)
-        raise
-    finally:
-        if world > 1:
-            dist.barrier(group=group)
+    except Exception as exc:
+        failure = exc
+    bad = all_ok(failure)                            # (and the barrier before the root maps what the others wrote)
+    if bad is not None:
+        files.unlink()                               # (no names are left behind in /dev/shm; every rank raises alike)
+        raise GatherError(f"gather_scores(to='host'): a rank failed while writing its block ({bad})") from failure
     if rank == dst:
         return files.stitch(np_dtype, (int(n_total), m))
     return None

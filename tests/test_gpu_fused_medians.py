@@ -236,3 +236,98 @@ def test_a_later_crossprod_into_the_same_matrix_invalidates_the_candidates(env):
     torch.cuda.synchronize()
     assert torch.equal(med_a, med_b)
     gs.close()
+
+
+def test_resume_with_a_stale_token_never_uses_old_candidates(env):
+    """the pending candidates of a fused crossprod used to be recognised by (S pointer, shape) alone -- an S that
+    was re-written (or re-allocated at the same address) by somebody else would have got the OLD medians.  With the token:
+    the matching token selects from the candidates; token 0 / a stale token / a discarded state run the standalone kernels
+    on whatever S holds NOW."""
+    torch, dev, stream, ctx = env
+    from plaid_amd import synth as sy
+    g, m, n = 20000, 9000, 1200
+    Gp, Gi = sy.geneset_csc(g, m)
+    gs = ctx.geneset(g, Gp, Gi)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    with torch.cuda.stream(stream):
+        dp, di, dx = (torch.from_numpy(np.ascontiguousarray(a_)).to(dev) for a_ in (Xp.astype(np.int32), Xi.astype(np.int32), Xx))
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        fl = torch.zeros(4, dtype=torch.int32, device=dev)
+        med = torch.empty(n, dtype=torch.float64, device=dev)
+        ref = torch.empty(n, dtype=torch.float64, device=dev)
+
+        def fused():
+            fl.zero_()
+            return ctx.dev_spmm_csc_fused(gs, dp.data_ptr(), di.data_ptr(), dx.data_ptr(), n, S.data_ptr(), m, "mean", 1.0, 0.0,
+                                          fl.data_ptr(), None, None, nnz=len(Xx))
+
+        def status_sum():
+            torch.cuda.synchronize()
+            nf, p_status, _, _ = ctx.dev_fused_medians_info()
+            st = np.zeros(max(nf, 1), dtype=np.int32)
+            ctx.lib.plaidhip_memcpy_d2h(ctx.handle, st.ctypes.data_as(C.c_void_p), C.c_void_p(p_status), C.c_size_t(4 * nf))
+            return int(st[:nf].sum())
+
+        # 1. the matching token: candidates are used
+        t1 = fused()
+        assert t1 > 0 and ctx.dev_fused_medians_token() == t1
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), fl.data_ptr(), token=t1)
+        ctx.dev_col_medians(S.data_ptr(), m, m, n, None, ref.data_ptr(), fl.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(med, ref) and ctx.dev_fused_medians_token() == 0 and status_sum() > 0.9 * n
+        # 2. somebody else rewrites S at the same address; a stale token (the consumed one) and token 0 take the plain kernels
+        t2 = fused()
+        assert t2 > t1
+        S.mul_(-3.0).add_(1.0)
+        ctx.dev_col_medians(S.data_ptr(), m, m, n, False, ref.data_ptr(), fl.data_ptr())
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, False, med.data_ptr(), fl.data_ptr(), token=t1)
+        torch.cuda.synchronize()
+        assert torch.equal(med, ref), "a stale token must not select among the candidates of an older S"
+        assert ctx.dev_fused_medians_token() == 0          # (and what was pending is dropped)
+        # 3. token 0 == "nothing pending that I know of"
+        fused()
+        S.mul_(0.5)
+        ctx.dev_col_medians(S.data_ptr(), m, m, n, False, ref.data_ptr(), fl.data_ptr())
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, False, med.data_ptr(), fl.data_ptr(), token=0)
+        torch.cuda.synchronize()
+        assert torch.equal(med, ref)
+        # 4. explicit discard
+        fused()
+        ctx.dev_fused_medians_discard()
+        assert ctx.dev_fused_medians_token() == 0
+    gs.close()
+
+
+def test_phase_engine_fuses_only_for_a_normalising_caller(env):
+    """sharded.HipPhaseEngine.spmm_csc(normalize=False) takes the plain crossprod and leaves nothing pending; with
+    normalize=True, medians() resumes only for the tensor that launch returned"""
+    torch, dev, stream, ctx = env
+    from plaid_amd import sharded, synth as sy
+    g, m, n = 20000, 9000, 1100
+    Gp, Gi = sy.geneset_csc(g, m)
+    gs = ctx.geneset(g, Gp, Gi)
+    Xp, Xi, Xx = sy.sparse_columns(g, 0, n)
+    with torch.cuda.stream(stream):
+        import scipy.sparse as sps
+        X = sharded.CscShard.from_scipy(sps.csc_matrix((Xx, Xi, Xp), shape=(g, n)), 0, n, dev)
+        eng = sharded.HipPhaseEngine(ctx, gs, dev)
+        fl = eng.new_flags()
+        S0 = eng.spmm_csc(X, flags=fl, normalize=False)
+        assert ctx.dev_fused_medians_token() == 0
+        fl = eng.new_flags()
+        S1 = eng.spmm_csc(X, flags=fl, normalize=True)
+        assert ctx.dev_fused_medians_token() > 0 and torch.equal(S0, S1)
+        # medians of ANOTHER tensor first: plain kernels, the pending state is dropped, not misapplied
+        other = (S1 * 2.0 - 1.0).contiguous()
+        fo = eng.new_flags()
+        ctx.dev_minflags(other.data_ptr(), other.numel(), fo.data_ptr())
+        med_o, _ = eng.medians(other, fo)
+        ref = torch.empty(n, dtype=torch.float64, device=dev)
+        ctx.dev_col_medians(other.data_ptr(), m, m, n, None, ref.data_ptr(), fo.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(med_o, ref) and ctx.dev_fused_medians_token() == 0
+        med1, _ = eng.medians(S1, fl)
+        ctx.dev_col_medians(S1.data_ptr(), m, m, n, None, ref.data_ptr(), fl.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(med1, ref)
+    gs.close()

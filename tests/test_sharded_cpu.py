@@ -58,7 +58,8 @@ class OraclePhaseEngine:
             flags[2] = max(int(flags[2]), int(np.isnan(S).any()))
         return torch.from_numpy(np.ascontiguousarray(S.T))
 
-    def spmm_csc(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None, rank_weights=False):
+    def spmm_csc(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, values=None, rank_weights=False,
+                 normalize=False):
         xx = (X.x if values is None else values).numpy()
         Xs = sp.csc_matrix((xx, X.i.numpy(), X.p.numpy()), shape=(self.g, X.n))
         return self._epilogue(np.asarray((self.G.T @ Xs).todense()), stat, alpha, beta, alpha_div, flags)

@@ -9,14 +9,15 @@ echo "pytest rc=$?" >> $out/pytest.log
 tail -5 $out/pytest.log
 python bench.py > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?"; tail -c 600 $out/bench.err
-python - <<PY
+cp bench_detail.json $out/bench_detail.json 2>/dev/null
+python3 - <<PY
 import json
 try:
-    d = json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
-    print("C2", d["value"], d["ms_per_step"], d["phases_ms"], d["roofline"]["frac"])
-    for k in ("c3", "c4"):
-        b = d.get(k, {})
-        print(k, b.get("ms_per_step"), b.get("scores_per_s"), b.get("phases_ms"), b.get("parity"), b.get("error"))
+    line = open("$out/bench.json").read().strip().splitlines()[-1]
+    d = json.loads(line)
+    print("line bytes", len(line), "C2", d["value"], d["ms_per_step"], d["phases_ms"], d["roofline"]["frac"], d["roofline"].get("lds_frac"), "parity", d["parity_ok"])
+    for k, b in d.get("blocks", {}).items():
+        print(k, b)
 except Exception as e:
     print("no bench line", e)
 PY
