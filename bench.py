@@ -458,6 +458,28 @@ def _bench_gather(env, S, n_total, modes):
     return out
 
 
+
+def _fused_info(ctx, torch):
+    """how the medians of the last timed step came about (status words of the fused crossprod, copied off the device)"""
+    try:
+        import ctypes as _C
+        import numpy as _np
+        nf, p_status, p_cal, _ = ctx.dev_fused_medians_info()
+        if not nf:
+            return None
+        torch.cuda.synchronize()
+        st_h, cal_h = _np.zeros(nf, dtype=_np.int32), _np.zeros(4)
+        ctx.lib.plaidhip_memcpy_d2h(ctx.handle, st_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_status), _C.c_size_t(4 * nf))
+        ctx.lib.plaidhip_memcpy_d2h(ctx.handle, cal_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_cal), _C.c_size_t(32))
+        return {"columns": int(nf), "selected_from_candidates": int(st_h.sum()), "left_to_the_standalone_kernel": int(nf - st_h.sum()),
+                "bracket": {"offset_from_predicted_mean": float(cal_h[0]), "half_width": float(cal_h[1]), "ignore_zero": bool(cal_h[2])},
+                "note": "medians selected inside the crossprod launch (plaidhip_dev_spmm_*_fused_f64 + ..._resume): "
+                        "phases_ms.crossprod includes the calibration, the column-mean prediction and the classifying "
+                        "epilogue; phases_ms.col_medians+sum is the selection + the standalone kernel on the columns left"}
+    except Exception as exc:  # pragma: no cover
+        return {"error": str(exc)[:200]}
+
+
 # ----------------------------------------------------------------------------------------- C2 (headline)
 def run_c2(a, env):
     import numpy as np
@@ -734,23 +756,7 @@ def run_sparse_ssgsea(a, env, n, label, collective, real_sets=False):
     snap = None
     if not collective and rank == 0 and a.cpu_sample > 0:
         snap = _snapshot(torch, S, med, red, flags, n, m, {"colmax": colmax, "gmax": gmax})
-    fused_info = None
-    try:   # how the medians of the last timed step came about (status words of the fused crossprod, copied off the device)
-        import ctypes as _C
-        import numpy as _np
-        nf, p_status, p_cal, _ = ctx.dev_fused_medians_info()
-        if nf:
-            torch.cuda.synchronize()
-            st_h, cal_h = _np.zeros(nf, dtype=_np.int32), _np.zeros(4)
-            ctx.lib.plaidhip_memcpy_d2h(ctx.handle, st_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_status), _C.c_size_t(4 * nf))
-            ctx.lib.plaidhip_memcpy_d2h(ctx.handle, cal_h.ctypes.data_as(_C.c_void_p), _C.c_void_p(p_cal), _C.c_size_t(32))
-            fused_info = {"columns": int(nf), "selected_from_candidates": int(st_h.sum()), "left_to_the_standalone_kernel": int(nf - st_h.sum()),
-                          "bracket": {"offset_from_predicted_mean": float(cal_h[0]), "half_width": float(cal_h[1]), "ignore_zero": bool(cal_h[2])},
-                          "note": "medians selected inside the crossprod launch (plaidhip_dev_spmm_csc_fused_f64 + ..._resume): "
-                                  "phases_ms.crossprod includes the calibration, the column-mean prediction and the classifying "
-                                  "epilogue; phases_ms.col_medians+sum is the selection + the standalone kernel on the columns left"}
-    except Exception as exc:  # pragma: no cover
-        fused_info = {"error": str(exc)[:200]}
+    fused_info = _fused_info(ctx, torch)
     rank_ms, spmm_ms, med_ms, shift_ms = (ev.phase_ms(i) for i in range(4))
     scatter = nnz * 8 < g * n
     spmm_alg = 12.0 * nnz + 4.0 * (n + 1) + 4.0 * z + 4.0 * (m + 1) + 8.0 * m * n
@@ -867,9 +873,11 @@ def run_c4(a, env):
         ctx.dev_colranks_dense(X.data_ptr(), g, g, ncols, R.data_ptr(), g, "average", False, 1.0 + alpha, colmax.data_ptr())
         ctx.dev_max(colmax.data_ptr(), ncols, gmax.data_ptr())
         ev.rec(k, 1)
-        ctx.dev_spmm_dense(gs, R.data_ptr(), g, ncols, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(), gmax.data_ptr())
+        # the crossprod also classifies its scores for normalize_medians (plaidhip_dev_spmm_dense_fused_f64, round 5); the resume
+        # call selects the medians among the candidates and sweeps only the columns it could not resolve
+        ctx.dev_spmm_dense_fused(gs, R.data_ptr(), g, ncols, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(), gmax.data_ptr())
         ev.rec(k, 2)
-        ctx.dev_col_medians(S.data_ptr(), m, m, ncols, None, med.data_ptr(), flags.data_ptr())
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, ncols, None, med.data_ptr(), flags.data_ptr())
         ctx.dev_sum(med.data_ptr(), ncols, red.data_ptr())
         ev.rec(k, 3)
         ctx.dev_shift_columns(S.data_ptr(), m, m, ncols, med.data_ptr(), 0.0, red.data_ptr())
@@ -880,6 +888,7 @@ def run_c4(a, env):
             pipeline(n, k)
 
     elapsed = _timed(torch, dist, False, dev, steps, 1, step)
+    fused_info = _fused_info(ctx, torch)
     snap = None
     if a.cpu_sample > 0:
         snap = _snapshot(torch, S, med, red, flags, n, m, {"colmax": colmax, "gmax": gmax})
@@ -895,12 +904,17 @@ def run_c4(a, env):
         "phases_ms": {"colranks+pow+max": round(rank_ms, 4), "crossprod": round(spmm_ms, 4),
                       "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4)},
         "rank_keys_per_s": round(float(g) * n / (rank_ms * 1e-3), 1),
+        "fused_medians": fused_info,
         "kernels": {
             "colranks": _roof("colranks_bucket_kernel<1024,20>", 16.0 * g * n, rank_ms,
                               _traffic("colranks_bucket_kernel<1024,20>", f"{g}xN", n)),
             "crossprod": _fp64_roof(_roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
                                           lds_bytes=float(info["padded_slots"]) * 8.0 * n), 2.0 * z * n),
-            "col_medians": _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n)),
+            "col_medians": (_roof("median_select_kernel + col_medians_stream_kernel (unresolved columns)", 8.0 * m * n, med_ms, None,
+                                  extra={"note": "algorithmic bytes are those of the full sweep the fused crossprod made unnecessary: "
+                                                 "frac > 1 would only say that S was not read again"})
+                            if fused_info else
+                            _roof("col_medians_stream_kernel", 8.0 * m * n, med_ms, _traffic("col_medians_stream_kernel", f"Nx{m}", n))),
             "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
         "dense_gemm_equivalent": {"flop": 2.0 * g * n * m, "note": "the dense contraction config 4 names would be "

@@ -270,6 +270,15 @@ int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* g
                                     double beta, void* S, int64_t lds, void* flags, const void* rmax);
 int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
                                     const void* flags, void* med);
+/* The DENSE crossprod that also prepares normalize_medians (round 5): plaidhip_dev_spmm_dense_f64 -- same S, same flags --
+ * and, when the fp64 pair kernel takes the input and the result has more than 6,144 sets per column and at least 1e9
+ * scores (PLAIDHIP_OPT_FUSED_MEDIANS overrides the size rule), the workgroup of a column pair computes the pair's mean
+ * scores from the X it stages (no extra pass over X), and the tile ends of the last gene slice classify the scores they
+ * write against the bracket around (mean + calibrated offset) exactly like the sparse form above.  Finish with
+ * plaidhip_dev_col_medians_resume (or ..._resume_token); with an ineligible call it is the plain crossprod.            */
+int plaidhip_dev_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X, int64_t ldx, int32_t n,
+                                      int stat, double alpha, const void* alpha_div, double beta, void* S, int64_t lds,
+                                      void* flags);
 /* plaidhip_dev_col_medians_resume recognises "that S" by (pointer, lds, m, n) only: right for a caller that resumes directly
  * after the fused crossprod.  A caller that may free and re-allocate S in between (an allocator that reuses addresses)
  * takes the TOKEN of the fused launch (plaidhip_dev_fused_medians_info, info[3], right after the crossprod; 0 = the plain

@@ -55,6 +55,7 @@ SIGNATURES = {
     "plaidhip_geneset_destroy": [_vp],
     "plaidhip_geneset_info": [_vp, C.POINTER(_i64)],
     "plaidhip_dev_spmm_dense_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
+    "plaidhip_dev_spmm_dense_fused_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_ranks_f64": [_vp, _vp, _vp, _i64, _i32, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],
     "plaidhip_dev_spmm_csc_ranks_f64": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _int, _f64, _vp, _f64, _vp, _i64, _vp],

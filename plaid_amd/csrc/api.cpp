@@ -346,6 +346,10 @@ int plaidhip_init(int device, void* stream, plaidhip_ctx** out) try {
                            // inside a stream capture must not allocate)
     hipError_t e = hipMalloc(&sel, 128);
     if (e == hipSuccess) e = hipMemset(sel, 0, 128);
+    // bytes 96..127: the EMPTY median bracket {offset 0, half width -1, ignore-zero 0} of a calibration launch (no score is a
+    // candidate), written once here so that no launch needs a host-to-device copy
+    static const double kEmptyBracket[4] = {0.0, -1.0, 0.0, 0.0};
+    if (e == hipSuccess) e = hipMemcpy(static_cast<char*>(sel) + 96, kEmptyBracket, 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -439,6 +443,21 @@ int plaidhip_dev_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   return launch_spmm_dense_f64(ctx, gs, static_cast<const double*>(X), ldx, n, stat, alpha,
                                static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
                                static_cast<uint32_t*>(flags));
+} catch (...) { return plaidhip::on_exception(); }
+
+int plaidhip_dev_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X,
+                                      int64_t ldx, int32_t n, int stat, double alpha, const void* alpha_div,
+                                      double beta, void* S, int64_t lds, void* flags) try {
+  PH_CTX(ctx);
+  PH_REQUIRE(gs != nullptr, "spmm_dense_fused: null geneset");
+  PH_REQUIRE(n >= 0, "spmm_dense_fused: n=%d", n);
+  PH_REQUIRE(n == 0 || (X != nullptr && S != nullptr), "spmm_dense_fused: null X/S");
+  PH_REQUIRE(ldx >= gs->g && lds >= gs->m, "spmm_dense_fused: leading dims ldx=%lld (g=%d) lds=%lld (m=%d)",
+             (long long)ldx, gs->g, (long long)lds, gs->m);
+  PH_REQUIRE(stat == PLAIDHIP_STAT_MEAN || stat == PLAIDHIP_STAT_SUM, "spmm_dense_fused: bad stat %d", stat);
+  return launch_spmm_dense_fused_f64(ctx, gs, static_cast<const double*>(X), ldx, n, stat, alpha,
+                                     static_cast<const double*>(alpha_div), beta, static_cast<double*>(S), lds,
+                                     static_cast<uint32_t*>(flags));
 } catch (...) { return plaidhip::on_exception(); }
 
 int plaidhip_dev_spmm_ranks_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* R,

@@ -336,6 +336,10 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
                               int32_t n, int64_t nnz, int stat, double alpha, const double* alpha_div, double beta, double* S,
                               int64_t lds, uint32_t* flags, bool bounded, const double* xmax_dev, double xmax_host,
                               int64_t nnz_choice = -1 /* what picks scatter / gather when it is not nnz itself */);
+// the dense crossprod (fp64 pair kernel) + everything normalize_medians can know by then (round 5); same resume call
+int launch_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n, int stat,
+                                double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                                int x_kind = 0);
 int launch_col_medians_resume(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, int ignore_zero,
                               const uint32_t* flags, double* med, int64_t token = -1);
 // {all values finite and >= 0 ? 0 : -1, max} of a device vector -> out[2] (kernels_norm.hip)

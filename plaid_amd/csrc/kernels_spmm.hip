@@ -400,6 +400,9 @@ struct SpmmPairArgs {
   const double* Xx;
   int32_t n, npairs, nslices, ktiles;
   int32_t nt_store;  // see SpmmArgs
+  int32_t part_nt;   // partial sums of the slice before are read with non-temporal loads: set when the workgroups' scratches
+                     // (32 per XCD) outgrow the 4 MiB L2 -- read once and dead, the lines then do not displace the index lists
+                     // (50,000 sets: -4 % kernel time; 5,000 sets, scratch L2-resident: +3 %, so not there)
   const plaidhip_pair_slice_dev* slices;
   const int32_t* wave_tile_off;
   const int32_t* meta_j;
@@ -415,6 +418,17 @@ struct SpmmPairArgs {
   uint32_t* spec;            // guarded fallback of a speculative launch (SpmmArgs::spec), null: unconditional
   uint32_t spec_gen;
   unsigned long long* dbg;   // STAMP only
+  // MED (dense X; medians selected on the fly, like spmm_scatter_csc_f64<.., MED> below): per-gene mean set weight u[] of
+  // this launch's statistic and beta x kappa (the column's mean score is alpha * sum_i x[i, c] u[i] + beta * kappa: the
+  // workgroup stages every x[i, c] anyway), the calibration {offset, half width, ignore-zero}, per (column, wavefront) a
+  // slice of `med_capc` candidate scores and the counts {below, zero, NaN, candidates}; med_pred: the predicted means (out)
+  const double* med_u;
+  double med_beta_kappa;
+  const double* med_cal;
+  double* med_pred;
+  unsigned long long* med_cand;
+  uint32_t* med_cnt;
+  int32_t med_capc;
 };
 
 __device__ __forceinline__ uint32_t off16_lo(uint32_t q) {
@@ -433,10 +447,15 @@ __device__ __forceinline__ f64x2 lds_pair_at(uint32_t byte_off) {
   return *reinterpret_cast<lds_cf64x2*>(static_cast<uintptr_t>(byte_off));
 }
 
-template <bool STAMP, int ABL = 0, bool CSC_X = false>
+// MED (dense X only): the launch also classifies every score it writes for normalize_medians (R/plaid.R:561-572) -- counts
+// below the bracket / exact zeros / NaN per (column, wavefront) and the scores inside the bracket to a candidate list --
+// so that the medians of a 50,000-set result need no second pass over the scores (launch_spmm_dense_fused_f64).  The
+// bracket sits around the column's MEAN score, which the workgroup computes from the X it stages: sum_i x[i, c] u[i].
+template <bool STAMP, int ABL = 0, bool CSC_X = false, bool MED = false>
 __global__ void __launch_bounds__(1024)
 spmm_colpair_f64(SpmmPairArgs a) {
   constexpr int BLOCK = 1024;
+  static_assert(!(MED && CSC_X), "the classifying epilogue is built for dense X");
   if (spec_guard(a.spec, a.spec_gen, a.flags)) return;
   if constexpr (CSC_X) {
     if (a.sparse_cells != 0 && ((int64_t)a.Xp[a.n] - a.Xp[0]) * 8 < a.sparse_cells) return;
@@ -461,6 +480,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
   const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
   const int ns = a.nslices;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
+  const bool part_nt = a.part_nt != 0;
   f64x2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;   // next slice: p0..p4 column A, p5..p9 column B
   p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = f64x2{0.0, 0.0};
 
@@ -500,10 +520,28 @@ spmm_colpair_f64(SpmmPairArgs a) {
   if (!CSC_X && p < a.npairs) PLAIDHIP_PREFETCH(p, 0);
   const char* part = reinterpret_cast<const char*>(a.partial + (size_t)blockIdx.x * (size_t)(a.ktiles + 1) * 64);  // uniform
 
+  // MED: wave-uniform state of the pair being written (scalar registers)
+  double med_dotA = 0.0, med_dotB = 0.0;                      // this thread's share of sum_i x[i, c] u[i]
+  double med_loA = 0.0, med_hiA = 0.0, med_loB = 0.0, med_hiB = 0.0;
+  uint32_t w_ltA = 0, w_zeroA = 0, w_candA = 0, w_ltB = 0, w_zeroB = 0, w_candB = 0;
+  uint32_t w_nanA = 0, w_nanB = 0;                            // a NaN score of column A / B was written by this wavefront
+  uint32_t med_fw = 0;                                        // flag bits from the lane masks (wave-uniform)
+  unsigned long long* med_sliceA = nullptr;
+  unsigned long long* med_sliceB = nullptr;
+  bool med_iz = false;
+  if constexpr (MED) med_iz = a.med_cal[2] != 0.0;
+
   for (; p < a.npairs; p += gridDim.x) {
     const int cA = 2 * p;
     const bool hasB = cA + 1 < a.n;
     const int cB = hasB ? cA + 1 : cA;
+    if constexpr (MED) {
+      med_dotA = med_dotB = 0.0;
+      w_ltA = w_zeroA = w_candA = w_ltB = w_zeroB = w_candB = 0u;
+      w_nanA = w_nanB = 0u;
+      med_sliceA = a.med_cand + ((int64_t)cA * (BLOCK / 64) + wave) * a.med_capc;
+      med_sliceB = a.med_cand + ((int64_t)cB * (BLOCK / 64) + wave) * a.med_capc;
+    }
     for (int si = 0; si < ns; ++si) {
       const cptr_pair_slice sl = (cptr_pair_slice)(a.slices + si);
       const int gs_ = sl->gs;
@@ -512,6 +550,53 @@ spmm_colpair_f64(SpmmPairArgs a) {
       if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
       int tid_o = tid;
       asm volatile("" : "+v"(tid_o));
+      if constexpr (MED) {
+        // this slice's share of the column means: the prefetched X of the slice is in p0..p9 (zero past the slice's end), u
+        // comes from L2 (160 KB per statistic); unconditional loads at clamped indices: one round trip for all five
+        const char* ub_ = reinterpret_cast<const char*>(a.med_u + sl->g0);
+        const int last2_ = g2 > 0 ? g2 - 1 : 0;
+#define PLAIDHIP_DOT_ONE(k, ra, rb)                                                                    \
+  if (k * BLOCK < g2) {                                                                                 \
+    const int i_ = tid_o + k * BLOCK;                                                                   \
+    const f64x2 u_ = *reinterpret_cast<const f64x2*>(ub_ + (size_t)(i_ < last2_ ? i_ : last2_) * 16);  \
+    med_dotA += ra.x * u_.x + ra.y * u_.y;                                                              \
+    med_dotB += rb.x * u_.x + rb.y * u_.y;                                                              \
+  }
+        PLAIDHIP_DOT_ONE(0, p0, p5) PLAIDHIP_DOT_ONE(1, p1, p6) PLAIDHIP_DOT_ONE(2, p2, p7)
+        PLAIDHIP_DOT_ONE(3, p3, p8) PLAIDHIP_DOT_ONE(4, p4, p9)
+#undef PLAIDHIP_DOT_ONE
+        if ((gs_ & 1) && tid == 0) {
+          const int64_t gl = (int64_t)sl->g0 + gs_ - 1;
+          const double u_ = a.med_u[gl];
+          med_dotA += a.X[(int64_t)cA * a.ldx + gl] * u_;
+          med_dotB += a.X[(int64_t)cB * a.ldx + gl] * u_;
+        }
+        if (si == ns - 1) {
+          // the column means, the same bits on every lane: wave sums -> 16 LDS entries (the slice of the pass before is
+          // dead behind its end barrier, this one is not staged yet) -> one fixed-order sum
+          double sa_ = med_dotA, sb_ = med_dotB;
+          for (int off = 32; off >= 1; off >>= 1) { sa_ += __shfl_xor(sa_, off, 64); sb_ += __shfl_xor(sb_, off, 64); }
+          if (lane == 0) ent[wave] = f64x2{sa_, sb_};
+          __syncthreads();
+          const f64x2 t_ = ent[lane & 15];
+          sa_ = t_.x; sb_ = t_.y;
+          for (int off = 8; off >= 1; off >>= 1) { sa_ += __shfl_xor(sa_, off, 64); sb_ += __shfl_xor(sb_, off, 64); }
+          __syncthreads();   // (the staging below overwrites the entries)
+          const double prA_ = alpha * sa_ + a.med_beta_kappa, prB_ = alpha * sb_ + a.med_beta_kappa;
+          if (tid == 0) {
+            a.med_pred[cA] = prA_;
+            if (hasB) a.med_pred[cB] = prB_;
+          }
+          const double off_ = a.med_cal[0], hw_ = a.med_cal[1];
+          auto uni = [](double x) {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+          };
+          med_loA = uni((prA_ + off_) - hw_);
+          med_hiA = uni((prA_ + off_) + hw_);
+          med_loB = uni((prB_ + off_) - hw_);
+          med_hiB = uni((prB_ + off_) + hw_);
+        }
+      }
       if constexpr (!CSC_X) {
         // ---- stage the slice of both columns, interleaved ---------------------------------
         PLAIDHIP_ST_ONE(0, p0, p5) PLAIDHIP_ST_ONE(1, p1, p6) PLAIDHIP_ST_ONE(2, p2, p7)
@@ -568,11 +653,25 @@ spmm_colpair_f64(SpmmPairArgs a) {
                     (lane_o + 256u) | ((lane_o + 320u) << 16), (lane_o + 384u) | ((lane_o + 448u + (rel)) << 16)} \
             : (ABL == 6 ? *(gptr_u32x4)(ibase0 + (int64_t)((rel) & 1) * 1024 + ioff)                   \
                         : *(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff)))
-#define PH_PAIR_PARTIALS (ABL != 5)   /* 5: no partial-sum round trip between slices (wrong scores) */
+#define PH_PAIR_PSTORE (ABL != 5 && ABL != 9)   /* 5: no partial-sum round trip between slices; 9: loads only (wrong scores) */
+#define PH_PAIR_PLOAD (ABL != 5 && ABL != 8)    /* 8: stores only */
+#define PH_PAIR_PSLOT(k_) (ABL == 10 ? ((k_) & 3) : (k_))   /* 10: a four-tile scratch per workgroup: always L2-resident */
+#define PH_PAIR_PST_NT (ABL == 11 || ABL == 12)   /* 11: non-temporal partial stores and loads, 12: stores only, 13: loads only */
+#define PH_PAIR_PLD_NT (ABL == 11 || ABL == 13 || ABL == 14)
+#define PH_PAIR_PST_SC1 (ABL == 14 || ABL == 15)   /* 14: agent-scope (sc1) 8-byte stores + nt loads, 15: sc1 stores + sc1 loads */
+#define PH_PAIR_PLD_SC1 (ABL == 15)
+#define PH_PAIR_SST_SC1 (ABL == 16)   /* 16: score stores with agent scope (sc1: the lines do not stay in L2) */
 #define PH_PAIR_META (ABL != 7)       /* 7: no per-tile metadata loads (wrong scores) */
 #else
 #define PLAIDHIP_LOADQ(rel) (*(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff))
-#define PH_PAIR_PARTIALS true
+#define PH_PAIR_PSTORE true
+#define PH_PAIR_PLOAD true
+#define PH_PAIR_PSLOT(k_) (k_)
+#define PH_PAIR_PST_NT false
+#define PH_PAIR_PLD_NT false
+#define PH_PAIR_PST_SC1 false
+#define PH_PAIR_PLD_SC1 false
+#define PH_PAIR_SST_SC1 false
 #define PH_PAIR_META true
 #endif
 #define PLAIDHIP_GATHER4A(q)                                                   \
@@ -584,25 +683,68 @@ spmm_colpair_f64(SpmmPairArgs a) {
 #define PLAIDHIP_ADD4(V)                                                       \
   a0 += (V##0).x; b0 += (V##0).y; a1 += (V##1).x; b1 += (V##1).y;                       \
   a2 += (V##2).x; b2 += (V##2).y; a3 += (V##3).x; b3 += (V##3).y;
-#define PLAIDHIP_EPI(sum, cc)                                                  \
+#define PLAIDHIP_EPI(sum, cc, out_)                                            \
   {                                                                            \
     const double w_ = is_mean ? mw : 1.0;                                      \
     const double v_ = alpha * ((sum) * w_) + a.beta * (mk * w_);               \
-    if (a.nt_store) __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);  \
+    if (PH_PAIR_SST_SC1) __hip_atomic_store(&a.S[(int64_t)(cc) * a.lds + mj], v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    else if (a.nt_store) __builtin_nontemporal_store(v_, &a.S[(int64_t)(cc) * a.lds + mj]);  \
     else a.S[(int64_t)(cc) * a.lds + mj] = v_;                                 \
-    f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                              \
-    f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                            \
-    f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                              \
+    if constexpr (!MED) {   /* (MED: the flag words come out of the classification's lane masks, below) */ \
+      f |= (v_ < 0.0) ? PLAIDHIP_FLAG_HAS_NEG : 0u;                            \
+      f |= (v_ == 0.0) ? PLAIDHIP_FLAG_HAS_ZERO : 0u;                          \
+      f |= (v_ != v_) ? PLAIDHIP_FLAG_HAS_NAN : 0u;                            \
+    }                                                                          \
+    out_ = v_;                                                                 \
+  }
+/* MED: five compares per score, all as lane masks in scalar registers -- below the bracket, not above it, exactly zero,  \
+   negative, NaN: scalar counters and the three flag words (no per-lane flag arithmetic in this form); the scores inside   \
+   the bracket are appended to this wavefront's own slice of the column's candidate list (no shared counter, no atomic).   \
+   Lanes without a set carry NaN and fail the first four compares; `set_` masks them out of the fifth. */                 \
+#define PLAIDHIP_MED_CLASSIFY(v_, X, set_)                                                                        \
+  {                                                                                                               \
+    const uint64_t lt_ = __ballot((v_) < med_lo##X);                                                              \
+    const uint64_t le_ = __ballot((v_) <= med_hi##X);                                                             \
+    const uint64_t zero_ = __ballot((v_) == 0.0);                                                                 \
+    const uint64_t neg_ = __ballot((v_) < 0.0);                                                                   \
+    const uint64_t nan_ = __ballot((v_) != (v_)) & (set_);                                                        \
+    med_fw |= (neg_ != 0ull ? PLAIDHIP_FLAG_HAS_NEG : 0u) | (zero_ != 0ull ? PLAIDHIP_FLAG_HAS_ZERO : 0u) |        \
+              (nan_ != 0ull ? PLAIDHIP_FLAG_HAS_NAN : 0u);                                                        \
+    w_nan##X |= nan_ != 0ull ? 1u : 0u;                                                                           \
+    const uint64_t in_ = (le_ & ~lt_) & (med_iz ? ~zero_ : ~0ull);                                                \
+    w_lt##X += (uint32_t)__popcll(lt_);                                                                           \
+    w_zero##X += (uint32_t)__popcll(zero_);                                                                       \
+    if (in_ != 0ull) {                                                                                            \
+      const uint32_t slot_ = w_cand##X + __builtin_amdgcn_mbcnt_hi((uint32_t)(in_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in_, 0u)); \
+      if (__builtin_amdgcn_inverse_ballot_w64(in_) && slot_ < (uint32_t)a.med_capc)                               \
+        med_slice##X[slot_] = (unsigned long long)__double_as_longlong(v_);                                      \
+      w_cand##X += (uint32_t)__popcll(in_);                                                                       \
+    }                                                                                                             \
   }
 #define PLAIDHIP_TILE_END(chv)                                                                 \
   if ((chv) + 1 == next_end) { /* wave-uniform: tile finished */                               \
     const double sumA = ((a0 + a1) + (a2 + a3)) + old.x;                                       \
     const double sumB = ((b0 + b1) + (b2 + b3)) + old.y;                                       \
     if (!last) {                                                                               \
-      if (PH_PAIR_PARTIALS) *reinterpret_cast<f64x2*>(const_cast<char*>(part) + (int64_t)k * 1024 + ioff) = f64x2{sumA, sumB};  \
-    } else if (mj >= 0) {                                                                      \
-      PLAIDHIP_EPI(sumA, cA)                                                                   \
-      if (hasB) PLAIDHIP_EPI(sumB, cB)                                                         \
+      if (PH_PAIR_PSTORE) {                                                                    \
+        f64x2* dst_ = reinterpret_cast<f64x2*>(const_cast<char*>(part) + (int64_t)PH_PAIR_PSLOT(k) * 1024 + ioff);  \
+        if (PH_PAIR_PST_NT) __builtin_nontemporal_store(f64x2{sumA, sumB}, dst_);              \
+        else if (PH_PAIR_PST_SC1) {                                                            \
+          __hip_atomic_store(reinterpret_cast<double*>(dst_), sumA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
+          __hip_atomic_store(reinterpret_cast<double*>(dst_) + 1, sumB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+        } else *dst_ = f64x2{sumA, sumB};                                                      \
+      }                                                                                        \
+    } else {                                                                                   \
+      double vA_ = __longlong_as_double(0x7ff8000000000000ll), vB_ = vA_;                      \
+      if (mj >= 0) {                                                                           \
+        PLAIDHIP_EPI(sumA, cA, vA_)                                                            \
+        if (hasB) PLAIDHIP_EPI(sumB, cB, vB_)                                                  \
+      }                                                                                        \
+      if constexpr (MED) {                                                                     \
+        const uint64_t set_ = __ballot(mj >= 0);                                               \
+        PLAIDHIP_MED_CLASSIFY(vA_, A, set_)                                                    \
+        PLAIDHIP_MED_CLASSIFY(vB_, B, hasB ? set_ : 0ull)                                      \
+      }                                                                                        \
     }                                                                                          \
     ++k;                                                                                       \
     next_end = wtile_end[k];                                   \
@@ -611,7 +753,13 @@ spmm_colpair_f64(SpmmPairArgs a) {
       mw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_w) + (int64_t)k * 512 + moff8);   \
       mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);   \
     }                                                                                          \
-    if (!first && PH_PAIR_PARTIALS) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);        \
+    if (!first && PH_PAIR_PLOAD) {                                                             \
+      const f64x2* src_ = reinterpret_cast<const f64x2*>(part + (int64_t)PH_PAIR_PSLOT(k) * 1024 + ioff);  \
+      if (PH_PAIR_PLD_SC1) {                                                                   \
+        old.x = __hip_atomic_load(reinterpret_cast<const double*>(src_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
+        old.y = __hip_atomic_load(reinterpret_cast<const double*>(src_) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+      } else old = (PH_PAIR_PLD_NT || part_nt) ? __builtin_nontemporal_load(src_) : *src_;     \
+    }                                                                                          \
     a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = 0.0;                                               \
   }
         // 8 index chunks (8 KiB per wave) in flight: the lists come from L2 (~1 us away under load)
@@ -635,7 +783,10 @@ spmm_colpair_f64(SpmmPairArgs a) {
           mk = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.meta_k) + (int64_t)k * 512 + moff8);
         }
         f64x2 old = f64x2{0.0, 0.0};
-        if (!first && PH_PAIR_PARTIALS) old = *reinterpret_cast<const f64x2*>(part + (int64_t)k * 1024 + ioff);
+        if (!first && PH_PAIR_PLOAD) {
+          const f64x2* src_ = reinterpret_cast<const f64x2*>(part + (int64_t)PH_PAIR_PSLOT(k) * 1024 + ioff);
+          old = (PH_PAIR_PLD_NT || part_nt) ? __builtin_nontemporal_load(src_) : *src_;
+        }
         f64x2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
 
         // Half-chunk software pipeline: the four gathers of the next half are in the LDS queue
@@ -680,8 +831,16 @@ spmm_colpair_f64(SpmmPairArgs a) {
 #undef PLAIDHIP_ADD4
 #undef PLAIDHIP_TILE_END
 #undef PLAIDHIP_EPI
+#undef PLAIDHIP_MED_CLASSIFY
 #undef PLAIDHIP_LOADQ
-#undef PH_PAIR_PARTIALS
+#undef PH_PAIR_PSTORE
+#undef PH_PAIR_PLOAD
+#undef PH_PAIR_PSLOT
+#undef PH_PAIR_PST_NT
+#undef PH_PAIR_PLD_NT
+#undef PH_PAIR_PST_SC1
+#undef PH_PAIR_PLD_SC1
+#undef PH_PAIR_SST_SC1
 #undef PH_PAIR_META
       }
       if (want_pf) {
@@ -698,6 +857,15 @@ spmm_colpair_f64(SpmmPairArgs a) {
         t_wait += ts3 - ts2;
       }
     }
+    if constexpr (MED) {   // this wavefront's counts of the pair's two columns (a wavefront without tiles writes zeros)
+      const uint32_t nanA_ = w_nanA, nanB_ = w_nanB;
+      if (lane == 0) {
+        uint4* o_ = reinterpret_cast<uint4*>(a.med_cnt);
+        // {scores below the bracket that take part, exact zeros, NaN (lanes, not scores: only "any" matters), candidates}
+        o_[(int64_t)cA * (BLOCK / 64) + wave] = make_uint4((med_iz && med_loA > 0.0) ? w_ltA - w_zeroA : w_ltA, w_zeroA, nanA_, w_candA);
+        if (hasB) o_[(int64_t)cB * (BLOCK / 64) + wave] = make_uint4((med_iz && med_loB > 0.0) ? w_ltB - w_zeroB : w_ltB, w_zeroB, nanB_, w_candB);
+      }
+    }
   }
   if constexpr (STAMP) {
     if (lane == 0 && a.dbg != nullptr) {
@@ -705,6 +873,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
       d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
     }
   }
+  if constexpr (MED) f |= med_fw;
   publish_flags(f, a.flags);
 #undef PLAIDHIP_PREFETCH
 #undef PLAIDHIP_PF_ONE
@@ -790,6 +959,7 @@ struct ScatterArgs {
   int32_t med_capc;
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
   int32_t abl;               // tools/ build: 1 no LDS atomics | 2 no id loads (synthetic conflict-free ids) | 3 no score stores | 4 = 1 + 2 | 5 no walk
+                             // | 6 score stores with agent scope (sc1: the lines do not stay in L2) | 7 plain score stores
 };
 
 #ifdef PLAIDHIP_DIAG
@@ -1034,7 +1204,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       }                                                                                             \
       acc[i] = 0.0;                                                                                 \
       val = alpha * (sum * kwv[u].y) + a.beta * kwv[u].x;                                           \
-      if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);       \
+      if (PH_SC_ABL(6)) __hip_atomic_store(&a.S[(int64_t)c * a.lds + j0 + i], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* sc1 */ \
+      else if (PH_SC_ABL(7)) a.S[(int64_t)c * a.lds + j0 + i] = val;                                  \
+      else if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);  \
       /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */  \
       /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */        \
       vmin = min_f64(vmin, val);                                                                    \
@@ -1954,10 +2126,22 @@ static int pair_kernel_mode(const plaidhip_ctx* ctx) {
   return ctx->opt_dense_kernel == 1 ? 0 : (ctx->opt_dense_kernel == 2 ? 2 : 1);
 }
 
+// what the MED form of the pair kernel needs (dense X; launch_spmm_dense_fused_f64)
+struct plaidhip_pair_med {
+  const double* u;
+  double beta_kappa;
+  const double* cal;
+  double* pred;
+  unsigned long long* cand;
+  uint32_t* cnt;
+  int32_t capc;
+};
+
 static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx,
                           const int32_t* Xp, const int32_t* Xi, const double* Xx, int32_t n,
                           int stat, double alpha, const double* alpha_div, double beta, double* S, int64_t lds,
-                          uint32_t* flags, bool auto_select = false, uint32_t* spec = nullptr, uint32_t spec_gen = 0) {
+                          uint32_t* flags, bool auto_select = false, uint32_t* spec = nullptr, uint32_t spec_gen = 0,
+                          const plaidhip_pair_med* med = nullptr) {
   const plaidhip_pair_plan& pl = gs->pair;
   int32_t gmax = 0;
   for (const plaidhip_pair_slice& sl : pl.slices) gmax = sl.gs > gmax ? sl.gs : gmax;
@@ -1975,6 +2159,7 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.nslices = (int32_t)pl.slices.size();
   a.ktiles = pl.ktiles;
   a.nt_store = nt_store_mode(ctx, gs);
+  a.part_nt = ((int64_t)(pl.ktiles + 1) * 1024 * 32 > (8ll << 20)) ? 1 : 0;   // 32 workgroups' scratches per XCD against its L2
   a.slices = pl.d_slices;
   a.wave_tile_off = pl.d_wave_tile_off;
   a.meta_j = pl.d_meta_j;
@@ -1996,32 +2181,31 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   int grid = ctx->num_cu * per_cu;
   if (a.nslices > 1 && grid > pl.partial_wgs) grid = pl.partial_wgs;
   if (grid > a.npairs) grid = a.npairs;
-  if (Xp != nullptr) {   // sparse X
+  if (med != nullptr) {   // dense X, medians selected on the fly
+    a.med_u = med->u;
+    a.med_beta_kappa = med->beta_kappa;
+    a.med_cal = med->cal;
+    a.med_pred = med->pred;
+    a.med_cand = med->cand;
+    a.med_cnt = med->cnt;
+    a.med_capc = med->capc;
+    PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, true>));
+    hipLaunchKernelGGL((spmm_colpair_f64<false, 0, false, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else if (Xp != nullptr) {   // sparse X
     PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, true>));
     hipLaunchKernelGGL((spmm_colpair_f64<false, 0, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
 #ifdef PLAIDHIP_DIAG
-  else if (g_ablate == 2) {   // no index loads (wrong scores)
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL((spmm_colpair_f64<true, 2>), dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (g_ablate == 5) {   // no partial-sum round trip between slices (tools/ only, wrong scores)
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 5>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL((spmm_colpair_f64<true, 5>), dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (g_ablate == 7) {   // no per-tile metadata loads (tools/ only, wrong scores)
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 7>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL((spmm_colpair_f64<true, 7>), dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (g_ablate == 6) {   // index loads always hit L1 (tools/ only, wrong scores)
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, 6>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL((spmm_colpair_f64<true, 6>), dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
+#define PH_PAIR_ABL_ARM(N)                                                                               \
+  else if (g_ablate == N) {   /* tools/ only, wrong scores: 2 no index loads, 5 no partial-sum round trip, 6 index loads */ \
+    a.dbg = g_dbg;            /* always hit L1, 7 no tile metadata, 8 partial stores only, 9 partial loads only, 10 a   */ \
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, N>),               /* four-tile scratch */ \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));                   \
+    hipLaunchKernelGGL((spmm_colpair_f64<true, N>), dim3(grid), dim3(1024), smem, ctx->stream, a);        \
+  }
+  PH_PAIR_ABL_ARM(2) PH_PAIR_ABL_ARM(5) PH_PAIR_ABL_ARM(6) PH_PAIR_ABL_ARM(7) PH_PAIR_ABL_ARM(8) PH_PAIR_ABL_ARM(9) PH_PAIR_ABL_ARM(10) PH_PAIR_ABL_ARM(11) PH_PAIR_ABL_ARM(12) PH_PAIR_ABL_ARM(13) PH_PAIR_ABL_ARM(14) PH_PAIR_ABL_ARM(15) PH_PAIR_ABL_ARM(16)
+#undef PH_PAIR_ABL_ARM
+  else if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
     a.dbg = g_dbg;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
@@ -2157,7 +2341,7 @@ int launch_spmm_dense_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   {
     // two columns per pass
     const int mode = pair_kernel_mode(ctx);
-    const bool diag = g_ablate == 0 || g_ablate == 2 || g_ablate == 4 || g_ablate == 5 || g_ablate == 6 || g_ablate == 7;
+    const bool diag = g_ablate == 0 || g_ablate == 2 || (g_ablate >= 4 && g_ablate <= 16);
     if (diag && mode != 0 && !gs->pair.slices.empty())
       return launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags, false,
                             spec, spec_gen);
@@ -2270,6 +2454,85 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
   plaidhip_scatter_med med{pred, cal, reinterpret_cast<unsigned long long*>(base + o_cand), reinterpret_cast<uint32_t*>(base + o_cnt), kCapC};
   rc = launch_spmm_scatter_csc_f64(ctx, gs, Xp, Xi, Xx, n, stat, alpha, alpha_div, beta, S, lds, flags, false, bounded, xmax_dev,
                                    xmax_host, nnz, &med);
+  if (rc != PLAIDHIP_OK) return rc;
+  ctx->fmed.valid = true;
+  ctx->fmed.token = ++ctx->fmed_gen;
+  ctx->fmed.S = S;
+  ctx->fmed.lds = lds;
+  ctx->fmed.m = gs->m;
+  ctx->fmed.n = n;
+  ctx->fmed.nslice = nslice;
+  ctx->fmed.capc = kCapC;
+  ctx->fmed.pred = pred;
+  ctx->fmed.cal = cal;
+  ctx->fmed.cnt = med.cnt;
+  ctx->fmed.cand = med.cand;
+  ctx->fmed.status = reinterpret_cast<int32_t*>(base + o_status);
+  return PLAIDHIP_OK;
+}
+
+// ---- the DENSE crossprod that also selects the column medians of its result (round 5) -------------------------------
+// Same idea and same resume call as launch_spmm_csc_fused_f64, for the pair kernel: the workgroup of a column pair stages
+// every x[i, c] anyway, so it computes the pair's mean scores itself (alpha * sum_i x[i, c] u[i] + beta * kappa: no extra
+// pass over X) before the last gene slice, whose tile ends classify the scores they write.  Applies when the fp64 pair
+// kernel takes the input (not the u16 / fp32 stagings of rank inputs, not the MFMA backend), the result has more sets per
+// column than the register-resident median kernel takes (m > 6,144) and is large enough for the calibration to pay
+// (>= 1e9 scores, PLAIDHIP_OPT_FUSED_MEDIANS overrides); everything else runs the plain crossprod.
+//   1. crossprod (classifying form, empty bracket) + standalone medians of the first K columns -> their predicted means too;
+//   2. {offset, half width, ignore-zero rule} of the bracket (median_calibrate_kernel);
+//   3. the crossprod of ALL columns with the classifying tile ends.
+int launch_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const double* X, int64_t ldx, int32_t n, int stat,
+                                double alpha, const double* alpha_div, double beta, double* S, int64_t lds, uint32_t* flags,
+                                int x_kind) {
+  ctx->fmed.valid = false;
+  ctx->fmed.token = 0;
+  ctx->fmed.n = 0;
+  constexpr int K = 256;
+  constexpr int32_t nslice = 16;                 // wavefronts of the pair kernel's workgroup
+  const int32_t kCapC = 8192 / nslice;           // candidate slots per (column, wavefront): 8,192 per column
+  const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16;
+  const bool compact = (x_kind != PLAIDHIP_X_ANY && ctx->opt_ranks_f32 >= 1 && one_slice_16) ||
+                       (ctx->precision == PLAIDHIP_PRECISION_MIXED && one_slice_16);
+  const bool big_enough = ctx->opt_fused_medians == 1 || (int64_t)gs->m * n >= 1000000000ll;
+  const bool eligible = ctx->opt_fused_medians != 2 && big_enough && gs->m > 6144 && n >= 4 * K && flags != nullptr &&
+                        ctx->opt_dense_kernel != 3 && !compact && g_ablate == 0 && pair_kernel_mode(ctx) != 0 &&
+                        !gs->pair.slices.empty() && gs->scatter.d_u != nullptr && gs->m > 0;
+  if (!eligible) return launch_spmm_dense_f64(ctx, gs, X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags, x_kind);
+  // scratch: [pred n f64][cal 4 f64][cal0 4 f64][medK K f64][flagsK 4 u32 (+pad)][status n i32 (+pad)][cnt n nslice 4 u32][cand n nslice capc u64]
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_pred = 0, o_cal = up(o_pred + (size_t)n * 8), o_cal0 = up(o_cal + 32), o_medK = up(o_cal0 + 32),
+               o_flagsK = up(o_medK + (size_t)K * 8), o_status = up(o_flagsK + 16), o_cnt = up(o_status + (size_t)n * 4),
+               o_cand = up(o_cnt + (size_t)n * nslice * 16), total = o_cand + (size_t)n * nslice * kCapC * 8;
+  if (ctx->fmed_bytes < total) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->fmed_buf) PH_HIP(hipFree(ctx->fmed_buf));
+    ctx->fmed_buf = nullptr;
+    ctx->fmed_bytes = 0;
+    if (hipMalloc(&ctx->fmed_buf, total) != hipSuccess) {   // no room for the candidate lists: the plain route
+      (void)hipGetLastError();
+      return launch_spmm_dense_f64(ctx, gs, X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags, x_kind);
+    }
+    ctx->fmed_bytes = total;
+  }
+  char* base = static_cast<char*>(ctx->fmed_buf);
+  double* pred = reinterpret_cast<double*>(base + o_pred);
+  double* cal = reinterpret_cast<double*>(base + o_cal);
+  const double* cal0 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ctx->d_sel) + 96);   // the empty bracket (plaidhip_create)
+  double* medK = reinterpret_cast<double*>(base + o_medK);
+  uint32_t* flagsK = reinterpret_cast<uint32_t*>(base + o_flagsK);
+  const int si = stat == PLAIDHIP_STAT_MEAN ? 0 : 1;
+  const plaidhip_scatter_plan& sp = gs->scatter;
+  plaidhip_pair_med med{sp.d_u + (size_t)si * gs->g, beta * sp.kappa[si], cal0, pred,
+                        reinterpret_cast<unsigned long long*>(base + o_cand), reinterpret_cast<uint32_t*>(base + o_cnt), kCapC};
+  PH_HIP(hipMemsetAsync(flagsK, 0, 16, ctx->stream));
+  int rc = launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, K, stat, alpha, alpha_div, beta, S, lds, flagsK, false, nullptr, 0, &med);
+  if (rc != PLAIDHIP_OK) return rc;
+  rc = launch_col_medians(ctx, S, lds, gs->m, K, -1, flagsK, medK);
+  if (rc != PLAIDHIP_OK) return rc;
+  rc = launch_median_calibrate(ctx, medK, pred, K, flagsK, cal);
+  if (rc != PLAIDHIP_OK) return rc;
+  med.cal = cal;
+  rc = launch_colpair(ctx, gs, X, ldx, nullptr, nullptr, nullptr, n, stat, alpha, alpha_div, beta, S, lds, flags, false, nullptr, 0, &med);
   if (rc != PLAIDHIP_OK) return rc;
   ctx->fmed.valid = true;
   ctx->fmed.token = ++ctx->fmed_gen;

@@ -491,8 +491,11 @@ int shard_worker(plaidhip_ctx* ctx, const Call& c, int ndev, int k, Shared& sh) 
       return launch_spmm_csc_f64(ctx, gs, dXp.as<int32_t>(), dXi.as<int32_t>(), vals, nloc, nnz_choice, stat, a, nullptr, b,
                                  dS.as<double>(), m, d_flags, /*bounded=*/c.method == 2, nullptr, gmax);
     }
-    return launch_spmm_dense_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags,
-                                 (c.method == 1 || (c.method == 2 && c.alpha == 0.0)) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY);
+    const int x_kind = (c.method == 1 || (c.method == 2 && c.alpha == 0.0)) ? PLAIDHIP_X_RANKS : PLAIDHIP_X_ANY;
+    // (normalised results on the fp64 pair kernel: the crossprod also classifies its scores for the medians below)
+    if (c.method == 2 || (c.method == 0 && c.normalize))
+      return launch_spmm_dense_fused_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags, x_kind);
+    return launch_spmm_dense_f64(ctx, gs, vals, ldg, nloc, stat, a, nullptr, b, dS.as<double>(), m, d_flags, x_kind);
   });
 
   // ---- normalize_medians (R/plaid.R:554-575): two more scalars --------------------------------------------------------

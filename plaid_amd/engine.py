@@ -127,6 +127,15 @@ class Context:
         check(self.lib.plaidhip_dev_spmm_dense_f64(self.handle, gs.handle, X, ldx, n, STAT[stat], alpha,
                                                    alpha_div, beta, S, lds, flags))
 
+    def dev_spmm_dense_fused(self, gs: Geneset, X: int, ldx: int, n: int, S: int, lds: int, stat="mean",
+                             alpha=1.0, beta=0.0, flags: int | None = None, alpha_div: int | None = None) -> int:
+        """dev_spmm_dense that also classifies the scores for normalize_medians while it writes them (the fp64 pair
+        kernel, more than 6,144 sets per column, >= 1e9 scores or fused_medians = on); dev_col_medians_resume then
+        finishes the medians without a second pass over S.  Returns the launch's token (0: the plain route ran)"""
+        check(self.lib.plaidhip_dev_spmm_dense_fused_f64(self.handle, gs.handle, X, ldx, n, STAT[stat], alpha,
+                                                         alpha_div, beta, S, lds, flags))
+        return self.dev_fused_medians_token()
+
     def dev_spmm_ranks(self, gs: Geneset, R: int, ldr: int, n: int, S: int, lds: int, stat="mean",
                        alpha=1.0, beta=0.0, flags: int | None = None, alpha_div: int | None = None):
         """the crossprod of a RANK matrix (what dev_colranks_dense wrote with power 1, unsigned): u16 staging, integer

@@ -144,15 +144,23 @@ class HipPhaseEngine:
     def new_flags(self):
         return self.torch.zeros(4, dtype=self.torch.int32, device=self.device)
 
-    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False):
-        """`ranks`: X is what colranks() wrote with power 1 (unsigned): the exact u16-staged crossprod takes it"""
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False, normalize=False):
+        """`ranks`: X is what colranks() wrote with power 1 (unsigned): the exact u16-staged crossprod takes it.
+        `normalize`: the caller will call medians(S, flags) on the result: the crossprod may classify its scores for them"""
         self._same_stream()
         t = self.torch
         n = X.shape[0]
         S = t.empty((n, self.gs.m), dtype=t.float64, device=self.device)
+        self._fused = None
+        fl = flags.data_ptr() if flags is not None else None
+        div = alpha_div.data_ptr() if alpha_div is not None else None
+        if normalize and not ranks and fl is not None and n > 0:
+            import weakref
+            token = self.ctx.dev_spmm_dense_fused(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta, fl, div)
+            self._fused = (weakref.ref(S), token) if token else None
+            return S
         call = self.ctx.dev_spmm_ranks if ranks else self.ctx.dev_spmm_dense
-        call(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta,
-             flags.data_ptr() if flags is not None else None, alpha_div.data_ptr() if alpha_div is not None else None)
+        call(self.gs, X.data_ptr(), X.shape[1], n, S.data_ptr(), self.gs.m, stat, alpha, beta, fl, div)
         return S
 
     def colranks(self, X, ties="average", signed=False, power=1.0):
@@ -228,8 +236,7 @@ def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=
     import torch.distributed as dist
     world, _ = _world(group)
     flags = engine.new_flags()
-    S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags, ranks=True) if x_is_ranks else \
-        engine.spmm(X_local, stat, alpha, beta, alpha_div, flags)
+    S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags, ranks=x_is_ranks, normalize=normalize)
     if normalize:
         if world > 1:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)       # min(x) == 0 over all samples

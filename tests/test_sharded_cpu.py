@@ -29,7 +29,7 @@ class OraclePhaseEngine:
     def new_flags(self):
         return torch.zeros(4, dtype=torch.int32)
 
-    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False):
+    def spmm(self, X, stat="mean", alpha=1.0, beta=0.0, alpha_div=None, flags=None, ranks=False, normalize=False):
         Xn = X.numpy().T[:self.g]                               # g x n_local (a padded leading dimension is cut off)
         raw = np.asarray(self.G.T @ Xn)
         w = 1.0 / (1e-8 + self.k) if stat == "mean" else np.ones_like(self.k)

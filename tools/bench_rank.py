@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Column-rank kernels alone (GPU): bucket ranker vs sorting network at config-4 shape, tied and tie-free data, with
 and without the fused power; with the tools/ build (PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so) also the share of
 every phase of the bucket kernel (in-kernel stamps of wave 0).   python tools/bench_rank.py [--genes 20000] [--cols 4096]"""

@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """shift_columns alone (GPU): (x - med[col]) + mean at the C2 and C3 column lengths.   python tools/bench_shift.py"""
 import os
 import sys

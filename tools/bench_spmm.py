@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Micro-benchmark of single kernels (for rocprofv3 --pmc passes and A/B work):
    python tools/bench_spmm.py [--kernel spmm|medians|ranks] [--genes G --samples N --sets M] [--iters K]"""
 import argparse
@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--real-sets", action="store_true", help="a collection with the shape of the reference's (synth.geneset_csc_real: sizes 3..5,000 + an all-genes set, hub genes)")
     ap.add_argument("--unsorted", action="store_true", help="gene sets in random order (not by decreasing size)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..7 (wrong results by design; needs PLAIDHIP_LIB=<the make diag library>)")
-    ap.add_argument("--fused", action="store_true", help="c3: medians selected inside the crossprod launch (dev_spmm_csc_fused + dev_col_medians_resume)")
+    ap.add_argument("--fused", action="store_true", help="c3 / c4: medians selected inside the crossprod launch (dev_spmm_csc_fused / dev_spmm_dense_fused + dev_col_medians_resume)")
     ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the scatter kernel (diag library)")
     ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
@@ -98,11 +98,14 @@ def main():
                 elif a.kernel == "c3":
                     ctx.dev_spmm_csc_ranks(gs, dXp.data_ptr(), dXi.data_ptr(), dRx.data_ptr(), n, S.data_ptr(), m,
                                            red.data_ptr() + 16, "mean", 1.0, -0.5, flags.data_ptr(), nnz=len(Xx))
+                elif a.fused:
+                    ctx.dev_spmm_dense_fused(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
+                                             red.data_ptr() + 16)
                 else:
                     ctx.dev_spmm_dense(gs, R.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, -0.5, flags.data_ptr(),
                                        red.data_ptr() + 16)
                 e2 = ev()
-                if a.kernel == "c3" and a.fused:
+                if a.fused:
                     ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
                 else:
                     ctx.dev_col_medians(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr())
@@ -237,7 +240,7 @@ def main():
             print(f"  stamps (mean over {len(d)} wavefronts, last launch; 100 MHz ticks): load+keys+minmax {d[:,0].mean():.0f} "
                   f"({100*d[:,0].mean()/tot:.0f}%)  passes {d[:,1].mean():.0f} ({100*d[:,1].mean()/tot:.0f}%)  fetch+upper {d[:,2].mean():.0f} "
                   f"({100*d[:,2].mean()/tot:.0f}%)  passes per column (last launch) {d[:,3].sum() / n:.2f}")
-    if a.ablate == 4 or (a.ablate in (2, 5, 6, 7) and True):
+    if a.ablate == 4 or a.ablate in (2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
         waves = info["waves"]
         nwg = min(n, 256)
         d = dbg.cpu().numpy()[: nwg * waves * 4].reshape(nwg, waves, 4).astype(float)

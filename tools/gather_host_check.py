@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """sharded.gather_scores(to="host") with several ranks on ONE GPU (gloo for the handshakes; the data path is device ->
 pinned slab -> this rank's /dev/shm file, no collective): rate and content.   On the GPU box:
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 tools/gather_host_check.py 60000"""

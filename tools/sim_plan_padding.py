@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Host-side pricing of pair-plan variants BEFORE a kernel is written (CPU only, numpy): slot efficiency (real memberships /
 padded gather slots) and the plan's own cost model (steps + 0.2 per deliberate 2-way conflict, geneset.cpp choose_steps) for
    python tools/sim_plan_padding.py <sets> <gene slices> <step granularity 8|4|2> [pool]

@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Randomised soak of the medians selected inside the sparse crossprod launch (tests/test_gpu_fused_medians.py's harness on
 random shapes): gene-set collections of both kinds, 4,200 ... 9,000 cells of varying density, counts or rank weights, mean or
 sum, random subsets of empty / 30x denser / NaN-holding / outlier / duplicated cells.  Every case asserts that the fused

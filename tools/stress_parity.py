@@ -1,4 +1,4 @@
-#!/usr/bin/env python
+#!/usr/bin/python3
 """Randomised parity stress (GPU): many random shapes / densities / value patterns through the C ABI against the
 oracle.  `run_case` is collected by pytest (tests/test_gpu_parity.py::test_stress_parity_random_case, 200 seeds);
 standalone for longer runs through gpurun:  python tools/stress_parity.py --cases 1500"""
