@@ -948,8 +948,8 @@ def run_c4(a, env):
             "ms": round(t_mfma, 3), "spmm_ms_same_launch": round(spmm_ms, 3), "slowdown_vs_spmm": round(t_mfma / spmm_ms, 2),
             "flop": flop, "scores_per_s": round(float(n) * m / (t_mfma * 1e-3), 1),
             "note": "dense 0/1 G (bf16, 2 GB) x bf16x3 split of the rank weights, fp32 accumulate: 3 x 2 g n m flop against "
-                    "2 z n for the SpMM (z/(g m) = 0.7 % dense); the time includes the split of every 8,192-sample panel into "
-                    "three bf16 planes; opt-in backend, never the default"}
+                    "2 z n for the SpMM (z/(g m) = 0.7 % dense); round 5: 256 x 256 tiles, 512 threads, two LDS stages; the time "
+                    "includes the split of every 8,192-sample panel into three bf16 planes; opt-in backend, never the default"}
     except Exception as exc:  # pragma: no cover
         out["mfma_backend"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
     finally:

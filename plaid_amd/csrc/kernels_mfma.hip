@@ -9,11 +9,16 @@
 //   * W (fp64) is split into three bf16 terms, W = hi + mid + lo (24 significant bits, ~6e-8 relative: inside the
 //     1e-5 bar); three MFMA products accumulate into the same fp32 tile.  Sums of <= 500 products of magnitude <= 1
 //     keep ~1e-7 relative in fp32.
-//   * tile: 128 samples x 128 sets per 256-thread workgroup, K step 64; four wavefronts in 2 x 2, each 64 x 64 =
-//     2 x 2 MFMA tiles of v_mfma_f32_32x32x16_bf16.  Samples are the MFMA rows and sets the columns, so that a
-//     lane of the accumulator tile is a set: 32 lanes store 32 neighbouring rows of S (column-major sets x samples).
-//   * operands staged through LDS with rows padded to 144 bytes (the four 16-lane groups of ds_read_b128 then hit
-//     16 distinct 16-byte slots: conflict-free), next K step prefetched into registers during the MFMAs.
+//   * tile (round 5): 256 samples x 256 sets per 512-thread workgroup, one per CU; eight wavefronts in 2 x 4, each
+//     128 samples x 64 sets = 4 x 2 MFMA tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers).  Samples are
+//     the MFMA rows and sets the columns, so that a lane of the accumulator tile is a set: 32 lanes store 32
+//     neighbouring rows of S (column-major sets x samples).  The three planes share the G fragments: per 16 genes a
+//     wavefront reads 2 G + 12 W fragments for 24 MFMAs.
+//   * K step 32 genes, TWO LDS stages (2 x 4 tiles x 256 rows x 80 bytes = the whole 160 KB): rows padded from 64 to
+//     80 bytes, so that the four 16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots (80 = 5 x 16, 5 is
+//     odd: conflict-free); step k + 1 is written to the other stage and step k + 2 requested from memory before the
+//     MFMAs of step k issue: one barrier per step.  (Rounds 2-4: 128 x 128 tiles, 256 threads, one stage, two
+//     barriers per step: 0.10 of the bf16 peak.)
 #include <mutex>
 
 #include "common.h"
@@ -23,9 +28,11 @@ namespace plaidhip {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMfmaTile = 128;   // samples and sets per workgroup tile
-constexpr int kMfmaBK = 64;      // K (genes) per step
-constexpr int kMfmaRowB = 144;   // bytes per LDS row: 64 bf16 + 16 bytes of padding
+constexpr int kMfmaTile = 256;   // samples and sets per workgroup tile
+constexpr int kMfmaBK = 32;      // K (genes) per step
+constexpr int kMfmaRowB = 80;    // bytes per LDS row: 32 bf16 + 16 bytes of padding
+constexpr int kMfmaGkPad = 64;   // the gene dimension of the bf16 operands is padded to a multiple of this
+constexpr int kMfmaStageB = 4 * kMfmaTile * kMfmaRowB;   // W hi / mid / lo, G: 81,920 bytes per stage
 
 // X (fp64, column-major genes x samples: a sample's genes are contiguous) -> three bf16 matrices [rows_pad][gk]
 __global__ void __launch_bounds__(256)
@@ -84,58 +91,74 @@ __device__ __forceinline__ void publish_flags_mfma(uint32_t f, uint32_t* flags) 
   }
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512)
 crossprod_mfma_bf16x3_kernel(MfmaArgs a) {
-  __shared__ __align__(16) unsigned char lds[4 * kMfmaTile * kMfmaRowB];   // W hi / mid / lo, G : 72 KB
+  extern __shared__ __align__(16) unsigned char lds[];   // two stages of {W hi, W mid, W lo, G} tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;    // 2 x 4 wavefronts: 128 samples x 64 sets each
   const int n0 = blockIdx.x * kMfmaTile;   // first set of the tile
   const int m0 = blockIdx.y * kMfmaTile;   // first sample of the tile
   const int64_t plane = (int64_t)a.rows_pad * a.gk;
-  // staging: 4 tiles x 128 rows x 8 pieces of 16 bytes = 4096 pieces, 16 per thread; piece q of a tile: row q / 8
-  const uint4* src[4];
-  uint32_t dst[4];
-  {
-    const int row = tid >> 3, c8 = tid & 7;   // piece q = tid + 256 i -> row + 32 i
-    for (int t = 0; t < 3; ++t)
-      src[t] = reinterpret_cast<const uint4*>(a.W3 + t * plane + (int64_t)(m0 + row) * a.gk) + c8;
-    src[3] = reinterpret_cast<const uint4*>(a.Gd + (int64_t)(n0 + row) * a.gk) + c8;
-    for (int t = 0; t < 4; ++t) dst[t] = (uint32_t)(t * kMfmaTile * kMfmaRowB + row * kMfmaRowB + c8 * 16);
+  // staging: 4 tiles x 256 rows x 4 pieces of 16 bytes = 4,096 pieces per step, 8 per thread: tile t = 0 .. 3, piece
+  // q = tid + 512 i (i = 0, 1): row q / 4, 16-byte column q % 4.  (Scalars, not arrays: under this kernel's register
+  // pressure hipcc leaves a private array in scratch memory -- the first build staged every step through it.)
+  const int srow = tid >> 2, sc4 = tid & 3;   // i adds 128 rows
+  const uint4* src0 = reinterpret_cast<const uint4*>(a.W3 + (int64_t)(m0 + srow) * a.gk) + sc4;
+  const uint4* src1 = reinterpret_cast<const uint4*>(a.W3 + plane + (int64_t)(m0 + srow) * a.gk) + sc4;
+  const uint4* src2 = reinterpret_cast<const uint4*>(a.W3 + 2 * plane + (int64_t)(m0 + srow) * a.gk) + sc4;
+  const uint4* src3 = reinterpret_cast<const uint4*>(a.Gd + (int64_t)(n0 + srow) * a.gk) + sc4;
+  const uint32_t dst0 = (uint32_t)(srow * kMfmaRowB + sc4 * 16);
+  const int64_t rstep = (int64_t)128 * a.gk * 2 / 16;   // 128 rows further, in uint4 units
+  uint4 pf00, pf01, pf10, pf11, pf20, pf21, pf30, pf31;
+#define PH_MFMA_PREFETCH(kstep)                                        \
+  {                                                                    \
+    const int64_t ko_ = (int64_t)(kstep) * (kMfmaBK * 2 / 16);         \
+    pf00 = src0[ko_]; pf01 = src0[rstep + ko_];                        \
+    pf10 = src1[ko_]; pf11 = src1[rstep + ko_];                        \
+    pf20 = src2[ko_]; pf21 = src2[rstep + ko_];                        \
+    pf30 = src3[ko_]; pf31 = src3[rstep + ko_];                        \
   }
-  const int64_t rstep = (int64_t)32 * a.gk * 2 / 16;   // 32 rows further, in uint4 units
-  uint4 pf[4][4];
-#define PH_MFMA_PREFETCH(kstep)                                                       \
-  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) pf[t][i] = src[t][(int64_t)i * rstep + (int64_t)(kstep) * (kMfmaBK * 2 / 16)];
-  f32x16 acc[2][2];
+#define PH_MFMA_ST1(stage, t, i, v) \
+  *reinterpret_cast<uint4*>(lds + (stage) * kMfmaStageB + (t) * kMfmaTile * kMfmaRowB + dst0 + (i) * 128 * kMfmaRowB) = v;
+#define PH_MFMA_STAGE(stage)                                                                      \
+  PH_MFMA_ST1(stage, 0, 0, pf00) PH_MFMA_ST1(stage, 0, 1, pf01) PH_MFMA_ST1(stage, 1, 0, pf10) PH_MFMA_ST1(stage, 1, 1, pf11) \
+  PH_MFMA_ST1(stage, 2, 0, pf20) PH_MFMA_ST1(stage, 2, 1, pf21) PH_MFMA_ST1(stage, 3, 0, pf30) PH_MFMA_ST1(stage, 3, 1, pf31)
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int nk = a.gk / kMfmaBK;
   PH_MFMA_PREFETCH(0)
-  const uint32_t arow = (uint32_t)((wm * 64 + (lane & 31)) * kMfmaRowB + (lane >> 5) * 16);
+  PH_MFMA_STAGE(0)
+  if (nk > 1) { PH_MFMA_PREFETCH(1) }
+  __syncthreads();
+  const uint32_t arow = (uint32_t)((wm * 128 + (lane & 31)) * kMfmaRowB + (lane >> 5) * 16);
   const uint32_t brow = (uint32_t)(3 * kMfmaTile * kMfmaRowB + (wn * 64 + (lane & 31)) * kMfmaRowB + (lane >> 5) * 16);
   for (int ks = 0; ks < nk; ++ks) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(lds + dst[t] + i * 32 * kMfmaRowB) = pf[t][i];
-    __syncthreads();
-    if (ks + 1 < nk) { PH_MFMA_PREFETCH(ks + 1) }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    const int cur = ks & 1;
+    // step ks + 1 (in registers since the step before) goes to the other stage -- its readers of step ks - 1 are behind the
+    // barrier that ended that step -- and step ks + 2 is requested; both before the MFMAs of this step issue
+    if (ks + 1 < nk) {
+      PH_MFMA_STAGE(cur ^ 1)
+      if (ks + 2 < nk) { PH_MFMA_PREFETCH(ks + 2) }
+    }
+    const unsigned char* st = lds + cur * kMfmaStageB;
+    // (rolled on purpose: unrolled, hipcc requests all 28 fragments of the step up front -- 112 registers next to the 128
+    // accumulators -- and moves the prefetch registers to scratch memory)
+#pragma unroll 1
+    for (int kk = 0; kk < kMfmaBK / 16; ++kk) {
       bf16x8 bfr[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(lds + brow + j * 32 * kMfmaRowB + kk * 32);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(st + brow + j * 32 * kMfmaRowB + kk * 32);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8 afr = *reinterpret_cast<const bf16x8*>(lds + t * kMfmaTile * kMfmaRowB + arow + i * 32 * kMfmaRowB + kk * 32);
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 afr = *reinterpret_cast<const bf16x8*>(st + t * kMfmaTile * kMfmaRowB + arow + i * 32 * kMfmaRowB + kk * 32);
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[j], acc[i][j], 0, 0, 0);
         }
@@ -144,6 +167,8 @@ crossprod_mfma_bf16x3_kernel(MfmaArgs a) {
     __syncthreads();
   }
 #undef PH_MFMA_PREFETCH
+#undef PH_MFMA_STAGE
+#undef PH_MFMA_ST1
   // epilogue: alpha * (sum * w) + beta * (k * w), the same as the SpMM kernels'
   const double alpha = (a.alpha_div != nullptr) ? a.alpha / *a.alpha_div : a.alpha;
   uint32_t f = 0;
@@ -154,10 +179,10 @@ crossprod_mfma_bf16x3_kernel(MfmaArgs a) {
     const double kj = sok ? a.k[set] : 0.0;
     const double wj = sok ? (a.stat == PLAIDHIP_STAT_MEAN ? a.w[set] : 1.0) : 0.0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int sample = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int sample = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (sok && sample < a.ncols) {
           const double v = alpha * ((double)acc[i][j][r] * wj) + a.beta * (kj * wj);
           a.S[(int64_t)sample * a.lds + set] = v;
@@ -177,7 +202,7 @@ static int ensure_dense_g(plaidhip_ctx* ctx, plaidhip_geneset* gs) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   if (gs->d_dense_g != nullptr) return PLAIDHIP_OK;
-  const int32_t gk = (gs->g + kMfmaBK - 1) / kMfmaBK * kMfmaBK;
+  const int32_t gk = (gs->g + kMfmaGkPad - 1) / kMfmaGkPad * kMfmaGkPad;
   const int32_t mpad = (gs->m + kMfmaTile - 1) / kMfmaTile * kMfmaTile;
   const size_t bytes = (size_t)mpad * gk * 2;
   struct Tmp {   // freed on every exit path
@@ -236,7 +261,8 @@ int launch_spmm_mfma_f64(plaidhip_ctx* ctx, plaidhip_geneset* gs, const double* 
     a.lds = lds;
     a.flags = flags;
     const int mt = (gs->m + kMfmaTile - 1) / kMfmaTile;
-    hipLaunchKernelGGL(crossprod_mfma_bf16x3_kernel, dim3(mt, rows_pad / kMfmaTile), dim3(256), 0, ctx->stream, a);
+    PH_FULL_LDS(ctx, (&crossprod_mfma_bf16x3_kernel));
+    hipLaunchKernelGGL(crossprod_mfma_bf16x3_kernel, dim3(mt, rows_pad / kMfmaTile), dim3(512), 2 * kMfmaStageB, ctx->stream, a);
   }
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;

@@ -400,9 +400,6 @@ struct SpmmPairArgs {
   const double* Xx;
   int32_t n, npairs, nslices, ktiles;
   int32_t nt_store;  // see SpmmArgs
-  int32_t part_nt;   // partial sums of the slice before are read with non-temporal loads: set when the workgroups' scratches
-                     // (32 per XCD) outgrow the 4 MiB L2 -- read once and dead, the lines then do not displace the index lists
-                     // (50,000 sets: -4 % kernel time; 5,000 sets, scratch L2-resident: +3 %, so not there)
   const plaidhip_pair_slice_dev* slices;
   const int32_t* wave_tile_off;
   const int32_t* meta_j;
@@ -451,7 +448,9 @@ __device__ __forceinline__ f64x2 lds_pair_at(uint32_t byte_off) {
 // below the bracket / exact zeros / NaN per (column, wavefront) and the scores inside the bracket to a candidate list --
 // so that the medians of a 50,000-set result need no second pass over the scores (launch_spmm_dense_fused_f64).  The
 // bracket sits around the column's MEAN score, which the workgroup computes from the X it stages: sum_i x[i, c] u[i].
-template <bool STAMP, int ABL = 0, bool CSC_X = false, bool MED = false>
+// PNT: the partial sums of the slice before are read with non-temporal loads (a compile-time form: hipcc merges the two
+// arms of a run-time choice into ONE plain load).
+template <bool STAMP, int ABL = 0, bool CSC_X = false, bool MED = false, bool PNT = false>
 __global__ void __launch_bounds__(1024)
 spmm_colpair_f64(SpmmPairArgs a) {
   constexpr int BLOCK = 1024;
@@ -480,7 +479,6 @@ spmm_colpair_f64(SpmmPairArgs a) {
   const int tk_begin = ((cptr_i32)a.wave_tile_off)[wave];
   const int ns = a.nslices;
   const bool is_mean = a.stat == PLAIDHIP_STAT_MEAN;
-  const bool part_nt = a.part_nt != 0;
   f64x2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;   // next slice: p0..p4 column A, p5..p9 column B
   p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = f64x2{0.0, 0.0};
 
@@ -758,7 +756,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
       if (PH_PAIR_PLD_SC1) {                                                                   \
         old.x = __hip_atomic_load(reinterpret_cast<const double*>(src_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
         old.y = __hip_atomic_load(reinterpret_cast<const double*>(src_) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
-      } else old = (PH_PAIR_PLD_NT || part_nt) ? __builtin_nontemporal_load(src_) : *src_;     \
+      } else old = (PH_PAIR_PLD_NT || PNT) ? __builtin_nontemporal_load(src_) : *src_;     \
     }                                                                                          \
     a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = 0.0;                                               \
   }
@@ -785,7 +783,7 @@ spmm_colpair_f64(SpmmPairArgs a) {
         f64x2 old = f64x2{0.0, 0.0};
         if (!first && PH_PAIR_PLOAD) {
           const f64x2* src_ = reinterpret_cast<const f64x2*>(part + (int64_t)PH_PAIR_PSLOT(k) * 1024 + ioff);
-          old = (PH_PAIR_PLD_NT || part_nt) ? __builtin_nontemporal_load(src_) : *src_;
+          old = (PH_PAIR_PLD_NT || PNT) ? __builtin_nontemporal_load(src_) : *src_;
         }
         f64x2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
 
@@ -2159,7 +2157,10 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.nslices = (int32_t)pl.slices.size();
   a.ktiles = pl.ktiles;
   a.nt_store = nt_store_mode(ctx, gs);
-  a.part_nt = ((int64_t)(pl.ktiles + 1) * 1024 * 32 > (8ll << 20)) ? 1 : 0;   // 32 workgroups' scratches per XCD against its L2
+  // the partial sums of the slice before are read with non-temporal loads when the workgroups' scratches (32 per XCD)
+  // outgrow the 4 MiB L2 -- read once and dead, the lines then do not displace the index lists (50,000 sets: -4 % kernel
+  // time; 5,000 sets, scratch L2-resident: +3 %, so not there)
+  const bool part_nt = a.nslices > 1 && (int64_t)(pl.ktiles + 1) * 1024 * 32 > (8ll << 20);
   a.slices = pl.d_slices;
   a.wave_tile_off = pl.d_wave_tile_off;
   a.meta_j = pl.d_meta_j;
@@ -2189,8 +2190,13 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     a.med_cand = med->cand;
     a.med_cnt = med->cnt;
     a.med_capc = med->capc;
-    PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, true>));
-    hipLaunchKernelGGL((spmm_colpair_f64<false, 0, false, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+    if (part_nt) {
+      PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, true, true>));
+      hipLaunchKernelGGL((spmm_colpair_f64<false, 0, false, true, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+    } else {
+      PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, true>));
+      hipLaunchKernelGGL((spmm_colpair_f64<false, 0, false, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+    }
   } else if (Xp != nullptr) {   // sparse X
     PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, true>));
     hipLaunchKernelGGL((spmm_colpair_f64<false, 0, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
@@ -2212,7 +2218,10 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     hipLaunchKernelGGL(spmm_colpair_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
 #endif
-  else {
+  else if (part_nt) {
+    PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, false, true>));
+    hipLaunchKernelGGL((spmm_colpair_f64<false, 0, false, false, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
+  } else {
     hipLaunchKernelGGL(spmm_colpair_f64<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
   PH_HIP(hipGetLastError());

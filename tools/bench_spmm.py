@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic SpMM variant 1..7 (wrong results by design; needs PLAIDHIP_LIB=<the make diag library>)")
     ap.add_argument("--fused", action="store_true", help="c3 / c4: medians selected inside the crossprod launch (dev_spmm_csc_fused / dev_spmm_dense_fused + dev_col_medians_resume)")
     ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the scatter kernel (diag library)")
-    ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair"])
+    ap.add_argument("--dense-kernel", default="auto", choices=["auto", "single", "pair", "mfma"])
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "scatter", "gather"])
     ap.add_argument("--nt-store", default="auto", choices=["auto", "off", "on"], help="non-temporal stores of the scores")
     ap.add_argument("--scatter-fixed", default="on", choices=["on", "off"], help="c3: u64 fixed-point accumulators in the scatter kernel")

@@ -1,6 +1,6 @@
 #!/bin/bash
-# One-shot evidence run for profiles/ (round 4 layout).  Run through gpurun:
-#     gpurun --timeout 2400 -- 'bash tools/profile_round.sh gpurun_out/r04x'
+# One-shot evidence run for profiles/ (round 4 layout, round 5 additions).  Run through gpurun:
+#     gpurun --timeout 2400 -- 'bash tools/profile_round.sh gpurun_out/r05x'
 #  * the bench line (all blocks);
 #  * rocprofv3 --kernel-trace --stats of `python3 bench.py --config c2` (the headline alone: no pre-heat, no mixed-precision
 #    leg) and of `--profile --config c3 | c4 | ref` (ONLY that block, no C2 headline in the process), so that every tracked
@@ -14,7 +14,7 @@
 out=${1:-gpurun_out/prof}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
-python3 bench.py > $out/bench.json 2> $out/bench.err
+BENCH_DETAIL=$PWD/$out/bench_detail.json python3 bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -- python3 bench.py --config c2 --preheat-steps 0 --cpu-sample 0 --no-mixed > $out/stats_c2.log 2>&1
 for cfg in c3 c4 ref; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$cfg -- python3 bench.py --profile --config $cfg --cpu-sample 0 --no-mixed > $out/stats_$cfg.log 2>&1
@@ -33,6 +33,7 @@ run_pmc c3 --kernel c3 --samples 8192 --sets 50000 --iters 3
 run_pmc c3fused --kernel c3 --samples 8192 --sets 50000 --iters 3 --fused
 run_pmc c3f64 --kernel c3 --samples 8192 --sets 50000 --iters 3 --scatter-fixed off --scatter-order column
 run_pmc c4 --kernel c4 --samples 4096 --sets 50000 --iters 3
+run_pmc c4fused --kernel c4 --samples 4096 --sets 50000 --iters 3 --fused
 run_pmc sing --kernel sing --samples 4096 --sets 50000 --iters 2
 run_pmc c2step --kernel step --iters 3
 python3 tools/bench_spmm.py --kernel c3 --samples 4096 --sets 50000 --iters 3 > $out/c3_4096.log 2>&1
@@ -48,6 +49,8 @@ python3 tools/bench_spmm.py --kernel step --iters 10 2>&1 | grep "^step" > $out/
 python3 tools/bench_weighted.py > $out/weighted.log 2>&1
 python3 tools/bench_rank_long.py > $out/rank_long.log 2>&1
 python3 tools/bench_sparse_sing.py > $out/sparse_sing.log 2>&1
+for ab in 0 5 8 9 10 13; do echo "ablate $ab (4096 x 50000 sets)"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --samples 4096 --sets 50000 --iters 8 --ablate $ab 2>&1 | grep -E "^spmm" | tail -1; done > $out/pair_partial_ablations_c4.log 2>&1
+for f in "" "--fused"; do python3 tools/bench_spmm.py --kernel c4 --samples 8192 --sets 50000 --iters 4 $f 2>&1 | grep "^c4" | tail -1; done > $out/c4_8192_fused.log 2>&1
 for ab in 0 2 6 7 5; do PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --iters 10 --ablate $ab 2>&1 | grep -E "^spmm|algorithmic" | tail -2; done > $out/pair_ablations.log 2>&1
 for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 3 --ablate $ab 2>&1 | grep -E "^c3|stamps" | tail -2; done > $out/scatter_ablations.log 2>&1
 [ -x tools/ubench/inexact_flag ] && ./tools/ubench/inexact_flag > $out/ubench_inexact_flag.log 2>&1
@@ -56,7 +59,7 @@ for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
-for tag in ("c2", "c3", "c3fused", "c3f64", "c4", "sing", "c2step"):
+for tag in ("c2", "c3", "c3fused", "c3f64", "c4", "c4fused", "sing", "c2step"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + f"/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -74,4 +77,4 @@ for cfg in ("c2", "c3", "c4", "ref"):
         os.replace(f, out + f"/bench_{cfg}_kernel_stats.csv")
 print(open(out + "/pmc_c2_summary.txt").read()[:1500])
 PY
-tail -c 600 $out/bench.json; tail -1 $out/c3_4096.log; tail -1 $out/c4_2048.log; tail -3 $out/sing_4096_50k.log
+tail -c 2700 $out/bench.json; tail -1 $out/c3_4096.log; tail -1 $out/c4_2048.log; tail -3 $out/sing_4096_50k.log
