@@ -19,7 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dense", action="store_true",
+                    help="the DENSE route (round 5: plaidhip_dev_spmm_dense_fused_f64, pair kernel): random gene counts incl. odd ones "
+                         "and one / two / three gene slices, leading dimensions, value kinds, odd columns")
     a = ap.parse_args()
+    if a.dense:
+        return main_dense(a)
     import torch
     import plaid_amd
     from plaid_amd import synth as sy
@@ -101,6 +106,89 @@ def main():
         del S1, S2
         torch.cuda.empty_cache()
     print(f"{a.cases} cases, {bad} failures, {time.time() - t0:.1f} s")
+    ctx.close()
+    return 1 if bad else 0
+
+
+def main_dense(a):
+    import torch
+    import plaid_amd
+    from plaid_amd import synth as sy
+    from test_gpu_fused_medians_dense import _run
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = plaid_amd.Context(0, stream.cuda_stream)
+    ctx.set_option("fused_medians", "on")
+    bad = 0
+    t0 = time.time()
+    for case in range(a.cases):
+        rng = np.random.default_rng(a.seed * 100019 + case)
+        real = bool(rng.integers(0, 2))
+        g = int(rng.choice([3001, 8000, 10224, 10225, 12010, 15001, 17713, 20000, 20448, 20449, 25000, 33538]))
+        m = int(rng.choice([6200, 9000, 17409, 24000, 34817, 50000]))
+        n = int(rng.integers(1100, 2400))
+        ld = g + int(rng.choice([0, 0, 1, 2, 7]))
+        kind = str(rng.choice(["normal", "rounded", "counts", "ssgsea", "centred"]))
+        stat = "mean" if kind == "ssgsea" else str(rng.choice(["mean", "sum"]))
+        Gp, Gi = (sy.geneset_csc_real(g, m, seed=int(rng.integers(1, 1 << 30))) if real else
+                  sy.geneset_csc(g, m, seed=int(rng.integers(1, 1 << 30)), kmax=int(rng.choice([60, 500]))))
+        gs = ctx.geneset(g, Gp, Gi)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(rng.integers(1, 1 << 30)))
+        with torch.cuda.stream(stream):
+            X = torch.zeros((n, ld), dtype=torch.float64, device=dev)
+            Z = torch.randn((n, g), dtype=torch.float64, device=dev, generator=gen)
+            if kind == "normal":
+                X[:, :g] = Z * 2.0 + 8.0
+            elif kind == "rounded":
+                X[:, :g] = torch.round((Z * 2.0 + 8.0) * 10.0) / 10.0
+            elif kind == "counts":
+                X[:, :g] = torch.floor(torch.rand((n, g), dtype=torch.float64, device=dev, generator=gen) * 4.0) * \
+                    (torch.rand((n, g), dtype=torch.float64, device=dev, generator=gen) < 0.08)
+            elif kind == "centred":
+                X[:, :g] = Z
+            alpha, beta, div = 1.0, 0.0, None
+            if kind == "ssgsea":
+                X[:, :g] = Z * 2.0 + 8.0
+                R = torch.zeros_like(X)
+                colmax = torch.zeros(n, dtype=torch.float64, device=dev)
+                div = torch.zeros(1, dtype=torch.float64, device=dev)
+                if g <= ctx.limit("sparse_rank_column"):
+                    ctx.dev_colranks_dense(X.data_ptr(), ld, g, n, R.data_ptr(), ld, "average", False, 1.25, colmax.data_ptr())
+                    ctx.dev_max(colmax.data_ptr(), n, div.data_ptr())
+                    X, beta = R, -0.5
+                else:
+                    div = None
+            # odd columns: a NaN, an Inf, an all-equal column, a copy of the neighbour
+            odd = {}
+            for c in rng.choice(n, size=int(rng.integers(0, 12)), replace=False):
+                odd[int(c)] = str(rng.choice(["nan", "inf", "const", "dup"]))
+            for c, k in odd.items():
+                if k == "nan":
+                    X[c, int(rng.integers(0, g))] = float("nan")
+                elif k == "inf" and kind != "ssgsea":
+                    X[c, int(rng.integers(0, g))] = float("inf")
+                elif k == "const":
+                    X[c, :g] = 3.0
+                elif k == "dup" and c > 0:
+                    X[c] = X[c - 1]
+        iz = [None, True, False][int(rng.integers(0, 3))]
+        tag = f"case {case}: g={g} ld={ld} m={m} n={n} kind={kind} real={real} stat={stat} ignore.zero={iz} odd columns={len(odd)}"
+        try:
+            S1, S2, f1, f2, m1, m2, status, cal, token = _run(ctx, torch, dev, stream, gs, m, X, ld, n, alpha, beta, div, iz, stat)
+            same_nan = bool(torch.equal(torch.isnan(S1), torch.isnan(S2)))
+            ok = token > 0 and same_nan and np.array_equal(f1, f2) and np.array_equal(m1, m2, equal_nan=True) and \
+                bool(torch.equal(torch.nan_to_num(S1, nan=-7.0, posinf=1e300, neginf=-1e300), torch.nan_to_num(S2, nan=-7.0, posinf=1e300, neginf=-1e300)))
+            print(("ok   " if ok else "FAIL ") + tag + f"  resolved {status.mean() if len(status) else float('nan'):.4f}", flush=True)
+            bad += 0 if ok else 1
+            del S1, S2
+        except AssertionError as exc:
+            print("FAIL " + tag + f"  {str(exc)[:200]}", flush=True)
+            bad += 1
+        gs.close()
+        del X
+        torch.cuda.empty_cache()
+    print(f"{a.cases} dense cases, {bad} failures, {time.time() - t0:.1f} s")
     ctx.close()
     return 1 if bad else 0
 
