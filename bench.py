@@ -415,6 +415,42 @@ def _parity_report(res, snap, n, m, extra=None):
     return out
 
 
+def _probe_csc(fullsize, Xp, Xi, Xx, cols, more=None):
+    """the CSC slots of the probe columns `cols` of a device-resident dgCMatrix, copied off the device run by run; `more`: a
+    device vector parallel to Xx (e.g. the ranks of the stored values) -> its probe entries as a fourth result"""
+    import numpy as np
+    ph_all = Xp.cpu().numpy()
+    parts, extra = [], []
+    for lo, hi in fullsize.contiguous_runs(cols):
+        q0, q1 = int(ph_all[lo]), int(ph_all[hi])
+        parts.append((ph_all[lo:hi + 1], Xi[q0:q1].cpu().numpy(), Xx[q0:q1].cpu().numpy()))
+        if more is not None:
+            extra.append(more[q0:q1].cpu().numpy())
+    sp_, si_, sx_ = fullsize.sub_csc(parts)
+    return (sp_, si_, sx_) if more is None else (sp_, si_, sx_, np.concatenate(extra))
+
+
+def _check_plaid_launch(torch, stream, snap, raw_oracle, relaunch_raw, S, n, m):
+    """parity of a timed plaid() launch (C2, the reference shapes): `snap` holds probe columns of the normalised S the last
+    timed step left, `raw_oracle` the oracle's un-normalised scores of those columns; `relaunch_raw()` enqueues ONE more
+    full-size crossprod into S without normalisation, for the independent check of the flag words and of the raw scores.
+    Returns the parity report (ok = False + the assertion's text when the checker raised)."""
+    import numpy as np
+    from oracle import fullsize
+    try:
+        with torch.cuda.stream(stream):
+            relaunch_raw()
+        torch.cuda.synchronize()
+        res = fullsize.check_normalised(raw_oracle, snap["S"], snap["med"], snap["cols"], snap["red"], snap["flags"],
+                                        _full_minmax(torch, S))
+        raw_g = np_f(S.index_select(0, snap["idx"]))
+        res["raw_max_rel_err_vs_oracle"] = _rel_err(raw_g, raw_oracle)
+        np.testing.assert_allclose(raw_g, raw_oracle, rtol=fullsize.RTOL, atol=fullsize.ATOL)
+        return _parity_report(res, snap, n, m)
+    except AssertionError as exc:
+        return {"launch": "full", "ok": False, "error": str(exc)[:400]}
+
+
 def _full_minmax(torch, Sraw):
     """independent device reduction over a FULL un-normalised result: (min, any zero) -- what R/plaid.R:556-557 tests"""
     return float(Sraw.min().item()), bool((Sraw == 0).any().item())
@@ -601,21 +637,9 @@ def run_c2(a, env):
                              "note": "same code, OpenMP over sample columns (not what the single-threaded reference does)"},
                "cpu_count": os.cpu_count()}
         # parity of the launch that was timed: probe columns of ITS result against the oracle, column by column
-        from oracle import fullsize
-        try:
-            Xc = np_f(X.index_select(0, snap["idx"]))
-            raw_o = c_oracle.crossprod_dense(Xc, Gp, Gi, "mean", nt)
-            with torch.cuda.stream(stream):     # one more full-size launch, un-normalised: for the independent flag check
-                ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, None)
-            torch.cuda.synchronize()
-            res = fullsize.check_normalised(raw_o, snap["S"], snap["med"], snap["cols"], snap["red"], snap["flags"],
-                                            _full_minmax(torch, S))
-            raw_g = np_f(S.index_select(0, snap["idx"]))
-            res["raw_max_rel_err_vs_oracle"] = float(np.max(np.abs(raw_g - raw_o) / np.maximum(np.abs(raw_o), 1e-300)))
-            np.testing.assert_allclose(raw_g, raw_o, rtol=fullsize.RTOL, atol=fullsize.ATOL)
-            parity = _parity_report(res, snap, n, m)
-        except AssertionError as exc:
-            parity = {"launch": "full", "ok": False, "error": str(exc)[:400]}
+        raw_o = c_oracle.crossprod_dense(np_f(X.index_select(0, snap["idx"])), Gp, Gi, "mean", nt)
+        parity = _check_plaid_launch(torch, stream, snap, raw_o,
+                                     lambda: ctx.dev_spmm_dense(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, None), S, n, m)
         if mixed is not None and "error" not in mixed:
             ctx.set_precision("mixed")
             with torch.cuda.stream(stream):
@@ -804,15 +828,8 @@ def run_sparse_ssgsea(a, env, n, label, collective, real_sets=False):
         # checker: probe cells of the launch that was timed (first / around element offset 2^31 / last), phase by phase
         from oracle import fullsize
         try:
-            cols, runs = snap["cols"], fullsize.contiguous_runs(snap["cols"])
-            ph_all = Xp.cpu().numpy()
-            parts, rparts = [], []
-            for lo, hi in runs:
-                q0, q1 = int(ph_all[lo]), int(ph_all[hi])
-                parts.append((ph_all[lo:hi + 1], Xi[q0:q1].cpu().numpy(), Xx[q0:q1].cpu().numpy()))
-                rparts.append(Rx[q0:q1].cpu().numpy())
-            sp_, si_, sx_ = fullsize.sub_csc(parts)
-            rx_gpu = np.concatenate(rparts)
+            cols = snap["cols"]
+            sp_, si_, sx_, rx_gpu = _probe_csc(fullsize, Xp, Xi, Xx, cols, more=Rx)
             gmax_dev = float(snap["gmax"][0])
             assert gmax_dev == float(snap["colmax"].max()), "max(rX) on the device != max of the device's colmax[]"
             r_o, raw_o = fullsize.ssgsea_csc_raw(sp_, si_, sx_, g, Gp, Gi, alpha, gmax_dev)
@@ -1198,28 +1215,12 @@ def run_ref_shape(a, env, name):
         from oracle import c_oracle, fullsize
         nt = _cpu_threads()
         # parity of the timed launch: probe columns against the oracle (crossprod, medians, shift)
-        try:
-            cols = snap["cols"]
-            if sparse:
-                ph_all = Xp.cpu().numpy()
-                parts = []
-                for lo, hi in fullsize.contiguous_runs(cols):
-                    q0, q1 = int(ph_all[lo]), int(ph_all[hi])
-                    parts.append((ph_all[lo:hi + 1], Xi[q0:q1].cpu().numpy(), Xx[q0:q1].cpu().numpy()))
-                sp_, si_, sx_ = fullsize.sub_csc(parts)
-                raw_o = c_oracle.crossprod_csc(sp_, si_, sx_, g, Gp, Gi, "mean", nt)
-            else:
-                raw_o = c_oracle.crossprod_dense(np_f(X.index_select(0, snap["idx"])), Gp, Gi, "mean", nt)
-            with torch.cuda.stream(stream):     # one more full-size launch, un-normalised: for the independent flag check
-                crossprod(None)
-            torch.cuda.synchronize()
-            res = fullsize.check_normalised(raw_o, snap["S"], snap["med"], cols, snap["red"], snap["flags"], _full_minmax(torch, S))
-            raw_g = np_f(S.index_select(0, snap["idx"]))
-            res["raw_max_rel_err_vs_oracle"] = _rel_err(raw_g, raw_o)
-            np.testing.assert_allclose(raw_g, raw_o, rtol=fullsize.RTOL, atol=fullsize.ATOL)
-            out["parity"] = _parity_report(res, snap, n, m)
-        except AssertionError as exc:
-            out["parity"] = {"launch": "full", "ok": False, "error": str(exc)[:400]}
+        if sparse:
+            sp_, si_, sx_ = _probe_csc(fullsize, Xp, Xi, Xx, snap["cols"])
+            raw_o = c_oracle.crossprod_csc(sp_, si_, sx_, g, Gp, Gi, "mean", nt)
+        else:
+            raw_o = c_oracle.crossprod_dense(np_f(X.index_select(0, snap["idx"])), Gp, Gi, "mean", nt)
+        out["parity"] = _check_plaid_launch(torch, stream, snap, raw_o, lambda: crossprod(None), S, n, m)
         # CPU leg: the oracle on a bounded sample, one core
         nc = min(128, n)
         if sparse:

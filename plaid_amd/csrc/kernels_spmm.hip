@@ -140,6 +140,18 @@ __device__ __forceinline__ double lds_at(uint32_t byte_off) {
 //   0 product kernel; 1 no LDS gathers (index stream + VALU only); 2 no index loads (synthetic
 //   conflict-free ids: LDS + VALU only); 3 no column prefetch / staging.  Modes 1-3 give wrong
 //   scores by construction and exist to price one pipe at a time.
+// (the ablation / stamp arms exist in the tools/ build only: behind PLAIDHIP_DIAG at the macro, the product kernel reads plain)
+#ifdef PLAIDHIP_DIAG
+#define PH_COL_PF (ABLATE != 3)
+#define PH_COL_STAMP (ABLATE == 4)
+#define PH_COL_LDS_AT(o_) lds_at<ABLATE>(o_)
+#define PH_COL_SYNTH_IDS (ABLATE == 2)
+#else
+#define PH_COL_PF true
+#define PH_COL_STAMP false
+#define PH_COL_LDS_AT(o_) lds_at<0>(o_)
+#define PH_COL_SYNTH_IDS false
+#endif
 template <bool CSC_X, int BLOCK, int ABLATE = 0>
 __global__ void __launch_bounds__(BLOCK)
 spmm_colgather_f64(SpmmArgs a) {
@@ -193,17 +205,17 @@ spmm_colgather_f64(SpmmArgs a) {
   }
 
   int c = blockIdx.x;
-  if (ABLATE != 3 && vec_ok && c < a.n && g2 > 0) PLAIDHIP_PREFETCH(c);
+  if (PH_COL_PF && vec_ok && c < a.n && g2 > 0) PLAIDHIP_PREFETCH(c);
 
   unsigned long long t_stage = 0, t_gather = 0, t_wait = 0, t_all0 = 0;
-  if constexpr (ABLATE == 4) t_all0 = __builtin_amdgcn_s_memtime();
+  if constexpr (PH_COL_STAMP) t_all0 = __builtin_amdgcn_s_memtime();
   for (; c < a.n; c += gridDim.x) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if constexpr (ABLATE == 4) ts0 = __builtin_amdgcn_s_memtime();
+    if constexpr (PH_COL_STAMP) ts0 = __builtin_amdgcn_s_memtime();
     // ---- stage the sample column in LDS ------------------------------------------------
     if constexpr (!CSC_X) {
       const double* xc = a.X + (int64_t)c * a.ldx;
-      if (ABLATE == 3) {
+      if (!PH_COL_PF) {
       } else if (vec_ok) {
         f64x2* col2 = reinterpret_cast<f64x2*>(col);
         PLAIDHIP_ITEMS(PLAIDHIP_ST_ONE)
@@ -222,23 +234,23 @@ spmm_colgather_f64(SpmmArgs a) {
       }
     }
     __syncthreads();
-    if constexpr (ABLATE == 4) ts1 = __builtin_amdgcn_s_memtime();
+    if constexpr (PH_COL_STAMP) ts1 = __builtin_amdgcn_s_memtime();
     const int cnext = c + gridDim.x;
-    const bool want_pf = ABLATE != 3 && vec_ok && cnext < a.n;
+    const bool want_pf = PH_COL_PF && vec_ok && cnext < a.n;
 
     // ---- gather: this wave's tile stream ---------------------------------------------------
     if (ch_begin < ch_end) {
       const char* ibase = reinterpret_cast<const char*>(a.tile_idx) + (int64_t)ch_begin * 1024;  // uniform
       const uint32_t ioff = (uint32_t)lane * 16u;
 #define PLAIDHIP_LOADQ(rel) \
-  (ABLATE == 2 ? make_uint4(lane | ((lane + 64u) << 16), (lane + 128u) | ((lane + 192u) << 16), \
+  (PH_COL_SYNTH_IDS ? make_uint4(lane | ((lane + 64u) << 16), (lane + 128u) | ((lane + 192u) << 16), \
                             (lane + 256u) | ((lane + 320u) << 16), (lane + 384u) | ((lane + 448u + (rel)) << 16)) \
                : *reinterpret_cast<const uint4*>(ibase + (int64_t)(rel) * 1024 + ioff))
 #define PLAIDHIP_GATHER8(V, q)                                               \
-  V##0 = lds_at<ABLATE>(off_lo((q).x)); V##1 = lds_at<ABLATE>(off_hi((q).x)); \
-  V##2 = lds_at<ABLATE>(off_lo((q).y)); V##3 = lds_at<ABLATE>(off_hi((q).y)); \
-  V##4 = lds_at<ABLATE>(off_lo((q).z)); V##5 = lds_at<ABLATE>(off_hi((q).z)); \
-  V##6 = lds_at<ABLATE>(off_lo((q).w)); V##7 = lds_at<ABLATE>(off_hi((q).w));
+  V##0 = PH_COL_LDS_AT(off_lo((q).x)); V##1 = PH_COL_LDS_AT(off_hi((q).x)); \
+  V##2 = PH_COL_LDS_AT(off_lo((q).y)); V##3 = PH_COL_LDS_AT(off_hi((q).y)); \
+  V##4 = PH_COL_LDS_AT(off_lo((q).z)); V##5 = PH_COL_LDS_AT(off_hi((q).z)); \
+  V##6 = PH_COL_LDS_AT(off_lo((q).w)); V##7 = PH_COL_LDS_AT(off_hi((q).w));
 #define PLAIDHIP_ADD8(V)                       \
   s0 += V##0; s1 += V##1; s2 += V##2; s3 += V##3; \
   s0 += V##4; s1 += V##5; s2 += V##6; s3 += V##7;
@@ -358,22 +370,26 @@ spmm_colgather_f64(SpmmArgs a) {
     } else if (want_pf) {
       PLAIDHIP_PREFETCH(cnext);
     }
-    if constexpr (ABLATE == 4) ts2 = __builtin_amdgcn_s_memtime();
+    if constexpr (PH_COL_STAMP) ts2 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // column is overwritten by the next iteration
-    if constexpr (ABLATE == 4) {
+    if constexpr (PH_COL_STAMP) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
       t_stage += ts1 - ts0;
       t_gather += ts2 - ts1;
       t_wait += ts3 - ts2;
     }
   }
-  if constexpr (ABLATE == 4) {
+  if constexpr (PH_COL_STAMP) {
     if (lane == 0 && a.dbg != nullptr) {
       unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (BLOCK / 64) + wave) * 4;
       d[0] = t_stage; d[1] = t_gather; d[2] = t_wait; d[3] = __builtin_amdgcn_s_memtime() - t_all0;
     }
   }
   publish_flags(f, a.flags);
+#undef PH_COL_PF
+#undef PH_COL_STAMP
+#undef PH_COL_LDS_AT
+#undef PH_COL_SYNTH_IDS
 #undef PLAIDHIP_GATHER8
 #undef PLAIDHIP_ADD8
 #undef PLAIDHIP_TILE_END
