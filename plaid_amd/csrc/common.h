@@ -97,6 +97,8 @@ struct plaidhip_ctx {
   int opt_scatter_order = 1;   // scatter kernel: 0 (column, chunk) | 1 (chunk, column) item order
   int opt_fused_medians = 0;   // medians selected inside the sparse crossprod: 0 by size (>= 1e9 scores) | 1 whenever possible | 2 never
   double* d_sel = nullptr;        // {0 or -1, max, smallest > 0, largest column sum or +inf} of the stored values of a sparse X (scatter kernel's choice of accumulators)
+                                  // (a 128-byte block: d_spec at byte 64; bytes 96..127 hold the EMPTY median bracket {0, -1, 0, 0} a
+                                  //  calibration launch of the dense fused crossprod classifies against, written once at plaidhip_init)
   uint32_t* d_spec = nullptr;     // speculative launches (u16 quad kernel): [0] generation that saw a non-rank, [1..3] its private flag words
   uint32_t spec_gen = 0;          // generation of the last speculative launch (host side)
   // medians selected inside the last sparse crossprod launch (launch_spmm_csc_fused_f64): what plaidhip_dev_col_medians_resume

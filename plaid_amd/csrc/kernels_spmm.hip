@@ -2521,11 +2521,11 @@ int launch_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   const bool big_enough = ctx->opt_fused_medians == 1 || (int64_t)gs->m * n >= 1000000000ll;
   const bool eligible = ctx->opt_fused_medians != 2 && big_enough && gs->m > 6144 && n >= 4 * K && flags != nullptr &&
                         ctx->opt_dense_kernel != 3 && !compact && g_ablate == 0 && pair_kernel_mode(ctx) != 0 &&
-                        !gs->pair.slices.empty() && gs->scatter.d_u != nullptr && gs->m > 0;
+                        !gs->pair.slices.empty() && gs->scatter.d_u != nullptr && gs->m > 0 && ctx->d_sel != nullptr;
   if (!eligible) return launch_spmm_dense_f64(ctx, gs, X, ldx, n, stat, alpha, alpha_div, beta, S, lds, flags, x_kind);
-  // scratch: [pred n f64][cal 4 f64][cal0 4 f64][medK K f64][flagsK 4 u32 (+pad)][status n i32 (+pad)][cnt n nslice 4 u32][cand n nslice capc u64]
+  // scratch: [pred n f64][cal 4 f64][medK K f64][flagsK 4 u32 (+pad)][status n i32 (+pad)][cnt n nslice 4 u32][cand n nslice capc u64]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_pred = 0, o_cal = up(o_pred + (size_t)n * 8), o_cal0 = up(o_cal + 32), o_medK = up(o_cal0 + 32),
+  const size_t o_pred = 0, o_cal = up(o_pred + (size_t)n * 8), o_medK = up(o_cal + 32),
                o_flagsK = up(o_medK + (size_t)K * 8), o_status = up(o_flagsK + 16), o_cnt = up(o_status + (size_t)n * 4),
                o_cand = up(o_cnt + (size_t)n * nslice * 16), total = o_cand + (size_t)n * nslice * kCapC * 8;
   if (ctx->fmed_bytes < total) {

@@ -67,6 +67,7 @@ class HipPhaseEngine:
         import torch
         self.torch = torch
         self.ctx, self.gs, self.device = ctx, geneset, device
+        self._fused = None      # (weak reference to the S of the last fused crossprod, its launch token): medians() resumes only for that tensor
 
     def _same_stream(self):
         # the library enqueues on ITS stream: tensors allocated, zeroed or all-reduced on another stream would race
@@ -184,7 +185,7 @@ class HipPhaseEngine:
         if n > 0:
             # dev_col_medians -- unless this very tensor came out of a fused crossprod whose candidates are still pending on the
             # context: then only unresolved columns are swept
-            fused, self._fused = getattr(self, "_fused", None), None
+            fused, self._fused = self._fused, None
             token = fused[1] if (fused is not None and fused[0]() is S) else 0
             self.ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), flags.data_ptr(), token=token)
             self.ctx.dev_sum(med.data_ptr(), n, red.data_ptr())
