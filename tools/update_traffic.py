@@ -38,7 +38,7 @@ def find(summ, needle):
 
 # (traffic.json key, pmc tag, kernel-name needle, columns of the measured launch or None for per-launch, note)
 ENTRIES = [
-    ("spmm_colpair_f64/20000x10000x5000", "c2", "spmm_colpair_f64<false, 0, false, false>", None,
+    ("spmm_colpair_f64/20000x10000x5000", "c2", "spmm_colpair_f64<false, 0, false, false, false>", None,
      "fabric-side bytes: 1.6 GB X + 0.4 GB S + the partial sums of the two gene slices (written and re-read ~30 us later; served "
      "by L2 / Infinity Cache, which these counters do not separate from HBM)"),
     ("col_medians_wave_kernel/10000x5000", "c2step", "col_medians_wave_kernel", None, "every column read once into registers"),
@@ -54,9 +54,9 @@ ENTRIES = [
     ("colranks_bucket_kernel<256,8>/csc", "c3", "colranks_bucket_kernel<256, 8>", 8192, "1000 stored values per column: 8 KB read + 8 KB written + colmax"),
     ("colranks_bucket_kernel<1024,20>/20000xN", "c4", "colranks_bucket_kernel<1024, 20>", 4096,
      "160 KB read + 160 KB written per column = the algorithmic 16 g bytes (+ the spilled registers' scratch)"),
-    ("spmm_colpair_f64/20000xNx50000", "c4", "spmm_colpair_f64<false, 0, false, false>", 4096,
+    ("spmm_colpair_f64/20000xNx50000", "c4", "spmm_colpair_f64<false, 0, false, false, true>", 4096,
      "0.8 MB of partial sums per column pair written and re-read between the two gene slices + tile streams missing L2"),
-    ("spmm_colpair_f64<med>/20000xNx50000", "c4fused", "spmm_colpair_f64<false, 0, false, true>", (4096 + 256) // 2,
+    ("spmm_colpair_f64<med>/20000xNx50000", "c4fused", "spmm_colpair_f64<false, 0, false, true, true>", (4096 + 256) // 2,
      "the pair kernel with the classifying tile ends (medians selected inside the launch): partial sums as above + the candidate "
      "slices and counts.  Two launches per call -- the calibration on 256 columns and the main one on 4,096 -- whose MEAN the "
      "summary holds: per column = mean / ((4096 + 256) / 2)"),
