@@ -241,6 +241,8 @@ def dry_run(a):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    if os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+        raise SystemExit(f"bench.py --dry-run: rank {rank} fails on request (BENCH_DRY_FAIL_RANK)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")

@@ -102,3 +102,14 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+
+
+def test_a_failing_rank_fails_the_launcher(tmp_path):
+    """`bench.py --gpus 2` forwards the exit status of its child launcher: a rank that dies must not end in a zero exit status
+    with a stale or missing line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BENCH_DETAIL=str(tmp_path / "detail.json"), MASTER_PORT="29619", BENCH_DRY_FAIL_RANK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0, p.stdout[-500:]
+    assert not any(ln.startswith('{"metric"') for ln in p.stdout.splitlines())
