@@ -192,3 +192,35 @@ def test_dense_fused_predicted_means_are_the_column_means(env):
     ctx.lib.plaidhip_memcpy_d2h(ctx.handle, pred.ctypes.data_as(C.c_void_p), C.c_void_p(p_pred), C.c_size_t(8 * n))
     np.testing.assert_allclose(pred, S.mean(dim=1).cpu().numpy(), rtol=1e-11, atol=1e-13)
     gs.close()
+
+
+def test_dense_fused_entry_points_check_their_arguments(env):
+    """bad dimensions / null pointers / a negative token are error codes with a message (no launch, no crash): the same
+    contract as every other entry point"""
+    import plaid_amd
+    torch, dev, stream, ctx = env
+    from plaid_amd import synth as sy
+    g, m, n = 3000, 7000, 8
+    Gp, Gi = sy.geneset_csc(g, m, kmin=5, kmax=60)
+    gs = ctx.geneset(g, Gp, Gi)
+    with torch.cuda.stream(stream):
+        X = _normal(torch, dev, n, g, 1)
+        S = torch.empty((n, m), dtype=torch.float64, device=dev)
+        fl = torch.zeros(4, dtype=torch.int32, device=dev)
+        med = torch.empty(n, dtype=torch.float64, device=dev)
+    for bad in (dict(ldx=g - 1), dict(lds=m - 1), dict(n=-1), dict(X=None), dict(S=None)):
+        a = dict(X=X.data_ptr(), ldx=g, n=n, S=S.data_ptr(), lds=m)
+        a.update(bad)
+        with pytest.raises(plaid_amd.PlaidHipError):
+            ctx.dev_spmm_dense_fused(gs, a["X"], a["ldx"], a["n"], a["S"], a["lds"], "mean", 1.0, 0.0, fl.data_ptr(), None)
+    with pytest.raises(plaid_amd.PlaidHipError):
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), fl.data_ptr(), token=-5)
+    with pytest.raises(plaid_amd.PlaidHipError):                      # ignore.zero = auto needs the flag words
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), None, token=0)
+    # and a legal small call still works afterwards (ineligible by size: the plain route, token 0)
+    with torch.cuda.stream(stream):
+        token = ctx.dev_spmm_dense_fused(gs, X.data_ptr(), g, n, S.data_ptr(), m, "mean", 1.0, 0.0, fl.data_ptr(), None)
+        ctx.dev_col_medians_resume(S.data_ptr(), m, m, n, None, med.data_ptr(), fl.data_ptr(), token=token)
+    torch.cuda.synchronize()
+    assert token == 0 and bool(torch.isfinite(med).all())
+    gs.close()
