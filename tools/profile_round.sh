@@ -53,6 +53,7 @@ for ab in 0 5 8 9 10 13; do echo "ablate $ab (4096 x 50000 sets)"; PLAIDHIP_LIB=
 for f in "" "--fused"; do python3 tools/bench_spmm.py --kernel c4 --samples 8192 --sets 50000 --iters 4 $f 2>&1 | grep "^c4" | tail -1; done > $out/c4_8192_fused.log 2>&1
 for ab in 0 2 6 7 5; do PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --iters 10 --ablate $ab 2>&1 | grep -E "^spmm|algorithmic" | tail -2; done > $out/pair_ablations.log 2>&1
 for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 3 --ablate $ab 2>&1 | grep -E "^c3|stamps" | tail -2; done > $out/scatter_ablations.log 2>&1
+[ -x tools/ubench/fetch_calib ] && bash tools/fetch_calib.sh $out/fetch_calib > $out/fetch_calib.log 2>&1   # FETCH_SIZE against known byte counts
 [ -x tools/ubench/inexact_flag ] && ./tools/ubench/inexact_flag > $out/ubench_inexact_flag.log 2>&1
 [ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
 [ -x tools/ubench/stream_rw ] && ./tools/ubench/stream_rw 3.2 > $out/ubench_stream_rw.log 2>&1
