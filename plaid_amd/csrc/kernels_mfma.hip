@@ -17,8 +17,9 @@
 //   * K step 32 genes, TWO LDS stages (2 x 4 tiles x 256 rows x 80 bytes = the whole 160 KB): rows padded from 64 to
 //     80 bytes, so that the four 16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots (80 = 5 x 16, 5 is
 //     odd: conflict-free); step k + 1 is written to the other stage and step k + 2 requested from memory before the
-//     MFMAs of step k issue: one barrier per step.  (Rounds 2-4: 128 x 128 tiles, 256 threads, one stage, two
-//     barriers per step: 0.10 of the bf16 peak.)
+//     MFMAs of step k issue: one barrier per step; the W fragments of plane t + 1 are read while the MFMAs of plane t
+//     issue.  0.57-0.59 of the bf16 peak.  (Rounds 2-4: 128 x 128 tiles, 256 threads, one stage, two barriers per step:
+//     0.10.)
 #include <mutex>
 
 #include "common.h"
@@ -137,35 +138,58 @@ crossprod_mfma_bf16x3_kernel(MfmaArgs a) {
   __syncthreads();
   const uint32_t arow = (uint32_t)((wm * 128 + (lane & 31)) * kMfmaRowB + (lane >> 5) * 16);
   const uint32_t brow = (uint32_t)(3 * kMfmaTile * kMfmaRowB + (wn * 64 + (lane & 31)) * kMfmaRowB + (lane >> 5) * 16);
+  // One K step = two halves of 16 genes, 24 MFMAs each.  The eight LDS writes that stage step ks + 1 are SPREAD over the first
+  // half (one per three MFMAs) instead of leading the step: issued together they hold the LDS pipe for ~830 cycles while the
+  // fragment reads of all eight wavefronts queue behind them (profiles/r05j: 0.52 of the peak in that form); the requests for
+  // step ks + 2 follow between the halves, when the prefetch registers are free again.
+// A half step: the W fragments of plane t + 1 are requested BEFORE the eight MFMAs of plane t issue (two register sets,
+// scheduling barriers between the groups): left to itself hipcc keeps two fragment reads in flight and every MFMA pair
+// waits for an LDS round trip.
+#define PH_MFMA_AFR(dst, t_, kk)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+    dst[i] = *reinterpret_cast<const bf16x8*>(st + (t_) * kMfmaTile * kMfmaRowB + arow + i * 32 * kMfmaRowB + (kk) * 32);
+#define PH_MFMA_PLANE(afr_, WA, WB, WC, WD)                                                                        \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[0], bfr0, acc[0][0], 0, 0, 0);                          \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[0], bfr1, acc[0][1], 0, 0, 0); WA                       \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[1], bfr0, acc[1][0], 0, 0, 0);                          \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[1], bfr1, acc[1][1], 0, 0, 0); WB                       \
+  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[2], bfr0, acc[2][0], 0, 0, 0);                          \
+  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[2], bfr1, acc[2][1], 0, 0, 0); WC                       \
+  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[3], bfr0, acc[3][0], 0, 0, 0);                          \
+  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr_[3], bfr1, acc[3][1], 0, 0, 0); WD
+#define PH_MFMA_HALF(kk, W0, W1, W2, W3, W4, W5, W6, W7)                                                        \
+  {                                                                                                               \
+    const bf16x8 bfr0 = *reinterpret_cast<const bf16x8*>(st + brow + (kk) * 32);                                  \
+    const bf16x8 bfr1 = *reinterpret_cast<const bf16x8*>(st + brow + 32 * kMfmaRowB + (kk) * 32);                 \
+    bf16x8 afa[4], afb[4];                                                                                        \
+    PH_MFMA_AFR(afa, 0, kk)                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    PH_MFMA_AFR(afb, 1, kk)                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    PH_MFMA_PLANE(afa, W0, W1, W2, W3)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    PH_MFMA_AFR(afa, 2, kk)                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    PH_MFMA_PLANE(afb, W4, W5, W6, W7)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    PH_MFMA_PLANE(afa, , , , )                                                                                    \
+  }
   for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    // step ks + 1 (in registers since the step before) goes to the other stage -- its readers of step ks - 1 are behind the
-    // barrier that ended that step -- and step ks + 2 is requested; both before the MFMAs of this step issue
-    if (ks + 1 < nk) {
-      PH_MFMA_STAGE(cur ^ 1)
-      if (ks + 2 < nk) { PH_MFMA_PREFETCH(ks + 2) }
-    }
+    const int cur = ks & 1, nx = cur ^ 1;
     const unsigned char* st = lds + cur * kMfmaStageB;
-    // (rolled on purpose: unrolled, hipcc requests all 28 fragments of the step up front -- 112 registers next to the 128
-    // accumulators -- and moves the prefetch registers to scratch memory)
-#pragma unroll 1
-    for (int kk = 0; kk < kMfmaBK / 16; ++kk) {
-      bf16x8 bfr[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(st + brow + j * 32 * kMfmaRowB + kk * 32);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16x8 afr = *reinterpret_cast<const bf16x8*>(st + t * kMfmaTile * kMfmaRowB + arow + i * 32 * kMfmaRowB + kk * 32);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
+    // step ks + 1 (in registers since the step before) goes to the other stage: its readers of step ks - 1 are behind the
+    // barrier that ended that step.  Unconditional on purpose (no second copy of the MFMA sequence, no branches inside it): the
+    // last step stages stale registers into a stage nobody reads again and re-requests its own slab.
+    PH_MFMA_HALF(0, PH_MFMA_ST1(nx, 0, 0, pf00), PH_MFMA_ST1(nx, 0, 1, pf01), PH_MFMA_ST1(nx, 1, 0, pf10), PH_MFMA_ST1(nx, 1, 1, pf11),
+                 PH_MFMA_ST1(nx, 2, 0, pf20), PH_MFMA_ST1(nx, 2, 1, pf21), PH_MFMA_ST1(nx, 3, 0, pf30), PH_MFMA_ST1(nx, 3, 1, pf31))
+    __builtin_amdgcn_sched_barrier(0);   // (keeps the second half's fragment reads behind the first half: registers)
+    PH_MFMA_PREFETCH(ks + 2 < nk ? ks + 2 : nk - 1)
+    PH_MFMA_HALF(1, , , , , , , , )
     __syncthreads();
   }
+#undef PH_MFMA_HALF
+#undef PH_MFMA_PLANE
+#undef PH_MFMA_AFR
 #undef PH_MFMA_PREFETCH
 #undef PH_MFMA_STAGE
 #undef PH_MFMA_ST1
