@@ -67,6 +67,7 @@ def parse(argv=None):
                     help="untimed C2 steps before the --warmup steps, so that the timed steps run at the sustained clocks (0: none)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="C2 columns timed on the CPU oracle (0 = skip all CPU legs)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--host-gather", action="store_true", help="N > 1: also time the host (/dev/shm) gather of the C5 shard's score matrix")
     ap.add_argument("--no-mixed", action="store_true", help="skip the secondary mixed-precision (fp32-staged) measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: rendezvous (gloo), the max-over-ranks reduction and the output line only (CPU test of the launcher)")
@@ -811,7 +812,9 @@ def run_sparse_ssgsea(a, env, n, label, collective, real_sets=False):
         },
     }
     if collective and not a.no_gather:
-        out["gather"] = _bench_gather(env, S, world * n, ("host", "device"))
+        # (the host gather of config 5 writes 8 x 50 GB through /dev/shm: tens of seconds; it runs on request only, so that
+        # the driver's scaling runs stay within minutes -- measured in tools/gather_host_check.py and DESIGN.md 8)
+        out["gather"] = _bench_gather(env, S, world * n, ("host", "device") if a.host_gather else ("device",))
     if not collective and rank == 0 and a.cpu_sample > 0:
         from oracle import c_oracle
         nc = min(2048, n)

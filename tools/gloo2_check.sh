@@ -6,7 +6,7 @@ out=${1:-gpurun_out/gloo2}
 mkdir -p $out
 export BENCH_DIST_BACKEND=gloo BENCH_DUMP_AFTER=300 BENCH_DETAIL=$out/bench_gloo2_detail.json MASTER_PORT=29533
 unset WORLD_SIZE RANK LOCAL_RANK
-timeout 350 python3 bench.py --gpus 2 --steps 3 --warmup 1 --preheat-steps 0 --c5-cells-per-gpu 2048 > $out/bench_gloo2.json 2> $out/bench_gloo2.err
+timeout 350 python3 bench.py --gpus 2 --steps 3 --warmup 1 --preheat-steps 0 --c5-cells-per-gpu 2048 --host-gather > $out/bench_gloo2.json 2> $out/bench_gloo2.err
 echo rc=$?
 grep -n "File \"/root/repo\|Error\|error" $out/bench_gloo2.err | head -20
 python3 - <<PY
