@@ -34,6 +34,11 @@ constexpr int kScatterTrash = 64;                      // accumulators behind a 
 #define PLAIDHIP_SCATTER_BLOCK 1024
 #endif
 constexpr int kScatterBlock = PLAIDHIP_SCATTER_BLOCK;
+// further id segments (genes in more than 128 sets of a chunk) whose loads ride the scatter walk's static pipeline per
+// wavefront and item; a wavefront with more of them fetches the rest group by group (A/B builds: -DPLAIDHIP_SCATTER_HE=8)
+#ifndef PLAIDHIP_SCATTER_HE
+#define PLAIDHIP_SCATTER_HE 12
+#endif
 // sets per chunk: 17 passes of the workgroup's 1,024 threads over the accumulators (136 KiB of the 160; the chunk epilogue
 // keeps one 16-byte factor pair per pass in registers, and 20 of them left none for anything else: 50,000 sets are three
 // chunks either way)
@@ -190,12 +195,28 @@ struct plaidhip_pair_plan {
   double* d_meta_k = nullptr;
 };
 
-// Scatter plan (sparse X): G transposed, gene-major.  The sets are cut into chunks of `ch` (the
-// LDS accumulators of one chunk); the sets of gene i inside chunk c are stored as whole segments
-// of 128 u16 ids (a dword = two ids per lane) relative to the chunk start (padding: a trash accumulator behind the chunk,
-// or 0xffff in every high half of a segment whose second instruction is empty): segments seg[c*g + i] ..
+// Scatter plan (sparse X): G transposed, gene-major.  The sets are dealt to `nch` chunks of `ch` accumulator slots (the
+// LDS accumulators of one chunk) in BLOCKS of kScatterBlock consecutive sets, block b to chunk b % nch at slots
+// (b / nch) * kScatterBlock ..: a collection straight from gmt2mat() has its sets in decreasing size (R/gmt-utils.R:25), and
+// chunks of consecutive sets gave the first chunk 72 % of all memberships -- two to three id segments per gene there, one
+// fifth-full segment in the last chunk, 4.35 (value, chunk) pairs per stored value at config 3 instead of the 3.3 the
+// interleaved deal needs (every chunk sees the whole range of set sizes).  A chunk pass of the 1,024 threads still writes
+// 1,024 consecutive scores.  The sets of gene i inside chunk c are stored as whole segments
+// of 128 u16 slot ids (a dword = two ids per lane; padding: a trash accumulator behind the chunk): segments seg[c*g + i] ..
 // seg[c*g + i + 1] - 1 of d_ids.  (seg has nch*g + 1 entries, chunk-major, so the ranges of
 // consecutive (chunk, gene) pairs are contiguous.)
+#if defined(__HIPCC__)
+#define PH_HD __host__ __device__
+#else
+#define PH_HD
+#endif
+PH_HD inline int32_t scatter_chunk_of(int32_t j, int32_t nch) { return (j / plaidhip::kScatterBlock) % nch; }
+PH_HD inline int32_t scatter_slot_of(int32_t j, int32_t nch) {
+  return ((j / plaidhip::kScatterBlock) / nch) * plaidhip::kScatterBlock + j % plaidhip::kScatterBlock;
+}
+PH_HD inline int32_t scatter_set_of(int32_t chunk, int32_t slot, int32_t nch) {
+  return ((slot / plaidhip::kScatterBlock) * nch + chunk) * plaidhip::kScatterBlock + slot % plaidhip::kScatterBlock;
+}
 struct plaidhip_scatter_plan {
   int32_t ch = 0, nch = 0;
   int32_t kbits = 0;           // bits of the largest set size + 1: headroom of the fixed-point sums

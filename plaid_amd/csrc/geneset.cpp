@@ -677,8 +677,10 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     // eight smaller chunks to the eight XCDs so that an XCD's L2 holds only its share of the id lists was measured:
     // 1.7x SLOWER -- the passes are bound by their chains of dependent loads, not by L2 misses.)
     sp.nch = (m + kScatterChunk - 1) / kScatterChunk;
-    sp.ch = (((m + sp.nch - 1) / sp.nch) + 15) & ~15;           // equal chunks; a multiple of 16: the trash slots keep their banks
-    if (sp.ch > kScatterChunk) sp.ch = kScatterChunk & ~15;
+    {   // blocks of kScatterBlock consecutive sets dealt round-robin to the chunks (common.h); ch is a multiple of 16: the trash slots keep their banks
+      const int32_t nb = (m + kScatterBlock - 1) / kScatterBlock;
+      sp.ch = ((nb + sp.nch - 1) / sp.nch) * kScatterBlock;     // <= kScatterChunk: nb <= 17 nch
+    }
     {
       int32_t kmax = 1;
       for (int32_t j = 0; j < m; ++j) kmax = std::max(kmax, Gp[j + 1] - Gp[j]);
@@ -687,7 +689,7 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     }
     std::vector<int32_t> cnt((size_t)sp.nch * g, 0);
     for (int32_t j = 0; j < m; ++j)
-      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) ++cnt[(size_t)(j / sp.ch) * g + Gi[p]];
+      for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) ++cnt[(size_t)scatter_chunk_of(j, sp.nch) * g + Gi[p]];
     std::vector<int32_t> seg((size_t)sp.nch * g + 1, 0);
     for (size_t i = 0; i < cnt.size(); ++i) seg[i + 1] = seg[i] + (cnt[i] + 127) / 128;
     sp.nseg = seg.back();
@@ -698,8 +700,8 @@ extern "C" int plaidhip_geneset_create(plaidhip_ctx* ctx, int32_t g, int32_t m, 
     std::fill(cnt.begin(), cnt.end(), 0);
     for (int32_t j = 0; j < m; ++j)
       for (int32_t p = Gp[j]; p < Gp[j + 1]; ++p) {
-        const size_t cell = (size_t)(j / sp.ch) * g + Gi[p];
-        ids[(size_t)seg[cell] * 128 + cnt[cell]++] = (uint16_t)(j % sp.ch);
+        const size_t cell = (size_t)scatter_chunk_of(j, sp.nch) * g + Gi[p];
+        ids[(size_t)seg[cell] * 128 + cnt[cell]++] = (uint16_t)scatter_slot_of(j, sp.nch);
       }
     TSW("scatter lists filled");
     // Bank-conflict-free order inside every (chunk, gene) list.  The kernel turns a segment into two ds_add_f64
@@ -973,7 +975,7 @@ extern "C" int plaidhip_debug_scatter_plan_check(const plaidhip_geneset* gs, int
               if (banks & (1u << (id & 15))) ++coll;
               banks |= 1u << (id & 15);
               if (id >= sp.ch) { if (id >= sp.ch + kScatterTrash) ++wrong; continue; }   // a trash accumulator
-              const int32_t j = ch * sp.ch + id;
+              const int32_t j = scatter_set_of(ch, id, sp.nch);
               if (j >= m) { ++wrong; continue; }
               const int32_t* lo = std::lower_bound(Gi + Gp[j], Gi + Gp[j + 1], gene);
               if (lo == Gi + Gp[j + 1] || *lo != gene || seen[lo - Gi]) { ++wrong; continue; }

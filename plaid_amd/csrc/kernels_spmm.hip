@@ -974,6 +974,7 @@ struct ScatterArgs {
   unsigned long long* dbg;   // tools/ build: per workgroup, wave 0: cycles in {walk, barrier, epilogue, barrier}
   int32_t abl;               // tools/ build: 1 no LDS atomics | 2 no id loads (synthetic conflict-free ids) | 3 no score stores | 4 = 1 + 2 | 5 no walk
                              // | 6 score stores with agent scope (sc1: the lines do not stay in L2) | 7 plain score stores
+                             // | 8 no further segments | 9 no factor loads in the epilogue
 };
 
 #ifdef PLAIDHIP_DIAG
@@ -991,8 +992,10 @@ struct ScatterArgs {
     t_last = t_;                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                 \
   } while (0)
+#define PH_SC_STAMP_IDS(x) do { asm volatile("" : "+v"(x)); PH_SC_STAMP(5); } while (0)
 #else
 #define PH_SC_STAMP(k) do { } while (0)
+#define PH_SC_STAMP_IDS(x) do { } while (0)
 #endif
 
 __device__ __forceinline__ double readlane_f64(double v, int src) {
@@ -1162,23 +1165,60 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #define PLAIDHIP_WALK_SEGMENTS()                                                                       \
   {                                                                                                    \
     const int s0e = ns > 0 ? s0 : a.dummy_seg;                                                         \
-    PLAIDHIP_AFTER_STAGE()                                                                             \
-    /* 48 id loads in flight per wavefront (three groups of 16 ahead of the group being applied): the loop was     \
-       bound by one L2 round trip per group of 8 values, not by the atomics */                        \
+    /* 48 + HE id loads in flight per wavefront.  Segment 0 of the wavefront's 64 values goes through a static pipeline   \
+       (groups A..D, owning lane = a CONSTANT readlane index).  Genes in more than 128 sets of the chunk have FURTHER       \
+       segments (~7 per wavefront and item at config 3).  Round 5 walked them behind the pipeline with scalar bookkeeping   \
+       per entry (ballot / find-first / dynamic readlane, ~20 dependent scalar instructions and three branches each) and a  \
+       load round trip of their own: 21 % of the launch (tools/bench_spmm.py --ablate 108), most of it the scalar code.     \
+       Now the second segments are COMPACTED with vector instructions -- the lanes that have one send {segment, value} to   \
+       lane rank-among-them by ds_permute_b32 (a full permutation: the other lanes fill up behind) -- so that entry u sits   \
+       in lane u like a first segment, and the first HE of them are group E of the same static pipeline, requested right    \
+       behind A, B, C.  What is left for the scalar walk behind the pipeline: third and later segments (a gene in more than \
+       256 sets of one chunk) and second segments beyond HE per wavefront. */                         \
     constexpr int HW = 16;                                                                             \
-    uint32_t idA[HW], idB[HW], idC[HW], idD[HW];                                                       \
+    constexpr int HE = PLAIDHIP_SCATTER_HE;                                                            \
+    static_assert(HE % 4 == 0 && HE <= 16, "group E is applied four entries at a time");              \
+    uint32_t idA[HW], idB[HW], idC[HW], idD[HW], idE[HE];                                              \
     const int nval = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(have)));            \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idA[u] = PLAIDHIP_ID_LOAD(u);                       \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idB[u] = PLAIDHIP_ID_LOAD(HW + u);                  \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idC[u] = PLAIDHIP_ID_LOAD(2 * HW + u);              \
+    PLAIDHIP_ISSUE_PREFETCH()                                                                          \
+    const uint64_t m1 = PH_SC_ABL(8) ? 0ull : __ballot(ns > 1);                                        \
+    const int cnt1 = __builtin_popcountll(m1);                                                         \
+    int segE = a.dummy_seg;                                                                            \
+    double vE = 0.0;                                                                                   \
+    {                                                                                                  \
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)); \
+      const int dest = (ns > 1 ? (int)below : cnt1 + lane - (int)below) << 2;                          \
+      const int sg_ = __builtin_amdgcn_ds_permute(dest, s0 + 1);                                       \
+      const int lo_ = __builtin_amdgcn_ds_permute(dest, __double2loint(v));                            \
+      const int hi_ = __builtin_amdgcn_ds_permute(dest, __double2hiint(v));                            \
+      if (lane < cnt1) {   /* (lanes behind the compacted entries: the all-padding segment, value 0) */ \
+        segE = sg_;                                                                                    \
+        vE = __hiloint2double(hi_, lo_);                                                               \
+      }                                                                                                \
+    }                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < HE; ++u)                                                     \
+      idE[u] = PH_SC_ABL(2) ? ((uint32_t)(2 * lane_i) | ((uint32_t)(2 * lane_i + 1) << 16))            \
+                            : (uint32_t)raw_buffer_load_i32(ids_rsrc, loff_b, (int32_t)((uint32_t)__builtin_amdgcn_readlane(segE, u) << 8), 0); \
+    PH_SC_STAMP_IDS(idA[0]);   /* tools/ build: the first ids in hand */                               \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idA[u], PLAIDHIP_V_OF(u))         \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idD[u] = PLAIDHIP_ID_LOAD(3 * HW + u);              \
     if (nval > HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idB[u], PLAIDHIP_V_OF(HW + u)) }      \
     if (nval > 2 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idC[u], PLAIDHIP_V_OF(2 * HW + u)) } \
     if (nval > 3 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idD[u], PLAIDHIP_V_OF(3 * HW + u)) } \
-    /* genes in more than 128 sets of the chunk: their segments 1, 2, ... (flattened over the lanes) */ \
-    uint64_t wmask = __ballot(ns > 1);                                                                 \
-    if (wmask != 0ull) {                                                                               \
+    PH_SC_STAMP(6);                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < HE / 4; ++q)                                                 \
+      if (cnt1 > 4 * q) { _Pragma("unroll") for (int u = 4 * q; u < 4 * q + 4; ++u) PLAIDHIP_SCATTER2(idE[u], readlane_f64(vE, u)) } \
+    /* the rest, scalar walk (flattened list, pass-major): second segments beyond HE, then segments 2, 3, ... */ \
+    const uint64_t m2 = PH_SC_ABL(8) ? 0ull : __ballot(ns > 2);                                        \
+    if (cnt1 > HE || m2 != 0ull) {                                                                     \
+      uint64_t wmask = 0ull;                                                                           \
+      if (cnt1 > HE) {                                                                                 \
+        wmask = m1;                                                                                    \
+        for (int u = 0; u < HE; ++u) wmask &= wmask - 1ull;                                            \
+      }                                                                                                \
       int pass = 1;                                                                                    \
       bool more = true;                                                                                \
       int sgX[UN], cntX;                                                                               \
@@ -1190,6 +1230,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
         PLAIDHIP_APPLY_GROUP(idX, vX, cntX)                                                            \
       } while (cntX == UN);                                                                            \
     }                                                                                                  \
+    PH_SC_STAMP(7);                                                                                    \
   }
 // The per-set factors of the chunk's sets -- 18 sets per thread at most -- are requested when the wavefront has applied
 // its stored values, BEFORE the barrier that ends the walk: they land while the slower wavefronts finish, and the
@@ -1199,18 +1240,19 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #define PLAIDHIP_EPI_PREFETCH()                                                                    \
   f64x2 kwv[kEpiSets];                                                                              \
   {                                                                                                 \
-    int tid_e = tid;                                                                                \
-    asm volatile("" : "+v"(tid_e));                                                                 \
+    int jb_p = jb;                                                                                  \
+    asm volatile("" : "+v"(jb_p));                                                                  \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
-      const int i = tid_e + u * BLOCK;                                                              \
-      kwv[u] = a.kw[j0 + (i < nj ? i : nj - 1)];                                                    \
+      const int j = jb_p + u * jstep;   /* the set of slot tid + u * BLOCK of this chunk (common.h: blocks dealt to the chunks) */ \
+      kwv[u] = PH_SC_ABL(9) ? f64x2{1.0, 0.5} : a.kw[j < a.m ? j : a.m - 1];                        \
     }                                                                                               \
   }
 #define PLAIDHIP_EPI_ONE(u)                                                                        \
   {                                                                                                 \
     const int i = tid_e + (u) * BLOCK;                                                              \
+    const int j = jb_e + (u) * jstep;                                                               \
     double val = __longlong_as_double(0x7ff8000000000000ll);   /* (lanes without a set: fails every compare below) */ \
-    if (i < nj) {                                                                                   \
+    if (j < a.m) {                                                                                  \
       double sum = acc[i];                                                                          \
       if constexpr (FIXED) {   /* u64 -> double, one rounding: hi * 2^32 + lo as a single fma */             \
         const unsigned long long b_ = (unsigned long long)__double_as_longlong(sum);                \
@@ -1218,9 +1260,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
       }                                                                                             \
       acc[i] = 0.0;                                                                                 \
       val = alpha * (sum * kwv[u].y) + a.beta * kwv[u].x;                                           \
-      if (PH_SC_ABL(6)) __hip_atomic_store(&a.S[(int64_t)c * a.lds + j0 + i], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* sc1 */ \
-      else if (PH_SC_ABL(7)) a.S[(int64_t)c * a.lds + j0 + i] = val;                                  \
-      else if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j0 + i]);  \
+      if (PH_SC_ABL(6)) __hip_atomic_store(&a.S[(int64_t)c * a.lds + j], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* sc1 */ \
+      else if (PH_SC_ABL(7)) a.S[(int64_t)c * a.lds + j] = val;                                     \
+      else if (!PH_SC_ABL(3)) __builtin_nontemporal_store(val, &a.S[(int64_t)c * a.lds + j]);       \
       /* the three flags, cheaply (the epilogue is bound by its vector instructions): the smallest score and the */  \
       /* smallest magnitude by v_min_f64 (which skips NaN), NaN by one compare counted into a lane counter */        \
       vmin = min_f64(vmin, val);                                                                    \
@@ -1247,11 +1289,11 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   }
 #define PLAIDHIP_CHUNK_EPILOGUE()                                                                  \
   {                                                                                                 \
-    /* all factors are awaited before the first store: one whose use is skipped (i >= nj) would stay "pending" in */ \
+    /* all factors are awaited before the first store: one whose use is skipped (no set in the slot) would stay "pending" in */ \
     /* hipcc's bookkeeping, and the next write to its register would wait with vmcnt(0) -- for the stores' acks */   \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) asm volatile("" : "+v"(kwv[u]));          \
-    int tid_e = tid;                                                                                \
-    asm volatile("" : "+v"(tid_e));                                                                 \
+    int tid_e = tid, jb_e = jb;                                                                     \
+    asm volatile("" : "+v"(tid_e), "+v"(jb_e));                                                     \
     _Pragma("unroll") for (int u = 0; u < kEpiSets; ++u) {                                          \
       PLAIDHIP_EPI_ONE(u)                                                                           \
     }                                                                                               \
@@ -1366,25 +1408,30 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     if constexpr (FIXED)   // one rounding to the fixed-point grid
       v = __longlong_as_double((long long)__double2ull_rn(v * fx_scale));
     const bool n1_loads = c1 < a.n, n2_loads = c2 < a.n && q12 > q02;
-    // requests for the items behind this one (before the walk's own loads: vmcnt retires in order)
-    if (n1_loads) PLAIDHIP_ASM_LOAD_SEG(a.seg + (int64_t)chunk1 * a.g + gene1);
-    if (n2_loads) {
-      int qi; bool hv;
-      PLAIDHIP_ITEM_MINE(r2, q02, q12, qi, hv)
-      PLAIDHIP_ASM_LOAD_CELL(a.Xi + qi, a.Xx + qi);
+    // requests for the items behind this one: BEHIND the walk's first 48 id loads (a wavefront's loads return in order, and two
+    // of these miss to HBM: in front of the id loads they kept every wavefront from its first ids for 9k cycles per item)
+#define PLAIDHIP_ISSUE_PREFETCH()                                                        \
+    {                                                                                    \
+      if (n1_loads) PLAIDHIP_ASM_LOAD_SEG(a.seg + (int64_t)chunk1 * a.g + gene1);        \
+      if (n2_loads) {                                                                    \
+        int qi; bool hv;                                                                 \
+        PLAIDHIP_ITEM_MINE(r2, q02, q12, qi, hv)                                         \
+        PLAIDHIP_ASM_LOAD_CELL(a.Xi + qi, a.Xx + qi);                                    \
+      }                                                                                  \
     }
-#define PLAIDHIP_AFTER_STAGE()
     PH_SC_STAMP(0);
     if (__ballot(have) != 0ull && !PH_SC_ABL(5)) {   // (a wavefront without a value in this round has nothing to apply)
       PLAIDHIP_WALK_SEGMENTS()
+    } else {
+      PLAIDHIP_ISSUE_PREFETCH()
     }
-#undef PLAIDHIP_AFTER_STAGE
+#undef PLAIDHIP_ISSUE_PREFETCH
     int s0_1, s1_1, gene2, xlo, xhi;
     PLAIDHIP_ASM_TAKE(s0_1, s1_1, gene2, xlo, xhi);   // (the walk has consumed every load of its own: nothing else to wait for)
     PH_SC_STAMP(1);
     if (rr + 1 >= PLAIDHIP_ITEM_ROUNDS(q0, q1)) {   // last round of this (column, chunk): scale and write the chunk's scores
-      const int j0 = chunk * a.ch;
-      const int nj = (a.m - j0) < a.ch ? (a.m - j0) : a.ch;
+      const int jb = chunk * BLOCK + tid;   // the set of this thread's slot `tid`; slot tid + u * BLOCK holds set jb + u * jstep
+      const int jstep = a.nch * BLOCK;
       double med_lo = 0.0, med_hi = 0.0;
       bool med_iz = false;
       unsigned long long* med_slice = nullptr;

@@ -230,6 +230,13 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _collective(group):
+    """whether the cross-shard reductions go through the process group: whenever one is initialised -- a group of ONE rank
+    included, so that a single GPU runs the very RCCL calls (device tensors, int32 MAX / fp64 SUM) the 8-GPU job makes"""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
                   group=None, x_is_ranks=False):
     """plaid() body (R/plaid.R:73-85) on this rank's sample shard; returns the local
@@ -239,10 +246,10 @@ def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=
     flags = engine.new_flags()
     S = engine.spmm(X_local, stat, alpha, beta, alpha_div, flags, ranks=x_is_ranks, normalize=normalize)
     if normalize:
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)       # min(x) == 0 over all samples
         med, red = engine.medians(S, flags)
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)         # mean(medx) over all samples
         engine.shift(S, med, red)
     return S
@@ -256,10 +263,10 @@ def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, 
     flags = engine.new_flags()
     S = engine.spmm_csc(X_local, stat, alpha, beta, alpha_div, flags, values, rank_weights=rank_weights, normalize=normalize)
     if normalize:
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
         med, red = engine.medians(S, flags)
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
         engine.shift(S, med, red)
     return S
@@ -272,7 +279,7 @@ def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
     import torch.distributed as dist
     world, _ = _world(group)
     Rx, gmax = engine.sparse_colranks(X_local, "average", False, 1.0 + alpha)
-    if world > 1:
+    if _collective(group):
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group, rank_weights=True)
 
@@ -303,7 +310,7 @@ def sharded_ssgsea(engine, X_local, alpha=0.0, group=None):
     import torch.distributed as dist
     world, _ = _world(group)
     R, gmax = engine.colranks(X_local, "average", False, 1.0 + alpha)
-    if world > 1:
+    if _collective(group):
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     return sharded_plaid(engine, R, "mean", True, 1.0, -0.5, gmax, group, x_is_ranks=(alpha == 0.0))
 
@@ -334,7 +341,7 @@ def sharded_plaid_test(engine, X_local, y_local, Gp, tests=("one", "two", "lm"),
     # rank holding the bad label must not be the only one that leaves before the collectives below
     y_ok = torch.tensor([1 if (y_local.numel() == 0 or bool(((y_local == 0) | (y_local == 1)).all())) else 0], dtype=torch.int32,
                         device=y_local.device)
-    if world > 1:
+    if _collective(group):
         dist.all_reduce(y_ok, op=dist.ReduceOp.MIN, group=group)
     if not bool(y_ok.item()):
         raise ValueError("elements of y must be 0 or 1")                      # R/plaid.R:394
@@ -343,7 +350,7 @@ def sharded_plaid_test(engine, X_local, y_local, Gp, tests=("one", "two", "lm"),
     cnt = torch.stack([(y_local == 0).sum(), (y_local == 1).sum()]).to(torch.float64)
 
     def allsum(t_):
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(t_, op=dist.ReduceOp.SUM, group=group)
         return t_
 

@@ -116,11 +116,12 @@ def main():
             torch.cuda.synchronize()
             if dbg is not None and a.kernel == "c3" and it == a.iters - 1:
                 d = dbg.cpu().numpy()[: 256 * 16 * 8].reshape(256, 16, 8).astype(float)
-                tot = d[:, :, :5].sum(axis=2).mean()
-                names = ["between", "walk", "barrier1", "epilogue", "barrier2"]
+                tot = d[:, :, :8].sum(axis=2).mean()
+                names = ["between", "walk: prefetch wait", "barrier1", "epilogue", "barrier2", "walk: first ids in hand",
+                         "walk: static pipeline", "walk: further segments"]
                 print("  scatter stamps (cycles per launch, mean over workgroups x waves): " +
                       "  ".join(f"{nm} {d[:, :, k].mean():.0f} ({100 * d[:, :, k].mean() / tot:.0f}%)" for k, nm in enumerate(names)))
-                print("  walk cycles by wave, WG 0:", d[0, :, 1].astype(int).tolist())
+                print("  walk cycles by wave, WG 0:", (d[0, :, 1] + d[0, :, 5] + d[0, :, 6] + d[0, :, 7]).astype(int).tolist())
                 for k, nm in enumerate(names):
                     print(f"  {nm} by wave, WG 5:", d[5, :, k].astype(int).tolist())
             print(f"{a.kernel} ({g}x{n}x{m}): rank {e0.elapsed_time(e1):.3f} ms  spmm {e1.elapsed_time(e2):.3f} ms  "
