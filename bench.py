@@ -216,17 +216,25 @@ def launch_ranks(a, argv):
     env.setdefault("OMP_NUM_THREADS", str(max(1, _cpu_threads() // max(1, a.gpus))))
     cmd = launcher_argv(a.gpus, argv)
     print("[bench] starting ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True,
+                              timeout=float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "3000")))
+    except subprocess.TimeoutExpired as exc:     # a hung rank: say so instead of waiting for the driver's own clock
+        print(f"[bench] the ranks did not finish within {exc.timeout:.0f} s (BENCH_LAUNCH_TIMEOUT)", file=sys.stderr)
+        return 4
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     for ln in lines[:-1]:
         print(ln, file=sys.stderr)
     if lines:
         print(lines[-1], flush=True)
-    if proc.returncode == 0 and lines:
+    if proc.returncode == 0:
         try:
-            got = json.loads(lines[-1]).get("n_gpus")
+            got = json.loads(lines[-1]).get("n_gpus") if lines else None
         except ValueError:
             got = None
+        if not lines or got is None:              # exit status 0 and no line would read as a successful, empty run
+            print("[bench] the ranks exited with status 0 but printed no JSON line", file=sys.stderr)
+            return 3
         if got != a.gpus:
             print(f"[bench] the ranks reported n_gpus = {got}, --gpus asked for {a.gpus}", file=sys.stderr)
             return 3
@@ -930,7 +938,11 @@ def run_c4(a, env):
         "kernels": {
             "colranks": _roof("colranks_bucket_kernel<1024,20>", 16.0 * g * n, rank_ms,
                               _traffic("colranks_bucket_kernel<1024,20>", f"{g}xN", n)),
-            "crossprod": _fp64_roof(_roof("spmm_colpair_f64", spmm_alg, spmm_ms, _traffic("spmm_colpair_f64", f"{g}xNx{m}", n),
+            # (with the medians selected in the launch the timed phase is the fused call: the 256-column calibration launch,
+            #  its standalone medians, the calibration and the classifying kernel -- labelled and priced as that kernel)
+            "crossprod": _fp64_roof(_roof("spmm_colpair_f64<med> (+ 256-column calibration)" if fused_info else "spmm_colpair_f64",
+                                          spmm_alg, spmm_ms,
+                                          _traffic("spmm_colpair_f64<med>" if fused_info else "spmm_colpair_f64", f"{g}xNx{m}", n),
                                           lds_bytes=float(info["padded_slots"]) * 8.0 * n), 2.0 * z * n),
             "col_medians": (_roof("median_select_kernel + col_medians_stream_kernel (unresolved columns)", 8.0 * m * n, med_ms, None,
                                   extra={"note": "algorithmic bytes are those of the full sweep the fused crossprod made unnecessary: "

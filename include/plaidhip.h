@@ -264,7 +264,11 @@ int plaidhip_dev_col_medians(plaidhip_ctx* ctx, const void* S, int64_t lds, int3
  * columns) are read again by the standalone kernel.  The 40 GB second pass of config 3 is gone.  Call it after the flag
  * words are final (a sample-sharded host all-reduces them in between) and before S is changed; with any other S, or after
  * an ineligible crossprod, it simply is plaidhip_dev_col_medians.  nnz must be the caller's true count (>= 0) for the
- * fused form to apply.  Stream-ordered, no host round trip.                                                          */
+ * fused form to apply.  Stream-ordered, no host round trip -- except that the context's candidate scratch is (re)allocated
+ * when a call needs more than the last one did (hipStreamSynchronize + hipFree + hipMalloc: NOT capture-safe; make the
+ * first call of a shape outside a stream capture).  Memory: 8 bytes per candidate slot, min(8,192, max(1,024, 0.16 m))
+ * slots per column, + 16 bytes per (column, wavefront slice): at most 0.2 x the bytes of S, kept by the context until
+ * plaidhip_dev_fused_medians_discard or plaidhip_destroy.  If that allocation fails the plain crossprod runs.             */
 int plaidhip_dev_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* Xp, const void* Xi,
                                     const void* Xx, int32_t n, int64_t nnz, int stat, double alpha, const void* alpha_div,
                                     double beta, void* S, int64_t lds, void* flags, const void* rmax);
@@ -275,7 +279,12 @@ int plaidhip_dev_col_medians_resume(plaidhip_ctx* ctx, const void* S, int64_t ld
  * scores (PLAIDHIP_OPT_FUSED_MEDIANS overrides the size rule), the workgroup of a column pair computes the pair's mean
  * scores from the X it stages (no extra pass over X), and the tile ends of the last gene slice classify the scores they
  * write against the bracket around (mean + calibrated offset) exactly like the sparse form above.  Finish with
- * plaidhip_dev_col_medians_resume (or ..._resume_token); with an ineligible call it is the plain crossprod.            */
+ * plaidhip_dev_col_medians_resume (or ..._resume_token); with an ineligible call it is the plain crossprod.
+ * Eligible means ALL of: PLAIDHIP_OPT_FUSED_MEDIANS != 2; m > 6,144; n >= 1,024 (four times the 256 calibration columns);
+ * m * n >= 1e9 or PLAIDHIP_OPT_FUSED_MEDIANS == 1; flags != NULL; the fp64 pair kernel takes the input -- not the u16 / fp32
+ * stagings of rank inputs (plaidhip_dev_spmm_ranks_f64, PLAIDHIP_OPT_RANKS_F32 >= 1 with a one-slice plan) or of
+ * PLAIDHIP_PRECISION_MIXED, not the MFMA backend (PLAIDHIP_OPT_SPMM_DENSE_KERNEL == 3), not the one-column kernel.
+ * Scratch, its memory cost and the capture caveat: as for plaidhip_dev_spmm_csc_fused_f64 above.                        */
 int plaidhip_dev_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const void* X, int64_t ldx, int32_t n,
                                       int stat, double alpha, const void* alpha_div, double beta, void* S, int64_t lds,
                                       void* flags);
@@ -284,7 +293,8 @@ int plaidhip_dev_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset*
  * takes the TOKEN of the fused launch (plaidhip_dev_fused_medians_info, info[3], right after the crossprod; 0 = the plain
  * route ran, nothing is pending) and resumes with it: the candidates are used only if they are still the pending ones of
  * exactly that launch; any other token (0, stale) runs plaidhip_dev_col_medians -- always correct -- and drops what was
- * pending.  plaidhip_dev_fused_medians_discard drops it explicitly (a caller that will not normalise after all).       */
+ * pending.  plaidhip_dev_fused_medians_discard drops it explicitly (a caller that will not normalise after all) and
+ * releases the candidate scratch (it waits for the context's stream first).                                             */
 int plaidhip_dev_col_medians_resume_token(plaidhip_ctx* ctx, int64_t token, const void* S, int64_t lds, int32_t m, int32_t n,
                                           int ignore_zero, const void* flags, void* med);
 int plaidhip_dev_fused_medians_discard(plaidhip_ctx* ctx);

@@ -596,6 +596,15 @@ int plaidhip_dev_fused_medians_discard(plaidhip_ctx* ctx) try {
   PH_CTX(ctx);
   ctx->fmed.valid = false;
   ctx->fmed.token = 0;
+  // the caller will not normalise: the candidate scratch (up to 0.2 x the bytes of S) goes back too.  (Stream-ordered work
+  // may still read it: wait for the stream first.  The next fused crossprod allocates again.)
+  if (ctx->fmed_buf != nullptr) {
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_HIP(hipFree(ctx->fmed_buf));
+    ctx->fmed_buf = nullptr;
+    ctx->fmed_bytes = 0;
+    ctx->fmed = decltype(ctx->fmed){};
+  }
   return PLAIDHIP_OK;
 } catch (...) { return plaidhip::on_exception(); }
 

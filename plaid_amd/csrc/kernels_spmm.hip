@@ -2220,9 +2220,10 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
   a.nslices = (int32_t)pl.slices.size();
   a.ktiles = pl.ktiles;
   a.nt_store = nt_store_mode(ctx, gs);
-  // the partial sums of the slice before are read with non-temporal loads when the workgroups' scratches (32 per XCD)
-  // outgrow the 4 MiB L2 -- read once and dead, the lines then do not displace the index lists (50,000 sets: -4 % kernel
-  // time; 5,000 sets, scratch L2-resident: +3 %, so not there)
+  // the partial sums of the slice before are read with non-temporal loads when the scratches of an XCD's 32 workgroups
+  // (1 KiB per tile each) come to more than 8 MiB -- twice the XCD's 4 MiB L2, where they are read once and dead and would
+  // only displace the index lists (50,000 sets, 12.5 MiB: -4 % kernel time; 5,000 sets, L2-resident scratch: +3 %, so not
+  // there; the threshold sits between the two measured shapes)
   const bool part_nt = a.nslices > 1 && (int64_t)(pl.ktiles + 1) * 1024 * 32 > (8ll << 20);
   a.slices = pl.d_slices;
   a.wave_tile_off = pl.d_wave_tile_off;
@@ -2454,6 +2455,17 @@ int launch_spmm_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const int
   return launch_colgather<true>(ctx, gs, a);
 }
 
+// Candidate slots per column of the fused-medians scratch.  The bracket catches 1-5 % of a column's m scores (half width 2.3 x
+// the 90th percentile of the calibration columns' deviations) and median_select_kernel takes at most 4,096 of them, so the
+// slices of a column hold 16 % of m between them, 1,024 at least and 8,192 at most (round 5 reserved 8,192 whatever m: 64 KB
+// per column -- more than the column's own scores below 8,192 sets, 8 GB for a 125,000-cell shard).  A slice that
+// overflows sends its column to the standalone kernel (the counts say so), so the size is a speed matter only.  The scratch
+// is 8 bytes per slot + 16 bytes per (column, slice): <= 0.2 x the bytes of S.
+static int32_t fused_cand_per_column(int32_t m) {
+  const int64_t want = ((int64_t)m * 16 + 99) / 100;
+  return (int32_t)std::min<int64_t>(8192, std::max<int64_t>(1024, want));
+}
+
 // ---- the sparse crossprod that also selects the column medians of its result (normalize_medians, R/plaid.R:561-572) ----
 // Applies when the scatter kernel takes the input and the result has more sets per column than the register-resident median
 // kernel takes (m > 6,144: there the standalone median kernel is a second pass over the whole score matrix -- 40 GB at
@@ -2477,9 +2489,8 @@ int launch_spmm_csc_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, con
   if (nnz_choice < 0) nnz_choice = nnz;   // (a shard of a larger call: the density of the WHOLE matrix picks the kernel)
   if (sm == 0 && nnz_choice >= 0) sm = (nnz_choice * 8 < (int64_t)gs->g * n) ? 1 : 2;
   const int32_t nslice = sp.nch * (kScatterBlock / 64);
-  // candidate slots per (column, chunk, wavefront): 8,192 per column over its slices (twice what the selection takes: the
-  // chunk of the largest sets holds most of the scores near the median)
-  const int32_t kCapC = std::max<int32_t>(64, (8192 / std::max<int32_t>(nslice, 1)) & ~15);
+  // candidate slots per (column, chunk, wavefront): fused_cand_per_column(m) per column over its slices
+  const int32_t kCapC = std::max<int32_t>(32, (fused_cand_per_column(gs->m) / std::max<int32_t>(nslice, 1)) & ~15);
   // worth it from ~1e9 scores on (measured: the classifying epilogue costs 0.4 ms per 1e9 scores and the calibration
   // ~0.45 ms per call, the standalone median kernel 1.4 ms per 1e9 scores -- but it has a floor of ~1 ms as soon as a few
   // hundred columns are left to it; at 6e8 scores, the reference's pbmc3k shape, the plain pair is faster: 6.5 against
@@ -2561,7 +2572,7 @@ int launch_spmm_dense_fused_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   ctx->fmed.n = 0;
   constexpr int K = 256;
   constexpr int32_t nslice = 16;                 // wavefronts of the pair kernel's workgroup
-  const int32_t kCapC = 8192 / nslice;           // candidate slots per (column, wavefront): 8,192 per column
+  const int32_t kCapC = std::max<int32_t>(32, (fused_cand_per_column(gs->m) / nslice) & ~15);   // candidate slots per (column, wavefront)
   const bool one_slice_16 = gs->slices.size() == 1 && gs->slices[0].waves == 16;
   const bool compact = (x_kind != PLAIDHIP_X_ANY && ctx->opt_ranks_f32 >= 1 && one_slice_16) ||
                        (ctx->precision == PLAIDHIP_PRECISION_MIXED && one_slice_16);

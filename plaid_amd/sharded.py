@@ -715,6 +715,11 @@ def _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, sh
         files.close_maps()
     except Exception as exc:
         failure = exc
+    except BaseException:
+        # KeyboardInterrupt / SystemExit on this rank: no collective any more (the others time out in all_ok), but the
+        # tens of GB this rank may have put under /dev/shm must not outlive it
+        files.unlink()
+        raise
     bad = all_ok(failure)                            # (and the barrier before the root maps what the others wrote)
     if bad is not None:
         files.unlink()                               # (no names are left behind in /dev/shm; every rank raises alike)
