@@ -306,6 +306,13 @@ int plaidhip_dev_fused_medians_info(plaidhip_ctx* ctx, int64_t info[4]);
 int plaidhip_dev_sum(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[2]: sum, #non-NaN */);
 int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t m, int32_t n,
                                const void* med, double add, const void* red);
+/* phase 3 fused with an fp64 -> fp32 cast into ANOTHER matrix (float out[ldo * n]): out = (float)((S - med[col]) + add), S left
+ * as it is.  What a sample-sharded job sends to the root when the assembled result must be fp32 to fit one GPU (config 5:
+ * 1e6 cells x 50,000 sets = 400 GB in fp64): one read of S and a half-size write instead of shift (read + write) followed by a
+ * cast (read + half-size write).  Bit-identical to plaidhip_dev_shift_columns followed by a conversion to float.
+ * R/plaid.R:572 (the sweep) and :110-119 (the chunks the reference assembles).                                          */
+int plaidhip_dev_shift_columns_cast_f32(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, const void* med,
+                                        double add, const void* red, void* out, int64_t ldo);
 /* max over a device double vector (global max(rX), R/plaid.R:251) */
 int plaidhip_dev_max(plaidhip_ctx* ctx, const void* v, int64_t count, void* out /* double[1] */);
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     "plaidhip_dev_fused_medians_info": [_vp, C.POINTER(_i64)],
     "plaidhip_dev_sum": [_vp, _vp, _i64, _vp],
     "plaidhip_dev_shift_columns": [_vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp],
+    "plaidhip_dev_shift_columns_cast_f32": [_vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp, _vp, _i64],
     "plaidhip_dev_max": [_vp, _vp, _i64, _vp],
     "plaidhip_plaid_dense": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],
     "plaidhip_plaid_csc": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _int, _int, _vp],

@@ -711,6 +711,15 @@ int plaidhip_dev_shift_columns(plaidhip_ctx* ctx, void* S, int64_t lds, int32_t 
                               static_cast<const double*>(red));
 } catch (...) { return plaidhip::on_exception(); }
 
+int plaidhip_dev_shift_columns_cast_f32(plaidhip_ctx* ctx, const void* S, int64_t lds, int32_t m, int32_t n, const void* med,
+                                        double add, const void* red, void* out, int64_t ldo) try {
+  PH_CTX(ctx);
+  PH_REQUIRE(m >= 0 && n >= 0 && lds >= m && ldo >= m, "shift_columns_cast_f32: bad dims");
+  PH_REQUIRE((m == 0 || n == 0) || (S != nullptr && med != nullptr && out != nullptr), "shift_columns_cast_f32: null argument");
+  return launch_shift_columns_cast_f32(ctx, static_cast<const double*>(S), lds, m, n, static_cast<const double*>(med), add,
+                                       static_cast<const double*>(red), static_cast<float*>(out), ldo);
+} catch (...) { return plaidhip::on_exception(); }
+
 // ---- host-level pipelines ---------------------------------------------------------------
 
 

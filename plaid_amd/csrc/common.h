@@ -417,6 +417,8 @@ int launch_sum(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_max(plaidhip_ctx* ctx, const double* v, int64_t count, double* out);
 int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, int32_t n,
                          const double* med, double add, const double* red);
+int launch_shift_columns_cast_f32(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, const double* med,
+                                  double add, const double* red, float* out, int64_t ldo);
 
 // element-wise / column helpers (replaid.ucell / aucell / scse)
 int launch_map(plaidhip_ctx* ctx, double* v, int64_t count, int op, double p0, const double* scalar);

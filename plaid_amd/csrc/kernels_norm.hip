@@ -539,6 +539,55 @@ shift_columns_kernel(double* __restrict__ S, int64_t lds, int32_t m, int32_t n,
   }
 }
 
+// (x - med[col]) + mean(med) written as FLOAT into another matrix: the last step of normalize_medians (R/plaid.R:572) fused
+// with the cast a sample-sharded job makes anyway before its scores travel to the root -- config 5's 1e6 x 50,000 result is
+// 400 GB in fp64, more than one GPU holds, so the gather carries fp32 (sharded.gather_scores(dtype = float32)).  S itself
+// stays as the crossprod wrote it: one read of S and a half-size write replace the read + write of the shift and the read +
+// half-size write of the cast.  16-byte loads (two scores), 8-byte stores, four loads in flight per thread; the rounding
+// is that of a plain fp64 -> fp32 conversion of the shifted value -- bit-identical to shift_columns followed by a cast.
+__global__ void __launch_bounds__(256)
+shift_columns_cast_f32_kernel(const double* __restrict__ S, int64_t lds, int32_t m, int32_t n, const double* __restrict__ med,
+                              double add, const double* __restrict__ red, float* __restrict__ out, int64_t ldo) {
+  typedef double f64x2_s __attribute__((ext_vector_type(2)));
+  typedef float f32x2_s __attribute__((ext_vector_type(2)));
+  constexpr int UN = 4;
+  if (red != nullptr) add = red[0] / red[1];
+  for (int c = blockIdx.y; c < n; c += gridDim.y) {
+    const double* sc = S + (int64_t)c * lds;
+    float* oc = out + (int64_t)c * ldo;
+    const double md = med[c];
+    // pairs are taken where BOTH the fp64 source (16 bytes) and the fp32 destination (8 bytes) are aligned; else by element
+    const bool pairs_ok = ((reinterpret_cast<uintptr_t>(sc) & 15u) == 0u) && ((reinterpret_cast<uintptr_t>(oc) & 7u) == 0u);
+    if (!pairs_ok) {
+      for (int i = blockIdx.x * 256 + (int)threadIdx.x; i < m; i += gridDim.x * 256)
+        oc[i] = (float)((sc[i] - md) + add);
+      continue;
+    }
+    const int npairs = m >> 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (m & 1)) oc[m - 1] = (float)((sc[m - 1] - md) + add);
+    const f64x2_s* p = reinterpret_cast<const f64x2_s*>(sc);
+    f32x2_s* q = reinterpret_cast<f32x2_s*>(oc);
+    for (int base = blockIdx.x * 256 * UN; base < npairs; base += gridDim.x * 256 * UN) {
+      f64x2_s v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = base + u * 256 + (int)threadIdx.x;
+        v[u] = __builtin_nontemporal_load(p + (i < npairs ? i : npairs - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = base + u * 256 + (int)threadIdx.x;
+        if (i < npairs) {
+          f32x2_s r;
+          r.x = (float)((v[u].x - md) + add);
+          r.y = (float)((v[u].y - md) + add);
+          __builtin_nontemporal_store(r, q + i);
+        }
+      }
+    }
+  }
+}
+
 // ---- element-wise / column helpers for the rank-transform callers -------------------------
 // (replaid.ucell R/plaid.R:276-282, replaid.aucell :304-309, replaid.scse :155-190)
 __global__ void __launch_bounds__(256)
@@ -2097,6 +2146,18 @@ int launch_shift_columns(plaidhip_ctx* ctx, double* S, int64_t lds, int32_t m, i
 #endif
   if (bx > bx_cap) bx = bx_cap;
   hipLaunchKernelGGL(shift_columns_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, S, lds, m, n, med, add, red);
+  PH_HIP(hipGetLastError());
+  return PLAIDHIP_OK;
+}
+
+int launch_shift_columns_cast_f32(plaidhip_ctx* ctx, const double* S, int64_t lds, int32_t m, int32_t n, const double* med,
+                                  double add, const double* red, float* out, int64_t ldo) {
+  if (n == 0 || m == 0) return PLAIDHIP_OK;
+  int bx = (m / 2 + 256 * 4 - 1) / (256 * 4);
+  if (bx < 1) bx = 1;
+  if (bx > 32) bx = 32;
+  const int by = n <= 65535 ? n : 2048;
+  hipLaunchKernelGGL(shift_columns_cast_f32_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, S, lds, m, n, med, add, red, out, ldo);
   PH_HIP(hipGetLastError());
   return PLAIDHIP_OK;
 }

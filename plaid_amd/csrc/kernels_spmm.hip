@@ -31,8 +31,9 @@ namespace plaidhip {
 // diagnostic kernel variants: only in the tools/ build (make diag, -DPLAIDHIP_DIAG); the product library
 // instantiates the plain kernels alone
 #ifdef PLAIDHIP_DIAG
-static int g_ablate = 0;
-static unsigned long long* g_dbg = nullptr;
+#define PH_DIAG_SECTION 1
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #else
 static constexpr int g_ablate = 0;
 #endif
@@ -142,10 +143,9 @@ __device__ __forceinline__ double lds_at(uint32_t byte_off) {
 //   scores by construction and exist to price one pipe at a time.
 // (the ablation / stamp arms exist in the tools/ build only: behind PLAIDHIP_DIAG at the macro, the product kernel reads plain)
 #ifdef PLAIDHIP_DIAG
-#define PH_COL_PF (ABLATE != 3)
-#define PH_COL_STAMP (ABLATE == 4)
-#define PH_COL_LDS_AT(o_) lds_at<ABLATE>(o_)
-#define PH_COL_SYNTH_IDS (ABLATE == 2)
+#define PH_DIAG_SECTION 2
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #else
 #define PH_COL_PF true
 #define PH_COL_STAMP false
@@ -656,26 +656,17 @@ spmm_colpair_f64(SpmmPairArgs a) {
         const cptr_i32 wtile_end = (cptr_i32)sl->wtile_end;
         gptr_u8 ibase = (gptr_u8)sl->tile_idx + (int64_t)ch_begin * 1024;  // uniform
 #ifdef PLAIDHIP_DIAG
-        const gptr_u8 ibase0 = ibase;
+#define PH_DIAG_SECTION 3
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
         uint32_t lane_o = (uint32_t)lane;
         asm volatile("" : "+v"(lane_o));
         const uint32_t ioff = lane_o * 16u;
-#ifdef PLAIDHIP_DIAG   /* tools/ build only: ABL 2 = synthetic ids (no index stream), 6 = the same 2 KiB again (L1-resident) */
-#define PLAIDHIP_LOADQ(rel)                                                                          \
-  (ABL == 2 ? u32x4{lane_o | ((lane_o + 64u) << 16), (lane_o + 128u) | ((lane_o + 192u) << 16),       \
-                    (lane_o + 256u) | ((lane_o + 320u) << 16), (lane_o + 384u) | ((lane_o + 448u + (rel)) << 16)} \
-            : (ABL == 6 ? *(gptr_u32x4)(ibase0 + (int64_t)((rel) & 1) * 1024 + ioff)                   \
-                        : *(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff)))
-#define PH_PAIR_PSTORE (ABL != 5 && ABL != 9)   /* 5: no partial-sum round trip between slices; 9: loads only (wrong scores) */
-#define PH_PAIR_PLOAD (ABL != 5 && ABL != 8)    /* 8: stores only */
-#define PH_PAIR_PSLOT(k_) (ABL == 10 ? ((k_) & 3) : (k_))   /* 10: a four-tile scratch per workgroup: always L2-resident */
-#define PH_PAIR_PST_NT (ABL == 11 || ABL == 12)   /* 11: non-temporal partial stores and loads, 12: stores only, 13: loads only */
-#define PH_PAIR_PLD_NT (ABL == 11 || ABL == 13 || ABL == 14)
-#define PH_PAIR_PST_SC1 (ABL == 14 || ABL == 15)   /* 14: agent-scope (sc1) 8-byte stores + nt loads, 15: sc1 stores + sc1 loads */
-#define PH_PAIR_PLD_SC1 (ABL == 15)
-#define PH_PAIR_SST_SC1 (ABL == 16)   /* 16: score stores with agent scope (sc1: the lines do not stay in L2) */
-#define PH_PAIR_META (ABL != 7)       /* 7: no per-tile metadata loads (wrong scores) */
+#ifdef PLAIDHIP_DIAG
+#define PH_DIAG_SECTION 4
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #else
 #define PLAIDHIP_LOADQ(rel) (*(gptr_u32x4)(ibase + (int64_t)(rel) * 1024 + ioff))
 #define PH_PAIR_PSTORE true
@@ -978,21 +969,16 @@ struct ScatterArgs {
 };
 
 #ifdef PLAIDHIP_DIAG
-#define PH_SC_ABL(k) (a.abl == (k) || (a.abl == 4 && ((k) == 1 || (k) == 2)))
+#define PH_DIAG_SECTION 5
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #else
 #define PH_SC_ABL(k) false
 #endif
 #ifdef PLAIDHIP_DIAG
-#define PH_SC_STAMP(k)                                                                \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
-    t_ph[k] += t_ - t_last;                                                            \
-    t_last = t_;                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-  } while (0)
-#define PH_SC_STAMP_IDS(x) do { asm volatile("" : "+v"(x)); PH_SC_STAMP(5); } while (0)
+#define PH_DIAG_SECTION 6
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #else
 #define PH_SC_STAMP(k) do { } while (0)
 #define PH_SC_STAMP_IDS(x) do { } while (0)
@@ -1369,8 +1355,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     qi_ = (q0_) + (have_ ? lo_ + i_ : 0);                                                               \
   }
 #ifdef PLAIDHIP_DIAG
-  unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#define PH_DIAG_SECTION 7
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   // current item, the next one (n1: gene / value here, segment range on its way during the current walk) and the one
   // after (n2: gene / value on their way)
@@ -1469,8 +1456,9 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #undef PLAIDHIP_ASM_LOAD_SEG
 #undef PLAIDHIP_ASM_LOAD_CELL
 #ifdef PLAIDHIP_DIAG
-  if (a.dbg != nullptr && (tid & 63) == 0)
-    for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = t_ph[k];
+#define PH_DIAG_SECTION 8
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
 #undef PLAIDHIP_WALK_SEGMENTS
 #undef PLAIDHIP_S0_OF
@@ -1544,8 +1532,9 @@ int launch_spmm_scatter_csc_f64(plaidhip_ctx* ctx, const plaidhip_geneset* gs, c
   a.lds = lds;
   a.flags = flags;
 #ifdef PLAIDHIP_DIAG
-  a.dbg = g_dbg;
-  a.abl = g_ablate > 100 ? g_ablate - 100 : 0;
+#define PH_DIAG_SECTION 9
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   const size_t smem = (size_t)(sp.ch + kScatterTrash) * sizeof(double);
   {
@@ -1832,12 +1821,9 @@ static int launch_colpair_mixed(plaidhip_ctx* ctx, const plaidhip_geneset* gs, S
   const int npairs = (a.n + 1) / 2;
   if (grid > npairs) grid = npairs;
 #ifdef PLAIDHIP_DIAG
-  if (g_ablate == 4) {   // in-kernel stamps
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_mixed<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL(spmm_colpair_mixed<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  } else
+#define PH_DIAG_SECTION 10
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   {
     hipLaunchKernelGGL(spmm_colpair_mixed<false>, dim3(grid), dim3(1024), smem, ctx->stream, a);
@@ -2162,11 +2148,9 @@ static int launch_colquad(plaidhip_ctx* ctx, const plaidhip_geneset* gs, SpmmArg
   const int nquads = (a.n + 3) / 4;
   if (grid > nquads) grid = nquads;
 #ifdef PLAIDHIP_DIAG
-  if (g_ablate == 4) {   // in-kernel stamps
-    qa.s.dbg = g_dbg;
-    PH_FULL_LDS(ctx, (&spmm_colquad_u16<true>));
-    hipLaunchKernelGGL((spmm_colquad_u16<true>), dim3(grid), dim3(1024), smem, ctx->stream, qa);
-  } else
+#define PH_DIAG_SECTION 11
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   {
     PH_FULL_LDS(ctx, (&spmm_colquad_u16<false>));
@@ -2266,21 +2250,9 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
     hipLaunchKernelGGL((spmm_colpair_f64<false, 0, true>), dim3(grid), dim3(1024), smem, ctx->stream, a);
   }
 #ifdef PLAIDHIP_DIAG
-#define PH_PAIR_ABL_ARM(N)                                                                               \
-  else if (g_ablate == N) {   /* tools/ only, wrong scores: 2 no index loads, 5 no partial-sum round trip, 6 index loads */ \
-    a.dbg = g_dbg;            /* always hit L1, 7 no tile metadata, 8 partial stores only, 9 partial loads only, 10 a   */ \
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true, N>),               /* four-tile scratch */ \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));                   \
-    hipLaunchKernelGGL((spmm_colpair_f64<true, N>), dim3(grid), dim3(1024), smem, ctx->stream, a);        \
-  }
-  PH_PAIR_ABL_ARM(2) PH_PAIR_ABL_ARM(5) PH_PAIR_ABL_ARM(6) PH_PAIR_ABL_ARM(7) PH_PAIR_ABL_ARM(8) PH_PAIR_ABL_ARM(9) PH_PAIR_ABL_ARM(10) PH_PAIR_ABL_ARM(11) PH_PAIR_ABL_ARM(12) PH_PAIR_ABL_ARM(13) PH_PAIR_ABL_ARM(14) PH_PAIR_ABL_ARM(15) PH_PAIR_ABL_ARM(16)
-#undef PH_PAIR_ABL_ARM
-  else if (g_ablate == 4) {   // in-kernel stamps (tools/ only)
-    a.dbg = g_dbg;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colpair_f64<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL(spmm_colpair_f64<true>, dim3(grid), dim3(1024), smem, ctx->stream, a);
-  }
+#define PH_DIAG_SECTION 12
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   else if (part_nt) {
     PH_FULL_LDS(ctx, (&spmm_colpair_f64<false, 0, false, false, true>));
@@ -2293,7 +2265,9 @@ static int launch_colpair(plaidhip_ctx* ctx, const plaidhip_geneset* gs, const d
 }
 
 #ifdef PLAIDHIP_DIAG
-void debug_set_ablation(int mode, void* dbg) { g_ablate = mode; g_dbg = static_cast<unsigned long long*>(dbg); }
+#define PH_DIAG_SECTION 13
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
 
 template <bool CSC_X, int BLOCK>
@@ -2308,21 +2282,9 @@ static int launch_one(plaidhip_ctx* ctx, const plaidhip_slice& sl, SpmmArgs& a) 
   int grid = ctx->num_cu * per_cu;
   if (grid > a.n) grid = a.n;
 #ifdef PLAIDHIP_DIAG
-  if constexpr (!CSC_X && BLOCK >= 512) {
-    if (g_ablate != 0) {   // diagnostic kernels
-      a.dbg = g_dbg;
-#define PLAIDHIP_ABL(N)                                                                              \
-  if (g_ablate == N) {                                                                                \
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgather_f64<false, BLOCK, N>),   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));               \
-    hipLaunchKernelGGL((spmm_colgather_f64<false, BLOCK, N>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a); \
-  }
-      PLAIDHIP_ABL(1) PLAIDHIP_ABL(2) PLAIDHIP_ABL(3) PLAIDHIP_ABL(4)
-#undef PLAIDHIP_ABL
-      PH_HIP(hipGetLastError());
-      return PLAIDHIP_OK;
-    }
-  }
+#define PH_DIAG_SECTION 14
+#include "kernels_spmm_diag.inc"
+#undef PH_DIAG_SECTION
 #endif
   hipLaunchKernelGGL((spmm_colgather_f64<CSC_X, BLOCK>), dim3(grid), dim3(BLOCK), smem, ctx->stream, a);
   PH_HIP(hipGetLastError());

@@ -241,6 +241,11 @@ class Context:
         """x - med[col] + add; with `red` (device {sum, count}) add = sum/count on the device."""
         check(self.lib.plaidhip_dev_shift_columns(self.handle, S, lds, m, n, med, float(add), red))
 
+    def dev_shift_columns_cast_f32(self, S: int, lds: int, m: int, n: int, med: int, out: int, ldo: int, add: float = 0.0,
+                                   red: int | None = None):
+        """out (float32) = x - med[col] + add, S untouched: the shift fused with the cast a sharded gather makes"""
+        check(self.lib.plaidhip_dev_shift_columns_cast_f32(self.handle, S, lds, m, n, med, float(add), red, out, ldo))
+
     def dev_row_group_sums(self, A: int, ld: int, rows: int, n: int, y: int, sums: int):
         """per-row sums over the columns with y == 0 / y == 1 -> sums[2][rows] (plaid.test, R/plaid.R:407-408, 431)"""
         check(self.lib.plaidhip_dev_row_group_sums(self.handle, A, ld, rows, n, y, sums))

@@ -197,6 +197,18 @@ class HipPhaseEngine:
         if n > 0:
             self.ctx.dev_shift_columns(S.data_ptr(), m, m, n, med.data_ptr(), 0.0, red.data_ptr())
 
+    def shift_cast(self, S, med, red, out=None):
+        """(S - med[col] + mean(med)) as float32 into `out` (allocated when None); S stays as the crossprod wrote it.
+        S: (rows, m) float64 rows of a score block, med: the medians of exactly those rows, red: {sum, count} of ALL medians"""
+        self._same_stream()
+        n, m = S.shape
+        if out is None:
+            out = self.torch.empty((n, m), dtype=self.torch.float32, device=S.device)
+        if n > 0:
+            assert S.is_contiguous() and out.is_contiguous() and med.is_contiguous()
+            self.ctx.dev_shift_columns_cast_f32(S.data_ptr(), m, m, n, med.data_ptr(), out.data_ptr(), m, 0.0, red.data_ptr())
+        return out
+
 
     def row_group_sums(self, A, y):
         """A (n_local, rows) row-major == rows x n_local column-major; y int32 (n_local,) of 0 / 1 -> (2, rows) sums"""
@@ -238,9 +250,11 @@ def _collective(group):
 
 
 def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
-                  group=None, x_is_ranks=False):
+                  group=None, x_is_ranks=False, defer_shift=False):
     """plaid() body (R/plaid.R:73-85) on this rank's sample shard; returns the local
-    (n_local, m) score block.  Collective: every rank of `group` must call it."""
+    (n_local, m) score block.  Collective: every rank of `group` must call it.
+    defer_shift (with normalize): the sweep of R/plaid.R:572 is left to the gather -- returns (S un-shifted, med, red) for
+    gather_scores(..., dtype=float32, shift=(engine, med, red)), which applies it while it casts each slab."""
     import torch.distributed as dist
     world, _ = _world(group)
     flags = engine.new_flags()
@@ -251,12 +265,14 @@ def sharded_plaid(engine, X_local, stat="mean", normalize=True, alpha=1.0, beta=
         med, red = engine.medians(S, flags)
         if _collective(group):
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)         # mean(medx) over all samples
+        if defer_shift:
+            return S, med, red
         engine.shift(S, med, red)
     return S
 
 
 def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, alpha=1.0, beta=0.0, alpha_div=None,
-                      values=None, group=None, rank_weights=False):
+                      values=None, group=None, rank_weights=False, defer_shift=False):
     """plaid() on a CSC shard (sparse branch of Matrix::crossprod, R/plaid.R:107); same collectives as sharded_plaid"""
     import torch.distributed as dist
     world, _ = _world(group)
@@ -268,11 +284,13 @@ def sharded_plaid_csc(engine, X_local: "CscShard", stat="mean", normalize=True, 
         med, red = engine.medians(S, flags)
         if _collective(group):
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+        if defer_shift:
+            return S, med, red
         engine.shift(S, med, red)
     return S
 
 
-def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
+def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None, defer_shift=False):
     """replaid.ssgsea on a dgCMatrix shard (BASELINE config 5's workload): sparse_colranks of the stored values
     (R/plaid.R:600-601, 631-650), rank^(1+alpha), global max(rX) = one all_reduce(MAX), then the crossprod with the
     `/max - 0.5` folded into its epilogue (the -0.5 reaches the implicit zeros too) and the median normalisation"""
@@ -281,7 +299,7 @@ def sharded_ssgsea_csc(engine, X_local: "CscShard", alpha=0.0, group=None):
     Rx, gmax = engine.sparse_colranks(X_local, "average", False, 1.0 + alpha)
     if _collective(group):
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-    return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group, rank_weights=True)
+    return sharded_plaid_csc(engine, X_local, "mean", True, 1.0, -0.5, gmax, Rx, group, rank_weights=True, defer_shift=defer_shift)
 
 
 def sharded_sing(engine, X_local, group=None):
@@ -401,7 +419,7 @@ def _free_shm_bytes(directory="/dev/shm"):
 
 
 def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "device", dtype=None,
-                  chunk_rows: int | None = None, max_bytes: int | None = None, shm_dir: str = "/dev/shm"):
+                  chunk_rows: int | None = None, max_bytes: int | None = None, shm_dir: str = "/dev/shm", shift=None):
     """Reassemble the (n_total, m) score matrix on `dst` from the per-rank blocks laid out by shard_bounds()
     (the reference fills ONE matrix chunk by chunk, R/plaid.R:110-119).  Collective over `group`.
 
@@ -414,6 +432,10 @@ def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "de
     to="host"    every rank copies its block device->host into ITS rows of one host matrix shared between the processes
                  (a file under `shm_dir`, unlinked once everyone has mapped it): each GPU uses its own PCIe link, no GPU
                  ever holds more than its shard -- what completes at config 5.  Returns a numpy array on dst.
+    shift=(engine, med, red) with dtype=torch.float32: S_local is the UN-shifted block a `defer_shift=True` call returned
+                 and the sweep of R/plaid.R:572 is applied while each slab is cast (`engine.shift_cast`: one read of the
+                 fp64 block and a half-size write, instead of shift_columns' read + write over the whole 50 GB shard
+                 followed by the cast's read).  S_local is left un-shifted.  to="host" applies the shift in place first.
     `max_bytes` overrides the free-memory probe (tests).  Returns the full matrix on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
@@ -424,9 +446,33 @@ def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "de
     m = int(S_local.shape[1])
     itemsize = torch.empty((), dtype=out_dtype).element_size()
     need = int(n_total) * m * itemsize
-    if world == 1 and to == "device":
-        return S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+    eng = med = red = None
+    if shift is not None:
+        eng, med, red = shift
+        if to == "host" or out_dtype != torch.float32:
+            # (the host lanes copy on side streams of their own, and an fp64 result has no cast to fuse with: plain sweep)
+            eng.shift(S_local, med, red)
+            eng = None
+
+    def cast(block, r0, r1, out=None):
+        """rows [r0, r1) of this rank's block in the result's dtype (into `out` when given), shifted if the gather shifts"""
+        if eng is not None:
+            return eng.shift_cast(block[r0:r1], med[r0:r1], red, out)
+        if out is not None:
+            out.copy_(block[r0:r1])
+            return out
+        slab_ = block[r0:r1]
+        return slab_.contiguous() if out_dtype == slab_.dtype else slab_.to(out_dtype)
+
     rows = chunk_rows or max(1, (256 << 20) // max(1, m * 8))          # ~256 MB slabs
+    if world == 1 and to == "device":
+        if eng is None:
+            return S_local if out_dtype == S_local.dtype else S_local.to(out_dtype)
+        full1 = torch.empty((int(S_local.shape[0]), m), dtype=out_dtype, device=S_local.device)
+        for r0 in range(0, int(S_local.shape[0]), rows):
+            r1 = min(int(S_local.shape[0]), r0 + rows)
+            cast(S_local, r0, r1, full1[r0:r1])
+        return full1
     if to == "host":
         return _gather_to_host(S_local, n_total, dst, group, out_dtype, rows, max_bytes, shm_dir, need)
     # ---- device: the root decides, everyone learns the verdict (a refusal must not leave the peers in a send) ----
@@ -449,7 +495,7 @@ def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "de
         lo, hi = shard_bounds(n_total, world, rank)
         for r0 in range(lo, hi, rows):
             r1 = min(hi, r0 + rows)
-            full[r0:r1].copy_(S_local[r0 - lo:r1 - lo])
+            cast(S_local, r0 - lo, r1 - lo, full[r0:r1])
     per = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
     for s0 in range(0, per, rows):                       # slab s of every peer's block in one grouped batch
         ops, keep = [], []
@@ -464,8 +510,7 @@ def gather_scores(S_local, n_total: int, dst: int = 0, group=None, to: str = "de
         else:
             r0, r1 = s0, min(S_local.shape[0], s0 + rows)
             if r1 > r0:
-                slab = S_local[r0:r1]
-                slab = slab.contiguous() if out_dtype == slab.dtype else slab.to(out_dtype)
+                slab = cast(S_local, r0, r1)
                 keep.append(slab)
                 ops.append(dist.P2POp(dist.isend, slab, dst, group))
         if ops:

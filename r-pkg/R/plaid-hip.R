@@ -278,8 +278,10 @@ gmt2mat.file <- function(gmt.file, dir = NULL, add.source = FALSE, nrows = -1,
 ## plaid.test(), R/plaid.R:392-474: same arguments and result; the group means of X, Gt fc, Gt fc^2 and the
 ## per-set Welch statistics are reduced on the device (with gsetX = NULL the score matrix never leaves it),
 ## only O(sets) numbers come back.
-plaid.test <- function(X, y, G, gsetX = NULL, tests = c("one", "two", "lm"),
+plaid.test <- function(X, y, G, gsetX, tests = c("one", "two", "lm"),
                        metap.method = "fisher", sort.by = "p.meta") {
+  ## (the reference's signature, R/plaid.R:392: gsetX has no default; left out, it is recomputed from X and G like NULL)
+  if (missing(gsetX)) gsetX <- NULL
   if (!all(unique(y) %in% c(0, 1))) stop("elements of y must be 0 or 1")
   if (is.list(G)) {
     message("[plaid.test] converting gmt to sparse matrix...")

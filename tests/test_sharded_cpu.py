@@ -93,6 +93,13 @@ class OraclePhaseEngine:
         if S.shape[0]:
             S.sub_(med[:, None]).add_(float(red[0] / red[1]))
 
+    def shift_cast(self, S, med, red, out=None):
+        r = ((S - med[:, None]) + float(red[0] / red[1])).to(torch.float32)
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
 
     # plaid.test's row-wise reductions (HipPhaseEngine.row_group_sums / row_group_ssd / crossprod_sum)
     def row_group_sums(self, A, y):
@@ -291,3 +298,39 @@ def test_sharded_plaid_test_equals_the_oracle_gloo(tmp_path, n):
                 np.testing.assert_allclose(r0[key][:, k], exp[name], rtol=1e-8, atol=1e-300, err_msg=f"{key} {name}")
             else:
                 assert np.isnan(r0[key][:, k]).all()
+
+
+def _shift_in_gather_worker(rank, world, port, n, out_path):
+    """ssGSEA on a dgCMatrix shard with the sweep of R/plaid.R:572 deferred to the gather (cast-with-shift per slab) against
+    the same call that shifts in place and lets the gather only cast"""
+    g, m = 300, 70
+    Gp, Gi = synth.geneset_csc(g, m, kmin=3, kmax=60)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        eng = OraclePhaseEngine(g, Gp, Gi)
+        Xs = sp.random(g, n, density=0.2, format="csc", random_state=3, data_rvs=lambda k: np.round(np.random.default_rng(4).gamma(2.0, 1.0, k), 1) + 0.1)
+        lo, hi = sharded.shard_bounds(n, world, rank)
+        shard = sharded.CscShard.from_scipy(Xs, lo, hi)
+        S_plain = sharded.sharded_ssgsea_csc(eng, shard, alpha=0.25)
+        full_a = sharded.gather_scores(S_plain, n, dst=0, to="device", dtype=torch.float32, chunk_rows=3)
+        S_raw, med, red = sharded.sharded_ssgsea_csc(eng, shard, alpha=0.25, defer_shift=True)
+        keep = S_raw.clone()
+        full_b = sharded.gather_scores(S_raw, n, dst=0, to="device", dtype=torch.float32, chunk_rows=3, shift=(eng, med, red))
+        assert torch.equal(S_raw, keep)                    # the gather leaves the un-shifted block alone
+        full_c = sharded.gather_scores(S_raw.clone(), n, dst=0, to="device", shift=(eng, med, red))   # fp64: plain sweep, then gather
+        if rank == 0:
+            np.savez(out_path, a=full_a.numpy(), b=full_b.numpy(), c=full_c.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [11, 4])
+def test_gather_that_shifts_while_it_casts_equals_shift_then_cast_gloo(tmp_path, n):
+    """config 5's per-GPU flow without the shift pass: gather_scores(dtype=float32, shift=(engine, med, red)) on the
+    un-shifted block == shift in place, then gather with a cast (two ranks, slabs of three rows, uneven blocks)"""
+    out = str(tmp_path / "sg.npz")
+    mp.spawn(_shift_in_gather_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got["a"].dtype == np.float32 and got["a"].shape[0] == n
+    assert np.array_equal(got["a"], got["b"])
+    assert np.array_equal(got["c"].astype(np.float32), got["a"])
