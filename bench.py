@@ -104,6 +104,11 @@ def _block_summary(b):
         o.update({"kernel": str(k.get("kernel"))[:40], "kernel_ms": k.get("kernel_ms"), "frac": k.get("frac")})
         if isinstance(k.get("lds_roof"), dict):
             o["lds_frac"] = k["lds_roof"].get("frac")
+        for kk in ("lds_active", "clock_ghz"):
+            if kk in k:
+                o[kk] = k[kk]
+    if isinstance(b.get("pipeline"), dict):
+        o["pipeline_frac"] = b["pipeline"].get("frac")
     if "phases_ms" in b:
         o["phases_ms"] = {kk[:24]: round(v, 3) for kk, v in b["phases_ms"].items()}
     if isinstance(b.get("cpu_baseline"), dict):
@@ -111,7 +116,7 @@ def _block_summary(b):
     if "vs_baseline" in b:
         o["vs_published"] = b["vs_baseline"]
     if isinstance(b.get("mfma_backend"), dict) and "frac" in b["mfma_backend"]:
-        o["mfma"] = _pick(b["mfma_backend"], ("ms", "achieved", "frac"))
+        o["mfma"] = _pick(b["mfma_backend"], ("ms", "achieved", "frac", "useful_frac"))
     o["parity_ok"] = _parity_ok(b.get("parity"))
     return o
 
@@ -133,6 +138,11 @@ def compact_line(full, detail_path="bench_detail.json"):
         roof["lds_frac"] = r["lds_roof"].get("frac")
         roof["lds_achieved"] = r["lds_roof"].get("achieved")
         roof["lds_peak"] = r["lds_roof"].get("peak")
+    for kk in ("lds_active", "clock_ghz"):       # PMC of the same kernel and shape (profiles/traffic.json): LDS busy share, clock held
+        if kk in r:
+            roof[kk] = r[kk]
+    if isinstance(full.get("pipeline"), dict):
+        line["pipeline_frac"] = full["pipeline"].get("frac")
     line["roofline"] = roof
     c = full.get("cpu_baseline")
     if isinstance(c, dict):
@@ -288,6 +298,30 @@ def _traffic(kernel, shape, columns=None):
         return (v, src) if v is not None else None
     except Exception:
         return None
+
+
+def _pmc_extra(kernel, shape):
+    """{lds_active, clock_ghz, lds_conflict_share, wait_share} of a kernel from the committed PMC passes (profiles/traffic.json:
+    SQ_LDS_IDX_ACTIVE / CUs over GRBM_GUI_ACTIVE / 8, GRBM_GUI_ACTIVE / 8 / the launch's duration in that very pass, ...):
+    what puts "it sits on the LDS roof" -- or does not -- into the record next to lds_frac"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{kernel}/{shape}", {})
+        o = {k: e[k] for k in ("lds_active", "clock_ghz", "lds_conflict_share", "wait_share") if k in e}
+        if o:
+            o["pmc_source"] = e.get("source", "profiles/traffic.json")
+        return o
+    except Exception:
+        return {}
+
+
+def _pipeline(kernels, ms_per_step, skip=()):
+    """the WHOLE step against the HBM roof: the algorithmic bytes of every kernel that ran (SURVEY.md 8(d) per phase) over the
+    step's time and 8 TB/s -- the view the per-kernel fractions do not give (a 14 ms shift at 0.7 of the roof beside a 20 ms
+    crossprod at 0.25)"""
+    tot = sum(int(k.get("algorithmic_bytes", 0)) for nm, k in kernels.items() if isinstance(k, dict) and nm not in skip)
+    return {"algorithmic_bytes": tot, "frac": round(tot / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "sum of the phases' algorithmic bytes / ms_per_step / 8 TB/s"
+                    + (f" (without {', '.join(skip)}: the fused crossprod made that sweep unnecessary)" if skip else "")}
 
 
 def _roof(kernel, alg_bytes, ms, traffic=None, lds_bytes=None, extra=None):
@@ -616,7 +650,8 @@ def run_c2(a, env):
     spmm_kernel = "spmm_colpair_f64"   # (any leading dimension: the 16-byte loads need no 16-byte alignment)
     # every padded membership slot of the plan returns 8 bytes per sample column from LDS
     lds_bytes = float(info["padded_slots"]) * 8.0 * n
-    roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes), 2.0 * z * n)
+    roofline = _fp64_roof(_roof(spmm_kernel, alg_bytes, spmm_ms, _traffic(spmm_kernel, f"{g}x{n}x{m}"), lds_bytes,
+                                extra=_pmc_extra(spmm_kernel, f"{g}x{n}x{m}")), 2.0 * z * n)
     kernels = {
         "col_medians": _roof("col_medians_wave_kernel" if m <= 6144 else "col_medians_stream_kernel", 8.0 * m * n, med_ms,
                              _traffic("col_medians_wave_kernel", f"{n}x{m}") if m <= 6144 else None),
@@ -689,7 +724,7 @@ def run_c2(a, env):
         "value": value, "ms_per_step": ms_step, "ms_per_step_cold": 1e3 * cold["elapsed"] / a.steps,
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "host_entry": host_entry,
-        "gather": gather, "mixed_precision": mixed, "kernels": kernels,
+        "gather": gather, "mixed_precision": mixed, "kernels": kernels, "pipeline": _pipeline(dict(kernels, crossprod=roofline), ms_step),
         "phases_ms": {"spmm": round(spmm_ms, 4), "col_medians+sum": round(med_ms, 4), "shift": round(shift_ms, 4),
                       "normalize_medians": round(med_ms + shift_ms, 4)},
         "config": {"workload": f"C2 dense plaid(): {g} genes x {n} samples/GPU x {m} gene sets "
@@ -812,13 +847,15 @@ def run_sparse_ssgsea(a, env, n, label, collective, real_sets=False):
                                      _traffic("colranks_bucket_kernel<256,8>", "csc", n) if max_nnz <= 2048 else None),
             "crossprod": _roof("spmm_scatter_csc_f64" if scatter else "spmm_colpair_f64<csc>", spmm_alg, spmm_ms,
                                _traffic("spmm_scatter_csc_f64<med>" if (fused_info and fused_info.get("columns")) else "spmm_scatter_csc_f64", f"{g}xNx{m}", n) if scatter else None,
-                               extra={"lds_atomic_adds_per_s": round(nnz * (z / g) / (spmm_ms * 1e-3), 1)} if scatter else None),
+                               extra=dict({"lds_atomic_adds_per_s": round(nnz * (z / g) / (spmm_ms * 1e-3), 1)},
+                                          **_pmc_extra("spmm_scatter_csc_f64<med>" if (fused_info and fused_info.get("columns")) else "spmm_scatter_csc_f64", f"{g}xNx{m}")) if scatter else None),
             "col_medians": _roof("median_select_kernel + col_medians_stream_kernel (unresolved columns)", 8.0 * m * n, med_ms, None,
                                  extra={"note": "algorithmic bytes are those of the full sweep the fused crossprod made unnecessary: "
                                                 "frac > 1 would only say that S was not read again"}),
             "shift_columns": _roof("shift_columns_kernel", 16.0 * m * n, shift_ms, _traffic("shift_columns_kernel", f"Nx{m}", n)),
         },
     }
+    out["pipeline"] = _pipeline(out["kernels"], out["ms_per_step"], skip=("col_medians",) if (fused_info and fused_info.get("columns")) else ())
     if collective and not a.no_gather:
         # (the host gather of config 5 writes 8 x 50 GB through /dev/shm: tens of seconds; it runs on request only, so that
         # the driver's scaling runs stay within minutes -- measured in tools/gather_host_check.py and DESIGN.md 8)
@@ -943,7 +980,8 @@ def run_c4(a, env):
             "crossprod": _fp64_roof(_roof("spmm_colpair_f64<med> (+ 256-column calibration)" if fused_info else "spmm_colpair_f64",
                                           spmm_alg, spmm_ms,
                                           _traffic("spmm_colpair_f64<med>" if fused_info else "spmm_colpair_f64", f"{g}xNx{m}", n),
-                                          lds_bytes=float(info["padded_slots"]) * 8.0 * n), 2.0 * z * n),
+                                          lds_bytes=float(info["padded_slots"]) * 8.0 * n,
+                                          extra=_pmc_extra("spmm_colpair_f64<med>" if fused_info else "spmm_colpair_f64", f"{g}xNx{m}")), 2.0 * z * n),
             "col_medians": (_roof("median_select_kernel + col_medians_stream_kernel (unresolved columns)", 8.0 * m * n, med_ms, None,
                                   extra={"note": "algorithmic bytes are those of the full sweep the fused crossprod made unnecessary: "
                                                  "frac > 1 would only say that S was not read again"})
@@ -955,6 +993,7 @@ def run_c4(a, env):
                                   f"{2.0 * g * n * m:.2e} flop (x3 issues as a bf16 split) against {2.0 * z * n:.2e} for this "
                                   "crossprod: see DESIGN.md (C4 row) for the measured MFMA rate beside this time"},
     }
+    out["pipeline"] = _pipeline(out["kernels"], out["ms_per_step"], skip=("col_medians",) if fused_info else ())
     # the same crossprod as the dense contraction config 4 names, on the matrix cores (opt-in backend): ONE call at the
     # FULL size (all n samples x m sets; the backend walks 8,192-sample panels), timed with HIP events, next to the SpMM
     # kernel's time for the same launch (phases_ms.crossprod above).  Its probe columns are checked against the oracle in
@@ -978,7 +1017,9 @@ def run_c4(a, env):
         tf = flop / (t_mfma * 1e-3) / 1e12
         out["mfma_backend"] = {
             "kernel": "crossprod_mfma_bf16x3_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
-            "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "samples": n, "sets": m, "genes": g, "launches": 1,
+            "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "useful_frac": round(2.0 * g * float(n) * m / (t_mfma * 1e-3) / 1e12 / 2500.0, 4),   # the contraction's own 2 g n m flop: `frac` counts the bf16 x 3 split's three issues
+            "samples": n, "sets": m, "genes": g, "launches": 1,
             "ms": round(t_mfma, 3), "spmm_ms_same_launch": round(spmm_ms, 3), "slowdown_vs_spmm": round(t_mfma / spmm_ms, 2),
             "flop": flop, "scores_per_s": round(float(n) * m / (t_mfma * 1e-3), 1),
             "note": "dense 0/1 G (bf16, 2 GB) x bf16x3 split of the rank weights, fp32 accumulate: 3 x 2 g n m flop against "
@@ -1396,7 +1437,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": c2["config"], "roofline": c2["roofline"], "cpu_baseline": c2["cpu_baseline"],
-            "phases_ms": c2["phases_ms"], "kernels": c2["kernels"], "parity": c2["parity"], "gather": c2["gather"],
+            "phases_ms": c2["phases_ms"], "kernels": c2["kernels"], "pipeline": c2.get("pipeline"), "parity": c2["parity"], "gather": c2["gather"],
             "mixed_precision": c2["mixed_precision"], "host_entry": c2["host_entry"],
         }
         out.update(blocks)

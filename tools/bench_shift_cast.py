@@ -35,5 +35,5 @@ with torch.cuda.stream(stream):
         if rep:
             a, b, c = e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)
             gb = n * m / 1e9
-            print(f"{n} x {m}: shift in place {a:.3f} ms + cast {b:.3f} ms = {a + b:.3f} ms ({28 * gb / (a + b):.0f} GB/s over 28 B per score)   "
-                  f"shift_columns_cast_f32 {c:.3f} ms ({12 * gb / c:.0f} GB/s over 12 B per score)   ratio {(a + b) / c:.2f}x")
+            print(f"{n} x {m}: shift in place {a:.3f} ms + cast {b:.3f} ms = {a + b:.3f} ms ({28e3 * gb / (a + b):.0f} GB/s over 28 B per score)   "
+                  f"shift_columns_cast_f32 {c:.3f} ms ({12e3 * gb / c:.0f} GB/s over 12 B per score)   ratio {(a + b) / c:.2f}x")

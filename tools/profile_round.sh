@@ -52,7 +52,9 @@ python3 tools/bench_sparse_sing.py > $out/sparse_sing.log 2>&1
 for ab in 0 5 8 9 10 13; do echo "ablate $ab (4096 x 50000 sets)"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --samples 4096 --sets 50000 --iters 8 --ablate $ab 2>&1 | grep -E "^spmm" | tail -1; done > $out/pair_partial_ablations_c4.log 2>&1
 for f in "" "--fused"; do python3 tools/bench_spmm.py --kernel c4 --samples 8192 --sets 50000 --iters 4 $f 2>&1 | grep "^c4" | tail -1; done > $out/c4_8192_fused.log 2>&1
 for ab in 0 2 6 7 5; do PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel spmm --iters 10 --ablate $ab 2>&1 | grep -E "^spmm|algorithmic" | tail -2; done > $out/pair_ablations.log 2>&1
-for ab in 100 101 102 103 104 105; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 3 --ablate $ab 2>&1 | grep -E "^c3|stamps" | tail -2; done > $out/scatter_ablations.log 2>&1
+for ab in 100 101 102 103 104 105 108 109; do echo "ablate $ab"; PLAIDHIP_LIB=plaid_amd/csrc/libplaidhip_diag.so python3 tools/bench_spmm.py --kernel c3 --samples 8192 --sets 50000 --iters 3 --ablate $ab 2>&1 | grep -E "^c3|stamps" | tail -2; done > $out/scatter_ablations.log 2>&1
+python3 tools/bench_shift_cast.py 16384 50000 > $out/shift_cast_ab.log 2>&1
+[ -x tools/ubench/scatter_ring ] && ./tools/ubench/scatter_ring 16 2 > $out/ubench_scatter_ring.log 2>&1
 [ -x tools/ubench/fetch_calib ] && bash tools/fetch_calib.sh $out/fetch_calib > $out/fetch_calib.log 2>&1   # FETCH_SIZE against known byte counts
 [ -x tools/ubench/inexact_flag ] && ./tools/ubench/inexact_flag > $out/ubench_inexact_flag.log 2>&1
 [ -x tools/ubench/column_stream ] && ./tools/ubench/column_stream 50000 8192 > $out/ubench_column_stream.log 2>&1
@@ -65,6 +67,11 @@ for tag in ("c2", "c3", "c3fused", "c3f64", "c4", "c4fused", "sing", "c2step"):
     for f in glob.glob(out + f"/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # kernel durations of the GRBM pass (pass 5), from its own kernel trace: GRBM_GUI_ACTIVE / 8 / duration is the clock the
+    # chip held in that very launch, and SQ_LDS_IDX_ACTIVE / CUs over GRBM_GUI_ACTIVE / 8 the share of it the LDS was busy
+    for f in glob.glob(out + f"/pmc_{tag}_5/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"][:70]]["DURATION_NS_GRBM_PASS"].append(float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open(out + f"/pmc_{tag}_summary.txt", "w") as fh:
         for k, d in sorted(agg.items()):
             if not any(x in k for x in ("spmm", "colranks", "median", "shift", "colmean")):
@@ -72,8 +79,11 @@ for tag in ("c2", "c3", "c3fused", "c3f64", "c4", "c4fused", "sing", "c2step"):
             fh.write(k + "\n")
             for c, v in sorted(d.items()):
                 fh.write(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
-# kernel stats of the three bench runs: one csv each
+# kernel stats of the bench runs: rocprofv3's own per-name csv, and one row per LAUNCH SHAPE (tools/kernel_stats_by_shape.py:
+# the calibration launches of the fused-medians calls no longer poison the averages of the main launches)
+import subprocess
 for cfg in ("c2", "c3", "c4", "ref"):
+    subprocess.run([sys.executable, "tools/kernel_stats_by_shape.py", out + f"/stats_{cfg}", out + f"/bench_{cfg}_kernel_stats_by_shape.csv"])
     for f in glob.glob(out + f"/stats_{cfg}/**/*kernel_stats.csv", recursive=True):
         os.replace(f, out + f"/bench_{cfg}_kernel_stats.csv")
 print(open(out + "/pmc_c2_summary.txt").read()[:1500])

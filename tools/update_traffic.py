@@ -44,8 +44,8 @@ ENTRIES = [
     ("col_medians_wave_kernel/10000x5000", "c2step", "col_medians_wave_kernel", None, "every column read once into registers"),
     ("shift_columns_kernel/10000x5000", "c2step", "shift_columns_kernel", None, "read + write of S"),
     ("spmm_scatter_csc_f64/20000xNx50000", "c3", "spmm_scatter_csc_f64<true, 1024, false>", 8192,
-     "round-4 kernel (readlane broadcasts, buffer loads with scalar segment offsets, u64 fixed-point accumulators, chunk-major "
-     "item order): fetched + written against 0.41 MB algorithmic per column"),
+     "round-6 kernel (sets dealt to the chunks in interleaved blocks, second segments in the static pipeline, u64 fixed-point "
+     "accumulators, chunk-major item order): fetched + written against 0.41 MB algorithmic per column"),
     ("spmm_scatter_csc_f64<med>/20000xNx50000", "c3fused", "spmm_scatter_csc_f64<true, 1024, true>", 8192,
      "the same kernel with the classifying epilogue (medians selected inside the launch): + the candidate slices and counts"),
     ("col_medians_stream_kernel/Nx50000", "c3", "col_medians_stream_kernel", 8192,
@@ -80,6 +80,16 @@ for key, tag, needle, cols, note in ENTRIES:
     for extra in ("TCC_HIT_sum", "TCC_MISS_sum"):
         if extra in c:
             e[extra.lower()] = c[extra]
+    # the clock the chip held in the GRBM pass and the share of the launch the LDS was active (256 CUs, 8 XCDs: the counters
+    # are sums over them) -- what says "on the LDS roof" next to lds_frac
+    if "GRBM_GUI_ACTIVE" in c and "DURATION_NS_GRBM_PASS" in c and c["DURATION_NS_GRBM_PASS"] > 0:
+        e["clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / c["DURATION_NS_GRBM_PASS"], 3)
+        if "SQ_LDS_IDX_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+            e["lds_active"] = round((c["SQ_LDS_IDX_ACTIVE"] / 256.0) / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            e["lds_conflict_share"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3)
+        if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:
+            e["wait_share"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
     out[key] = e
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps({k: v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_column")) for k, v in out.items()}, indent=1))
