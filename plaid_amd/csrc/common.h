@@ -36,6 +36,12 @@ constexpr int kScatterTrash = 64;                      // accumulators behind a 
 constexpr int kScatterBlock = PLAIDHIP_SCATTER_BLOCK;
 // further id segments (genes in more than 128 sets of a chunk) whose loads ride the scatter walk's static pipeline per
 // wavefront and item; a wavefront with more of them fetches the rest group by group (A/B builds: -DPLAIDHIP_SCATTER_HE=8)
+// groups of 16 first-segment loads a wavefront requests before it applies the first one: 2 (3, round 5's depth, puts 960
+// requests into the CU's in-order memory pipe at the start of an item and the youngest wavefronts' first ids behind all of
+// them: +2.5 % at 16,384 x 50,000, profiles/r06h_scatter_depth_ab.txt; A/B builds: -DPLAIDHIP_SCATTER_DEPTH=3)
+#ifndef PLAIDHIP_SCATTER_DEPTH
+#define PLAIDHIP_SCATTER_DEPTH 2
+#endif
 #ifndef PLAIDHIP_SCATTER_HE
 #define PLAIDHIP_SCATTER_HE 12
 #endif

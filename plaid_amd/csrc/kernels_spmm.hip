@@ -1151,7 +1151,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
 #define PLAIDHIP_WALK_SEGMENTS()                                                                       \
   {                                                                                                    \
     const int s0e = ns > 0 ? s0 : a.dummy_seg;                                                         \
-    /* 48 + HE id loads in flight per wavefront.  Segment 0 of the wavefront's 64 values goes through a static pipeline   \
+    /* 32 .. 48 + HE id loads in flight per wavefront.  Segment 0 of the wavefront's 64 values goes through a static pipeline   \
        (groups A..D, owning lane = a CONSTANT readlane index).  Genes in more than 128 sets of the chunk have FURTHER       \
        segments (~7 per wavefront and item at config 3).  Round 5 walked them behind the pipeline with scalar bookkeeping   \
        per entry (ballot / find-first / dynamic readlane, ~20 dependent scalar instructions and three branches each) and a  \
@@ -1168,7 +1168,7 @@ spmm_scatter_csc_f64(ScatterArgs a) {
     const int nval = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(have)));            \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idA[u] = PLAIDHIP_ID_LOAD(u);                       \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) idB[u] = PLAIDHIP_ID_LOAD(HW + u);                  \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u) idC[u] = PLAIDHIP_ID_LOAD(2 * HW + u);              \
+    if (PLAIDHIP_SCATTER_DEPTH >= 3) { _Pragma("unroll") for (int u = 0; u < HW; ++u) idC[u] = PLAIDHIP_ID_LOAD(2 * HW + u); } \
     PLAIDHIP_ISSUE_PREFETCH()                                                                          \
     const uint64_t m1 = PH_SC_ABL(8) ? 0ull : __ballot(ns > 1);                                        \
     const int cnt1 = __builtin_popcountll(m1);                                                         \
@@ -1190,8 +1190,10 @@ spmm_scatter_csc_f64(ScatterArgs a) {
                             : (uint32_t)raw_buffer_load_i32(ids_rsrc, loff_b, (int32_t)((uint32_t)__builtin_amdgcn_readlane(segE, u) << 8), 0); \
     PH_SC_STAMP_IDS(idA[0]);   /* tools/ build: the first ids in hand */                               \
     _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idA[u], PLAIDHIP_V_OF(u))         \
-    _Pragma("unroll") for (int u = 0; u < HW; ++u) idD[u] = PLAIDHIP_ID_LOAD(3 * HW + u);              \
+    if (PLAIDHIP_SCATTER_DEPTH < 3) { _Pragma("unroll") for (int u = 0; u < HW; ++u) idC[u] = PLAIDHIP_ID_LOAD(2 * HW + u); } \
+    else { _Pragma("unroll") for (int u = 0; u < HW; ++u) idD[u] = PLAIDHIP_ID_LOAD(3 * HW + u); }     \
     if (nval > HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idB[u], PLAIDHIP_V_OF(HW + u)) }      \
+    if (PLAIDHIP_SCATTER_DEPTH < 3) { _Pragma("unroll") for (int u = 0; u < HW; ++u) idD[u] = PLAIDHIP_ID_LOAD(3 * HW + u); } \
     if (nval > 2 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idC[u], PLAIDHIP_V_OF(2 * HW + u)) } \
     if (nval > 3 * HW) { _Pragma("unroll") for (int u = 0; u < HW; ++u) PLAIDHIP_SCATTER2(idD[u], PLAIDHIP_V_OF(3 * HW + u)) } \
     PH_SC_STAMP(6);                                                                                    \
