@@ -210,6 +210,101 @@ __global__ void __launch_bounds__(1024) walk_cur(Args a, unsigned long long* sta
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// steal: the item's entries {segment, value} sit in a table in LDS (behind the accumulators) and the wavefronts TAKE groups
+// of 16 of them as they go (one returning LDS atomic per group), two groups in flight per wavefront -- the wavefronts the
+// memory pipe serves first simply take more groups, so nobody waits at the end-of-walk barrier for the ones served last.
+// The loads stay unconditional (hipcc counts vmcnt exactly): a wavefront that finds the table empty issues one or two
+// groups of loads of the all-padding segment (L1 hits) before it leaves the loop.
+constexpr int kEntOff = (kCh + kTrash) * 8;                 // entry table: u32 segment per entry (the value is index + 1 here)
+constexpr int kEntCap = 1536;
+constexpr int kGrabOff = kEntOff + kEntCap * 4;
+static_assert(kGrabOff + 16 <= 160 * 1024, "LDS");
+template <bool STAMP>
+__global__ void __launch_bounds__(1024) walk_steal(Args a, unsigned long long* stamps) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* ent = reinterpret_cast<uint32_t*>(smem + kEntOff);
+  uint32_t* grab = reinterpret_cast<uint32_t*>(smem + kGrabOff);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < kCh + kTrash; i += 1024) acc[i] = 0ull;
+  __syncthreads();
+  const i32x4 rsrc = make_raw_rsrc(a.ids, a.ids_bytes);
+  const int32_t loff = lane * 4;
+  const int32_t dummy = (int32_t)(a.ids_bytes / 256) - 1;
+  unsigned long long chk = 0;
+  unsigned long long ph[4] = {0, 0, 0, 0}, tl = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  tl = t0;
+  for (int item = 0; item < a.items; ++item) {
+    const int32_t* list = a.work + ((size_t)blockIdx.x * a.items + item) * kListCap;
+    const int n = a.cnt[(size_t)blockIdx.x * a.items + item];
+    // publish the entries (the product's threads would publish their own {segment, value} here)
+    for (int e = tid; e < n; e += 1024) ent[e] = (uint32_t)list[e];
+    if (tid == 0) *grab = 0u;
+    __syncthreads();
+    STAMP_AT(0)
+    const int ngroups = (n + 15) >> 4;
+    uint32_t idA[16], idB[16];
+    int segA = dummy, segB = dummy, eA = 0, eB = 0;
+    bool vA, vB;
+#define TAKE_GROUP(SEG, E0, VALID)                                                                                   \
+    {                                                                                                                 \
+      uint32_t g_ = 0;                                                                                                \
+      if (lane == 0) g_ = __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(kGrabOff)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      g_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_);                                                         \
+      VALID = (int)g_ < ngroups;                                                                                      \
+      E0 = (int)g_ * 16;                                                                                              \
+      const int e_ = E0 + (lane & 15);                                                                                \
+      SEG = (VALID && e_ < n) ? (int)ent[e_ < kEntCap ? e_ : 0] : dummy;                                              \
+    }
+#define ISSUE_GROUP(ID, SEG)                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u)                                                                  \
+      ID[u] = (uint32_t)raw_buffer_load_i32(rsrc, loff, (int32_t)((uint32_t)__builtin_amdgcn_readlane(SEG, u) << 8), 0);
+#define APPLY_GROUP(ID, E0)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                                \
+      const unsigned long long val_ = (E0 + u < n) ? (unsigned long long)(E0 + u + 1) : 0ull;                        \
+      lds_add_u64(off_lo(ID[u]), val_);                                                                               \
+      lds_add_u64(off_hi(ID[u]), val_);                                                                               \
+    }
+    TAKE_GROUP(segA, eA, vA)
+    ISSUE_GROUP(idA, segA)
+    TAKE_GROUP(segB, eB, vB)
+    ISSUE_GROUP(idB, segB)
+    while (vA) {
+      APPLY_GROUP(idA, eA)
+      TAKE_GROUP(segA, eA, vA)
+      ISSUE_GROUP(idA, segA)
+      if (!vB) break;
+      APPLY_GROUP(idB, eB)
+      TAKE_GROUP(segB, eB, vB)
+      ISSUE_GROUP(idB, segB)
+    }
+    // (a wavefront leaves with its last one or two groups of padding loads in flight; they are awaited here so that
+    // the register arrays are dead at the top of the next item)
+    asm volatile("" : "+v"(idA[0]), "+v"(idB[0]));
+#undef TAKE_GROUP
+#undef ISSUE_GROUP
+#undef APPLY_GROUP
+    if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); STAMP_AT(1) }
+    __syncthreads();
+    STAMP_AT(2)
+    if (a.epi != 0) epilogue<1024>(a, tid, item, acc, 0, chk);
+    __syncthreads();
+    STAMP_AT(3)
+  }
+  if constexpr (STAMP) {
+    if (lane == 0) for (int k = 0; k < 4; ++k) stamps[((size_t)blockIdx.x * 16 + wave) * 4 + k] = ph[k];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (a.epi == 0)
+    for (int i = tid; i < kCh; i += 1024) chk += acc[i] * (unsigned long long)(i + 1);
+  for (int off = 32; off >= 1; off >>= 1) chk += __shfl_xor(chk, off, 64);
+  if (lane == 0) atomicAdd(&a.chk[blockIdx.x], chk);
+  if (tid == 0) a.cyc[blockIdx.x] = t1 - t0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // quad: the same structure as `cur`, but one vector-memory instruction fetches FOUR segments: a buffer_load_dwordx4 whose
 // 16-lane rows read 256 bytes each (16 bytes per lane), row q of step t taking the segment of lane 16 q + t (its number and
 // its value reach the row by DPP row_newbcast -- no scalar registers, no readlane).  A lane then holds 8 ids of its row's
@@ -691,6 +786,43 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> st((size_t)nwg * 16 * 4);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     printf("    quad, stamps per item (cycles): wavefront: first ids in hand | walk | barrier 1 | epilogue + barrier 2\n");
+    for (int w = 0; w < 16; w += 3) {
+      double ph[4] = {0, 0, 0, 0};
+      for (int b = 0; b < nwg; ++b) for (int k = 0; k < 4; ++k) ph[k] += (double)st[((size_t)b * 16 + w) * 4 + k];
+      printf("      w%-2d %7.0f %7.0f %7.0f %7.0f\n", w, ph[0] / nwg / items, ph[1] / nwg / items, ph[2] / nwg / items, ph[3] / nwg / items);
+    }
+    CK(hipFree(d_st));
+  }
+  {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_steal<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_steal<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t smem_steal = (size_t)kGrabOff + 16;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipMemset(d_chk, 0, nwg * 8));
+      a.S = d_S2;
+      CK(hipMemset(d_S2, 0xff, Swords * 8));
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(walk_steal<false>, dim3(nwg), dim3(1024), smem_steal, 0, a, (unsigned long long*)nullptr);
+      CK(hipEventRecord(e1));
+      CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 1) report("steal (groups of 16 taken from LDS)", ms);
+    }
+    if (epi == 2) {
+      std::vector<unsigned long long> S2(Swords);
+      CK(hipMemcpy(S2.data(), d_S2, Swords * 8, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < Swords; ++i) bad += S2[i] != S_ref[i];
+      printf("    scores vs cur: %zu of %zu differ\n", bad, Swords);
+    }
+    unsigned long long* d_st;
+    CK(hipMalloc(&d_st, (size_t)nwg * 16 * 4 * 8));
+    CK(hipMemset(d_chk, 0, nwg * 8));
+    hipLaunchKernelGGL(walk_steal<true>, dim3(nwg), dim3(1024), smem_steal, 0, a, d_st);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st((size_t)nwg * 16 * 4);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    printf("    steal, stamps per item (cycles): wavefront: publish + barrier | walk | barrier 1 | epilogue + barrier 2\n");
     for (int w = 0; w < 16; w += 3) {
       double ph[4] = {0, 0, 0, 0};
       for (int b = 0; b < nwg; ++b) for (int k = 0; k < 4; ++k) ph[k] += (double)st[((size_t)b * 16 + w) * 4 + k];
