@@ -912,6 +912,28 @@ def test_c3_shape_ssgsea_csc_50k_sets(pinned_ctx, g50k, mode):
     close(ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
 
 
+@pytest.mark.parametrize("sets", [1, 1023, 1024, 1025, 2049, 17407, 17408, 17409, 34816, 34817, 52225])
+def test_scatter_kernel_block_interleaved_chunks_at_every_boundary(pinned_ctx, sets):
+    """round 6 deals the sets to the LDS chunks in interleaved blocks of 1,024 (block b -> chunk b mod nch, common.h): one set,
+    either side of a block, of one / two / three chunks of 17,408 slots, a last block of one set -- with sets in DECREASING
+    size (gmt2mat's order, R/gmt-utils.R:25: what made chunks of consecutive sets lopsided) and genes in 1 ... 3 segments of a
+    chunk; scatter kernel pinned, mean and sum, raw and normalised, against the oracle"""
+    from plaid_amd import synth as sy
+    g = 600
+    Gp, Gi = sy.geneset_csc(g, sets, kmin=1, kmax=min(g, 90 if sets > 4000 else 400))     # (sorted by decreasing size)
+    G = sp.csc_matrix((np.ones(len(Gi)), Gi, Gp), shape=(g, sets))
+    rn = [str(k) for k in range(g)]
+    rng = np.random.default_rng(sets)
+    Xs = sp.random(g, 24, density=0.3, format="csc", random_state=int(sets) % 1000,
+                   data_rvs=lambda k: np.round(rng.gamma(2.0, 1.0, k), 2) + 0.01)
+    Xs.sort_indices()
+    ctx = pinned_ctx(spmm_sparse_kernel="scatter")
+    for stat in ("mean", "sum"):
+        close(ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, stat, False),
+              _oracle().plaid(Xs, rn, G, rn, stats=stat, normalize=False))
+    close(ctx.plaid_csc(Xs.indptr, Xs.indices, Xs.data, g, Gp, Gi, "mean", True), _oracle().plaid(Xs, rn, G, rn))
+
+
 @pytest.mark.parametrize("sets", [700, 24000])
 def test_scatter_kernel_any_number_of_stored_values_per_column(pinned_ctx, sets):
     """the scatter kernel's item pipeline (column, chunk, round): columns of 0 ... 6,000 stored values next to each
