@@ -73,6 +73,36 @@ struct RankBucketArgs {
 #define PH_STAMP(k) do { } while (0)
 #endif
 
+// v_min_f64 / v_max_f64 as single instructions (fmin / fmax put a canonicalising v_max_f64 x, x in front of each)
+__device__ __forceinline__ double ph_min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double ph_max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// r^(1/4) for a normal r > 0 (ranks are >= 0.5): two raw reciprocal square roots (v_rsq_f64, ~23 bits) and two steps of a
+// simplified Newton iteration z += z (r - z^4) / (4 r) with 1 / (4 r) taken from the first estimate (its 2^-22 error only
+// scales the correction: 2^-22 -> 2^-44 -> 2^-66): 12 fp64 instructions against ~30 for sqrt(sqrt(r)) -- the rank kernel is
+// bound by its vector instructions (5.2k per wavefront and column, profiles/r06p_pmc_c4_summary.txt), and ssGSEA's
+// alpha = 0.25 spent a fifth of them on the two correctly rounded square roots.  Within 1 ulp of sqrt(sqrt(r)).
+__device__ __forceinline__ double root4_pos(double r) {
+  const double y = __builtin_amdgcn_rsq(r);          // ~ r^-1/2
+  double z = __builtin_amdgcn_rsq(y);                // ~ r^1/4
+  const double c = 0.25 * (y * y);                   // ~ 1 / (4 r)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double w = z * z;
+    const double e = __fma_rn(-w, w, r);             // r - z^4
+    z = __fma_rn(z * c, e, z);
+  }
+  return z;
+}
+
 // r^(q/4) for r > 0 by (correctly rounded) square roots and multiplications: a few ulp, ~6x cheaper than pow()
 __device__ __forceinline__ double pow_quarters(double r, int q) {
   double res = 1.0, base = r;
@@ -80,6 +110,7 @@ __device__ __forceinline__ double pow_quarters(double r, int q) {
     if (e & 1) res *= base;
     base *= base;
   }
+  if ((q & 3) == 1) return res * root4_pos(r);       // 1.25 (ssGSEA's default exponent), 2.25, ...
   if (q & 3) {
     const double s = sqrt(r);
     if (q & 2) res *= s;
@@ -283,6 +314,9 @@ colranks_bucket_kernel(RankBucketArgs a) {
     // ---- 1. the column -> registers as ordered keys ------------------------------------------------
     uint64_t validmask = 0, nanmask = 0, negmask = 0;
     uint64_t kmin = ~0ull, kmax = 0ull;
+    // (the extremes are taken on the DOUBLES -- v_min_f64 / v_max_f64, one instruction each per key; the key map is monotone --
+    // and turned into keys once per thread: the u64 compare-and-select pairs per key were 8 vector instructions)
+    double dmin = INFINITY, dmax = -INFINITY;
     {
       if (!have_next) PH_COLUMN_LOAD(xc, cnt)
       have_next = false;
@@ -306,9 +340,15 @@ colranks_bucket_kernel(RankBucketArgs a) {
         const uint64_t u = (uint64_t)__double_as_longlong(xv + 0.0);       // -0 -> +0
         const uint64_t k = ((long long)u < 0) ? ~u : (u | 0x8000000000000000ull);
         key[j] = ok ? k : ~0ull;
-        kmin = (ok && k < kmin) ? k : kmin;
-        kmax = (ok && k > kmax) ? k : kmax;
+        const double xn = ok ? xv + 0.0 : dmin;                              // (a key that does not count repeats the minimum)
+        dmin = ph_min_f64(dmin, xn);
+        dmax = ph_max_f64(dmax, ok ? xv + 0.0 : dmax);
       })
+    }
+    if (validmask != 0) {   // (per thread: the extremes of its own valid keys, as keys)
+      const uint64_t u1 = (uint64_t)__double_as_longlong(dmin), u2 = (uint64_t)__double_as_longlong(dmax);
+      kmin = ((long long)u1 < 0) ? ~u1 : (u1 | 0x8000000000000000ull);
+      kmax = ((long long)u2 < 0) ? ~u2 : (u2 | 0x8000000000000000ull);
     }
     kmin = wave_minmax_u64<true>(kmin);
     kmax = wave_minmax_u64<false>(kmax);
@@ -326,11 +366,17 @@ colranks_bucket_kernel(RankBucketArgs a) {
     const uint64_t lo = kmin;                                         // ~0 when the column has no real key at all
     const uint64_t range = kmax > kmin ? kmax - kmin : 0ull;
     const int rbits = range ? 64 - __clzll((long long)range) : 0;
-    const int shift1 = rbits > LOG2K1 ? rbits - LOG2K1 : 0;          // (range >> shift1) < K1
+    // A key's place in [lo, lo + range] as a 32-bit fraction d32 = (key - lo) scaled to 32 bits (the top 32 bits of a longer
+    // offset, all bits of a shorter one): monotone in the key, which is all the buckets need -- the coarse interval is its top
+    // LOG2K1 bits, the position inside the interval the 32 - LOG2K1 bits below (round 6: the 64-bit shifts, products and
+    // differences per key of the former form were a third of the fine-bucket phase's vector instructions)
+    const int d_shr = rbits > 32 ? rbits - 32 : 0;
+    const int d_shl = rbits > 32 ? 0 : (rbits > 0 ? 32 - rbits : 0);
+#define PH_D32(k_) ((uint32_t)(((k_) - lo) >> d_shr) << d_shl)
 
     // ---- 2a. coarse histogram over key space ---------------------------------------------------------
     PH_FOR_ITEMS({
-      const uint32_t b = (uint32_t)((key[j] - lo) >> shift1);
+      const uint32_t b = PH_D32(key[j]) >> (32 - LOG2K1);
       atomicAdd(&c1[((validmask >> j) & 1ull) ? b : (uint32_t)(K1 + 1)], 1u);
     })
     __syncthreads();
@@ -357,12 +403,11 @@ colranks_bucket_kernel(RankBucketArgs a) {
     for (int j = 0; j < KPT; ++j) st[j] = 0;
     PH_FOR_ITEMS({
       const bool ok = (validmask >> j) & 1u;
-      const uint64_t d = ok ? key[j] - lo : 0ull;
-      const uint32_t b = (uint32_t)(d >> shift1);
+      const uint32_t d32 = ok ? PH_D32(key[j]) : 0u;
+      const uint32_t b = d32 >> (32 - LOG2K1);
       const uint32_t cb = c1[b], cn = c1[b + 1] - cb;
-      const uint64_t rem = d - ((uint64_t)b << shift1);
-      const uint32_t fr = shift1 >= 32 ? (uint32_t)(rem >> (shift1 - 32)) : (uint32_t)(rem << (32 - shift1));
-      uint32_t f = cb + (uint32_t)(((uint64_t)fr * cn) >> 32);
+      const uint32_t fr = d32 << LOG2K1;                               // the position inside the coarse interval, 32-bit fraction
+      uint32_t f = cb + __umulhi(fr, cn);
       f = ok ? f : (uint32_t)(CAP + 1);
       const uint32_t slot = atomicAdd(&c2[f], 1u);
       st[j] = f | (slot << 16);
@@ -449,6 +494,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
     PH_FOR_ITEMS({
       if (st[j] >> 31) lkeys[(st[j] & 0x7fffu) + ((st[j] >> 15) & 0xffu)] = key[j];
     })
+    if (tid == 0) lkeys[-1] = ~0ull;   // the probes' sentinel (the last 8 bytes of the reduction scratch in front of the keys)
     __syncthreads();
     // the in-bucket counts first (the keys die here), then the output pass
     uint64_t zeromask = 0;
@@ -462,9 +508,11 @@ colranks_bucket_kernel(RankBucketArgs a) {
       const uint64_t k = key[j];
       uint32_t less = 0, leq = 0;
       _Pragma("unroll") for (uint32_t s = 0; s < 4; ++s) {
-        const uint64_t o = lkeys[start + (s < cs ? s : 0u)];
-        less += (s < cs && o < k) ? 1u : 0u;
-        leq += (s < cs && o <= k) ? 1u : 0u;
+        // (a slot the bucket does not have reads the sentinel in front of the keys -- the largest u64, above every valid
+        // key -- so that neither count needs a mask)
+        const uint64_t o = lkeys[(int32_t)(s < cs ? start + s : 0xffffffffu)];
+        less += (o < k) ? 1u : 0u;
+        leq += (o <= k) ? 1u : 0u;
       }
       if (cs > 4u) {
         for (uint32_t s = 4; s < cs; ++s) {
@@ -538,6 +586,7 @@ colranks_bucket_kernel(RankBucketArgs a) {
     }
     __syncthreads();
     PH_STAMP(5);   // ranks -> power -> store (+ column maximum)
+#undef PH_D32
 #undef PH_GROUP
 #undef PH_FOR_ITEMS
 #undef PH_COLUMN_DESC
