@@ -1106,7 +1106,10 @@ spmm_scatter_csc_f64(ScatterArgs a) {
   // that has one.  The list is walked UN segments at a time (wave-uniform bookkeeping in scalar registers), and
   // the loads of the next group are in flight while the LDS atomics of the current one issue: the kernel was
   // bound by the L2 latency of these loads, not by the atomics.
-  constexpr int UN = 8;
+#ifndef PLAIDHIP_SCATTER_UN
+#define PLAIDHIP_SCATTER_UN 8
+#endif
+  constexpr int UN = PLAIDHIP_SCATTER_UN;   // (A/B builds: -DPLAIDHIP_SCATTER_UN=16)
 #define PLAIDHIP_FETCH_GROUP(SEGV, VALV, CNT)                                                \
   {                                                                                          \
     CNT = 0;                                                                                 \
